@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the KV quantize / dequantize / eviction path.
+
+Run ONLY in the build container, where the reference checkout is mounted read-only:
+
+    python tests/golden/make_golden.py [/root/reference]
+
+It imports the reference's own Python functions (CPU branches: src/quantization/ops.py:88-90
+and :120-133 are taken because no GPU is visible) and stores inputs + outputs as ``.npz``
+(plain arrays, loadable with ``allow_pickle=False``).  The fixtures are DATA; no reference
+source text is stored.  The reference never travels to the GPU box — these files do.
+
+Groups:
+  G1/G4  a1-a4 on slice shapes, fp32 + fp16 (+bf16), N(0,1) and heavy-tailed
+  G2     rounding / packing known-answer test
+  G3     all-zero slice
+  G5     QuantizedKVCache end-to-end (init_from_prompt_past, append_from_past,
+         to_past_key_values, estimated_bytes) for int8 / int4 / mixed
+  G6     trim_kv_sliding_window  (T<W, T==W, T>W)
+  G7     chunk_summarize_kv      (old%chunk==0, !=0, T<=keep_last, keep_last=0, re-application)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+sys.path.insert(0, REF)
+
+from src.cache.implementations import chunk_summarize_kv, trim_kv_sliding_window  # noqa: E402
+from src.quantization.ops import (  # noqa: E402
+    QuantizedKVCache,
+    dequantize_int4_per_tensor_packed,
+    dequantize_int8_per_tensor,
+    quantize_int4_per_tensor_packed,
+    quantize_int8_per_tensor,
+)
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+TD = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+
+
+def to_np(t: torch.Tensor) -> np.ndarray:
+    """bf16 has no numpy dtype: store its bit pattern as uint16."""
+    t = t.detach().contiguous()
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.int16).numpy().view(np.uint16).copy()
+    return t.numpy().copy()
+
+
+def make_input(shape, dtype, dist, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(shape, generator=g)
+    if dist == "heavy":
+        m = torch.rand(shape, generator=g) < 0.01
+        x = torch.where(m, x * 10.0, x)
+    elif dist == "tiny":
+        x = x * 1e-6
+    return x.to(TD[dtype])
+
+
+def gen_slices():
+    out = {}
+    shapes = {"gpt2": (1, 12, 1, 64), "gpt2m": (1, 16, 1, 64), "llama": (1, 8, 1, 128),
+              "odd": (2, 3, 1, 5), "one": (1, 1, 1, 1), "b2": (2, 4, 1, 16)}
+    case = 0
+    for sname, shape in shapes.items():
+        for dtype in ("f32", "f16", "bf16"):
+            for dist in ("normal", "heavy", "tiny"):
+                x = make_input(shape, dtype, dist, 1000 + case)
+                key = f"{sname}.{dtype}.{dist}"
+                q8, s8 = quantize_int8_per_tensor(x)
+                p4, s4, last = quantize_int4_per_tensor_packed(x)
+                out[key + ".x"] = to_np(x)
+                out[key + ".q8"] = to_np(q8)
+                out[key + ".s8"] = to_np(s8.reshape(1))
+                out[key + ".p4"] = to_np(p4)
+                out[key + ".s4"] = to_np(s4.reshape(1))
+                out[key + ".last"] = np.array([last], dtype=np.int64)
+                for od in ("f16", "f32", "bf16"):
+                    out[key + f".dq8.{od}"] = to_np(dequantize_int8_per_tensor(q8, s8, TD[od]))
+                    out[key + f".dq4.{od}"] = to_np(dequantize_int4_per_tensor_packed(p4, s4, last, TD[od]))
+                case += 1
+    np.savez_compressed(os.path.join(OUT, "g1_slices.npz"), **out)
+    print("g1_slices:", len(out), "arrays")
+
+
+def gen_kat():
+    out = {}
+    x = torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, 7.0, -7.0, 3.5])
+    p4, s4, last = quantize_int4_per_tensor_packed(x)
+    out["kat4.x"] = to_np(x)
+    out["kat4.p4"] = to_np(p4)
+    out["kat4.s4"] = to_np(s4.reshape(1))
+    out["kat4.dq.f16"] = to_np(dequantize_int4_per_tensor_packed(p4, s4, last, torch.float16))
+    # int8 half-to-even KAT: scale is exactly 1.0 when max|x| = 127
+    x8 = torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 126.5, 127.0, -127.0, 63.5, 0.49999, 100.5])
+    q8, s8 = quantize_int8_per_tensor(x8)
+    out["kat8.x"] = to_np(x8)
+    out["kat8.q8"] = to_np(q8)
+    out["kat8.s8"] = to_np(s8.reshape(1))
+    # zero slices (G3)
+    for dtype in ("f32", "f16", "bf16"):
+        z = torch.zeros(1, 4, 1, 8, dtype=TD[dtype])
+        q8, s8 = quantize_int8_per_tensor(z)
+        p4, s4, last = quantize_int4_per_tensor_packed(z)
+        out[f"zero.{dtype}.q8"] = to_np(q8)
+        out[f"zero.{dtype}.s8"] = to_np(s8.reshape(1))
+        out[f"zero.{dtype}.p4"] = to_np(p4)
+        out[f"zero.{dtype}.s4"] = to_np(s4.reshape(1))
+        out[f"zero.{dtype}.dq8.f16"] = to_np(dequantize_int8_per_tensor(q8, s8, torch.float16))
+        out[f"zero.{dtype}.dq4.f16"] = to_np(dequantize_int4_per_tensor_packed(p4, s4, last, torch.float16))
+    np.savez_compressed(os.path.join(OUT, "g2_kat.npz"), **out)
+    print("g2_kat:", len(out), "arrays")
+
+
+def gen_cache():
+    """G5: the container end-to-end.  Input KV is [L,2,B,H,T,D]; one extra token is appended
+    through append_from_past (ops.py:323-330, which reads k[:,:,-1:,:])."""
+    out = {}
+    cfgs = {"tiny": (2, 1, 2, 5, 8), "gpt2ish": (3, 1, 12, 9, 64), "llamaish": (2, 1, 8, 6, 128),
+            "odd": (2, 2, 3, 4, 5)}
+    case = 0
+    for cname, (L, B, H, T, D) in cfgs.items():
+        for dtype in ("f32", "f16"):
+            kv = make_input((L, 2, B, H, T + 1, D), dtype, "heavy" if case % 2 else "normal", 2000 + case)
+            out[f"{cname}.{dtype}.kv"] = to_np(kv)
+            for mode in ("int8", "int4", "mixed"):
+                qc = QuantizedKVCache(n_layers=L, mode=mode, device="cpu", compute_dtype=TD[dtype])
+                prompt = tuple((kv[l, 0, :, :, :T], kv[l, 1, :, :, :T]) for l in range(L))
+                qc.init_from_prompt_past(prompt)
+                full = tuple((kv[l, 0], kv[l, 1]) for l in range(L))
+                qc.append_from_past(full)
+                past = qc.to_past_key_values()
+                deq = torch.stack([torch.stack([k, v]) for k, v in past])  # [L,2,B,H,T+1,D]
+                key = f"{cname}.{dtype}.{mode}"
+                out[key + ".deq"] = to_np(deq)
+                out[key + ".bytes"] = np.array([qc.estimated_bytes()], dtype=np.int64)
+                # stored scales per layer per token (k then v), in the storage dtype
+                ks = torch.stack([torch.stack(layer.k_scales) for layer in qc.layers])
+                vs = torch.stack([torch.stack(layer.v_scales) for layer in qc.layers])
+                out[key + ".scales"] = to_np(torch.stack([ks, vs], dim=1))  # [L,2,T+1]
+                kq = torch.stack([torch.cat(layer.k_store, dim=2) for layer in qc.layers])
+                vq = torch.stack([torch.cat(layer.v_store, dim=2) for layer in qc.layers])
+                out[key + ".kq"] = to_np(kq)
+                out[key + ".vq"] = to_np(vq)
+            case += 1
+    np.savez_compressed(os.path.join(OUT, "g5_cache.npz"), **out)
+    print("g5_cache:", len(out), "arrays")
+
+
+def gen_evict():
+    out = {}
+    case = 0
+    # G6 sliding window
+    for dtype in ("f16", "f32"):
+        for (T, W) in ((5, 8), (8, 8), (13, 8), (40, 1)):
+            x = make_input((1, 3, T, 16), dtype, "normal", 3000 + case)
+            (k, v), = trim_kv_sliding_window(((x, x * 2),), W)
+            out[f"win.{dtype}.T{T}.W{W}.x"] = to_np(x)
+            out[f"win.{dtype}.T{T}.W{W}.k"] = to_np(k)
+            out[f"win.{dtype}.T{T}.W{W}.v"] = to_np(v)
+            case += 1
+    # G7 chunk summary
+    for dtype in ("f16", "f32", "bf16"):
+        for (T, chunk, keep) in ((40, 8, 8), (45, 8, 8), (6, 8, 8), (33, 4, 0), (300, 64, 16), (19, 64, 3)):
+            x = make_input((2, 3, T, 16), dtype, "heavy", 4000 + case)
+            (k, v), = chunk_summarize_kv(((x, -x),), chunk_size=chunk, keep_last=keep)
+            out[f"chunk.{dtype}.T{T}.c{chunk}.k{keep}.x"] = to_np(x)
+            out[f"chunk.{dtype}.T{T}.c{chunk}.k{keep}.k"] = to_np(k)
+            case += 1
+    # re-application trajectory of generate_with_chunked_cache (benchmarker.py:610-626):
+    # each decode step appends one token then re-summarises the already summarised cache.
+    T, lens = 32768, []
+    x = torch.zeros(1, 1, T, 2)
+    for _ in range(4):
+        (x, _), = chunk_summarize_kv(((x, x),), chunk_size=64, keep_last=256)
+        lens.append(x.size(2))
+        x = torch.cat([x, torch.zeros(1, 1, 1, 2)], dim=2)
+    out["chunk.trajectory"] = np.array(lens, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "g6_evict.npz"), **out)
+    print("g6_evict:", len(out), "arrays; trajectory", lens)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(42)
+    gen_slices()
+    gen_kat()
+    gen_cache()
+    gen_evict()
