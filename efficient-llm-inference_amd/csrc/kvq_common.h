@@ -1,0 +1,194 @@
+// kvq_common.h — shared device helpers for the gfx950 KV quantize/dequantize/eviction kernels.
+// CDNA4 only: wave64, 16-byte vector memory ops, no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/kvq_hip.h"
+
+namespace kvq {
+
+typedef _Float16 f16;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kBlock = 256;  // 4 waves of 64
+constexpr int kWave = 64;
+
+struct Strides {
+  int64_t g, b, h, t;
+};
+static inline Strides to_strides(const kvq_strides_t* s) { return Strides{s->g, s->b, s->h, s->t}; }
+
+// Up to KVQ_PTRS_PER_LAUNCH group base pointers travel by value in the kernarg segment, so a
+// legacy tuple of separately allocated [B,H,T,D] tensors needs no host->device table copy.
+constexpr int kPtrsPerLaunch = 128;
+struct PtrTable {
+  const void* p[kPtrsPerLaunch];
+};
+
+// ------------------------------------------------------------------ error reporting (host)
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+struct Tunables {
+  int64_t dequant_variant;       // -1 = shipped default
+  int64_t dequant_grid;          // 0 = auto
+  int64_t quant_force_two_pass;  // 0/1
+  int64_t pool_variant;
+};
+Tunables& tunables();
+
+// ------------------------------------------------------------------ element conversion
+
+template <int DT>
+struct Elem;  // storage type + widen/narrow (RN-even, what torch .float()/.to(dtype) do)
+
+template <>
+struct Elem<KVQ_F16> {
+  typedef f16 type;
+  static constexpr int size = 2;
+  __device__ static inline float widen(uint16_t bits) {
+    f16 h;
+    __builtin_memcpy(&h, &bits, 2);
+    return (float)h;
+  }
+  __device__ static inline uint32_t pack2(float a, float b) {
+    f16x2 v = {(f16)a, (f16)b};
+    uint32_t u;
+    __builtin_memcpy(&u, &v, 4);
+    return u;
+  }
+  __device__ static inline float round_trip(float v) { return (float)(f16)v; }
+};
+
+template <>
+struct Elem<KVQ_BF16> {
+  typedef __bf16 type;
+  static constexpr int size = 2;
+  __device__ static inline float widen(uint16_t bits) { return __uint_as_float((uint32_t)bits << 16); }
+  __device__ static inline uint32_t pack2(float a, float b) {
+    bf16x2 v = {(__bf16)a, (__bf16)b};
+    uint32_t u;
+    __builtin_memcpy(&u, &v, 4);
+    return u;
+  }
+  __device__ static inline float round_trip(float v) { return (float)(__bf16)v; }
+};
+
+template <>
+struct Elem<KVQ_F32> {
+  typedef float type;
+  static constexpr int size = 4;
+  __device__ static inline float round_trip(float v) { return v; }
+};
+
+// Load 8 consecutive elements (16-byte aligned for 2-byte types, 32 bytes for f32) as fp32.
+template <int DT>
+__device__ inline void load8(const void* p, float (&x)[8]) {
+  if constexpr (DT == KVQ_F32) {
+    const u32x4 a = *reinterpret_cast<const u32x4*>(p);
+    const u32x4 b = *(reinterpret_cast<const u32x4*>(p) + 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      x[i] = __uint_as_float(a[i]);
+      x[4 + i] = __uint_as_float(b[i]);
+    }
+  } else {
+    const u32x4 a = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      x[2 * i] = Elem<DT>::widen((uint16_t)(a[i] & 0xFFFFu));
+      x[2 * i + 1] = Elem<DT>::widen((uint16_t)(a[i] >> 16));
+    }
+  }
+}
+
+// Store 8 fp32 values as 8 consecutive elements of DT (RN-even), 16-byte vector stores.
+template <int DT, bool NT>
+__device__ inline void store8(void* p, const float (&x)[8]) {
+  if constexpr (DT == KVQ_F32) {
+    u32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a[i] = __float_as_uint(x[i]);
+      b[i] = __float_as_uint(x[4 + i]);
+    }
+    if constexpr (NT) {
+      __builtin_nontemporal_store(a, reinterpret_cast<u32x4*>(p));
+      __builtin_nontemporal_store(b, reinterpret_cast<u32x4*>(p) + 1);
+    } else {
+      *reinterpret_cast<u32x4*>(p) = a;
+      *(reinterpret_cast<u32x4*>(p) + 1) = b;
+    }
+  } else {
+    u32x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = Elem<DT>::pack2(x[2 * i], x[2 * i + 1]);
+    if constexpr (NT) {
+      __builtin_nontemporal_store(a, reinterpret_cast<u32x4*>(p));
+    } else {
+      *reinterpret_cast<u32x4*>(p) = a;
+    }
+  }
+}
+
+// scalar element access for the generic (any shape / stride) kernels
+template <int DT>
+__device__ inline float load1(const void* base, int64_t idx) {
+  if constexpr (DT == KVQ_F32) {
+    return reinterpret_cast<const float*>(base)[idx];
+  } else {
+    return Elem<DT>::widen(reinterpret_cast<const uint16_t*>(base)[idx]);
+  }
+}
+template <int DT>
+__device__ inline void store1(void* base, int64_t idx, float v) {
+  if constexpr (DT == KVQ_F32) {
+    reinterpret_cast<float*>(base)[idx] = v;
+  } else {
+    reinterpret_cast<uint16_t*>(base)[idx] = (uint16_t)(Elem<DT>::pack2(v, 0.0f) & 0xFFFFu);
+  }
+}
+
+// ------------------------------------------------------------------ wave64 reductions
+
+// max over aligned groups of `width` consecutive lanes (width = power of two <= 64); every
+// lane of a group receives the group's max. DPP within a 16-lane row, bpermute across rows.
+__device__ inline float group_max(float v, int width) {
+  if (width > 1) v = fmaxf(v, __shfl_xor(v, 1));
+  if (width > 2) v = fmaxf(v, __shfl_xor(v, 2));
+  if (width > 4) v = fmaxf(v, __shfl_xor(v, 4));
+  if (width > 8) v = fmaxf(v, __shfl_xor(v, 8));
+  if (width > 16) v = fmaxf(v, __shfl_xor(v, 16));
+  if (width > 32) v = fmaxf(v, __shfl_xor(v, 32));
+  return v;
+}
+
+__device__ inline float wave_max(float v) { return group_max(v, 64); }
+
+// block-wide max of non-negative floats through LDS (s_red: >= kBlock/kWave floats)
+__device__ inline float block_max_nonneg(float v, float* s_red) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_red[wave] = v;
+  __syncthreads();
+  float r = s_red[0];
+#pragma unroll
+  for (int i = 1; i < kBlock / kWave; ++i) r = fmaxf(r, s_red[i]);
+  __syncthreads();
+  return r;
+}
+
+static inline int ilog2_exact(int64_t v) {  // log2 if power of two else -1
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int s = 0;
+  while ((int64_t(1) << s) < v) ++s;
+  return s;
+}
+
+static inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace kvq

@@ -1,0 +1,317 @@
+// kvq_evict.hip — KV eviction kernels for gfx950: sliding-window compaction and chunk-summary
+// mean-pooling over [G,B,H,T,D] tensors.
+//
+// Replaces trim_kv_sliding_window (src/cache/implementations.py:124-140) and
+// chunk_summarize_kv (implementations.py:295-346).
+//
+// Roofline: HBM streams. Window compaction moves 2*esz bytes per kept element. Mean-pool reads
+// every old token once (esz*B*H*D*old) plus the kept tail, writes n_chunks + keep rows: ~64:1
+// read-dominated at chunk_size 64.
+#include "kvq_common.h"
+
+namespace kvq {
+
+// ---------------------------------------------------------------------------- window compaction
+
+struct CopyArgs {
+  PtrTable in;  // per-group source base, already advanced to the first kept token
+  Strides isb;  // source strides in BYTES
+  char* out;    // destination base of this launch's first group
+  Strides osb;  // destination strides in BYTES
+  uint32_t BH, H;
+  uint32_t segs_per_bh;  // 1 when (t,d) is contiguous on both sides, else W (one segment per token)
+  int64_t seg_bytes;     // bytes per segment
+  uint32_t cps;          // chunks per segment
+};
+
+constexpr int kCopyUnroll = 4;
+constexpr int64_t kCopyChunk = (int64_t)kBlock * 16 * kCopyUnroll;  // 16 KiB per work item
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void copy_rows_k(const CopyArgs a) {
+  const uint32_t g = blockIdx.y;
+  uint32_t item = blockIdx.x;
+  const uint32_t chunk = item % a.cps;
+  item /= a.cps;
+  const uint32_t seg = item % a.segs_per_bh;
+  const uint32_t bh = item / a.segs_per_bh;
+  const uint32_t b = bh / a.H, h = bh - b * a.H;
+  const char* src = reinterpret_cast<const char*>(a.in.p[g]) + (int64_t)b * a.isb.b + (int64_t)h * a.isb.h +
+                    (int64_t)seg * a.isb.t;
+  char* dst = a.out + (int64_t)g * a.osb.g + (int64_t)b * a.osb.b + (int64_t)h * a.osb.h + (int64_t)seg * a.osb.t;
+  const int64_t c0 = (int64_t)chunk * kCopyChunk;
+  if constexpr (VEC) {
+    u32x4 v[kCopyUnroll];
+#pragma unroll
+    for (int u = 0; u < kCopyUnroll; ++u) {
+      const int64_t o = c0 + ((int64_t)u * kBlock + threadIdx.x) * 16;
+      if (o < a.seg_bytes) v[u] = *reinterpret_cast<const u32x4*>(src + o);
+    }
+#pragma unroll
+    for (int u = 0; u < kCopyUnroll; ++u) {
+      const int64_t o = c0 + ((int64_t)u * kBlock + threadIdx.x) * 16;
+      if (o < a.seg_bytes) *reinterpret_cast<u32x4*>(dst + o) = v[u];
+    }
+  } else {  // 2-byte granularity (elem_size is 2 or 4)
+    int64_t c1 = c0 + kCopyChunk;
+    if (c1 > a.seg_bytes) c1 = a.seg_bytes;
+    for (int64_t o = c0 + (int64_t)threadIdx.x * 2; o < c1; o += kBlock * 2)
+      *reinterpret_cast<uint16_t*>(dst + o) = *reinterpret_cast<const uint16_t*>(src + o);
+  }
+}
+
+// ---------------------------------------------------------------------------- chunk mean-pool
+
+struct PoolArgs {
+  PtrTable in;
+  Strides is;  // elements
+  void* out;   // base of this launch's first group
+  Strides os;  // elements
+  uint32_t B, H, D;
+  uint32_t T, Tout;
+  uint32_t old_len, n_chunks, chunk;
+  float chunk_f;  // (float)chunk_size: the divisor, also for the ragged last chunk
+};
+
+constexpr int kPoolBatch = 8;  // independent 16-byte loads in flight per lane
+
+// Fast path: D % 8 == 0, 16-byte aligned rows. One lane owns 8 consecutive d of one output
+// token; the D/8 lanes of a token read one contiguous row per step. fp32 accumulation is
+// sequential in t (bit-reproducible, mirrored by the oracle).
+template <int DT>
+__global__ __launch_bounds__(kBlock) void chunk_pool_vec_k(const PoolArgs a, uint32_t items_per_g) {
+  const uint32_t g = blockIdx.y;
+  const uint32_t DV = a.D >> 3;
+  const uint32_t item = blockIdx.x * kBlock + threadIdx.x;
+  if (item >= items_per_g) return;
+  const uint32_t dv = item % DV;
+  uint32_t r = item / DV;
+  const uint32_t j = r % a.Tout;
+  r /= a.Tout;
+  const uint32_t h = r % a.H, b = r / a.H;
+  const char* in = reinterpret_cast<const char*>(a.in.p[g]) +
+                   ((int64_t)b * a.is.b + (int64_t)h * a.is.h + (int64_t)dv * 8) * Elem<DT>::size;
+  char* out = reinterpret_cast<char*>(a.out) +
+              ((int64_t)g * a.os.g + (int64_t)b * a.os.b + (int64_t)h * a.os.h + (int64_t)j * a.os.t + (int64_t)dv * 8) *
+                  Elem<DT>::size;
+  const int64_t tstride = a.is.t * Elem<DT>::size;
+  float acc[8];
+  if (j >= a.n_chunks) {  // recent tail: exact copy
+    load8<DT>(in + (int64_t)(a.old_len + (j - a.n_chunks)) * tstride, acc);
+    store8<DT, false>(out, acc);
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.0f;
+  const uint32_t t0 = j * a.chunk;
+  uint32_t n = a.old_len - t0;
+  if (n > a.chunk) n = a.chunk;
+  uint32_t i = 0;
+  for (; i + kPoolBatch <= n; i += kPoolBatch) {
+    float x[kPoolBatch][8];
+#pragma unroll
+    for (int u = 0; u < kPoolBatch; ++u) load8<DT>(in + (int64_t)(t0 + i + u) * tstride, x[u]);
+#pragma unroll
+    for (int u = 0; u < kPoolBatch; ++u)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += x[u][k];
+  }
+  for (; i < n; ++i) {
+    float x[8];
+    load8<DT>(in + (int64_t)(t0 + i) * tstride, x);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += x[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = acc[k] / a.chunk_f;
+  store8<DT, false>(out, acc);
+}
+
+// Generic path: any D / strides / alignment; one thread per output element.
+template <int DT>
+__global__ __launch_bounds__(kBlock) void chunk_pool_generic_k(const PoolArgs a, int64_t items_per_g) {
+  const uint32_t g = blockIdx.y;
+  const void* in = a.in.p[g];
+  for (int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x; item < items_per_g;
+       item += (int64_t)gridDim.x * kBlock) {
+    const int64_t d = item % a.D;
+    int64_t r = item / a.D;
+    const int64_t j = r % a.Tout;
+    r /= a.Tout;
+    const int64_t h = r % a.H, b = r / a.H;
+    const int64_t ibase = b * a.is.b + h * a.is.h + d;
+    const int64_t o = (int64_t)g * a.os.g + b * a.os.b + h * a.os.h + j * a.os.t + d;
+    if (j >= a.n_chunks) {
+      store1<DT>(a.out, o, load1<DT>(in, ibase + (int64_t)(a.old_len + (j - a.n_chunks)) * a.is.t));
+      continue;
+    }
+    const int64_t t0 = j * (int64_t)a.chunk;
+    int64_t n = (int64_t)a.old_len - t0;
+    if (n > a.chunk) n = a.chunk;
+    float acc = 0.0f;
+    for (int64_t i = 0; i < n; ++i) acc += load1<DT>(in, ibase + (t0 + i) * a.is.t);
+    store1<DT>(a.out, o, acc / a.chunk_f);
+  }
+}
+
+// ---------------------------------------------------------------------------- host side
+
+static int fill_ptrs(PtrTable& tbl, const void* base, const void* const* ptrs, int64_t g0, int64_t gn,
+                     int64_t stride_g_bytes, int64_t extra_bytes, const char* name) {
+  for (int64_t i = 0; i < gn; ++i) {
+    const char* p = ptrs ? static_cast<const char*>(ptrs[g0 + i])
+                         : static_cast<const char*>(base) + (g0 + i) * stride_g_bytes;
+    if (!p) {
+      set_error("%s: in_ptrs[%lld] is NULL", name, (long long)(g0 + i));
+      return KVQ_E_NULL;
+    }
+    tbl.p[i] = p + extra_bytes;
+  }
+  return 0;
+}
+
+static int common_checks(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st, void* out,
+                         const kvq_strides_t* out_st, const kvq_dims_t* d, const char* name) {
+  if (!in_st || !out_st || !d || !out || (!in_base && !in_ptrs)) {
+    set_error("%s: NULL argument", name);
+    return KVQ_E_NULL;
+  }
+  if (in_base && in_ptrs) {
+    set_error("%s: pass in_base or in_ptrs, not both", name);
+    return KVQ_E_DIMS;
+  }
+  if (d->G < 0 || d->B < 0 || d->H < 0 || d->T < 0 || d->D < 0) {
+    set_error("%s: negative dim", name);
+    return KVQ_E_DIMS;
+  }
+  if (d->B * d->H >= (int64_t(1) << 31) || d->T >= (int64_t(1) << 31) || d->D >= (int64_t(1) << 31)) {
+    set_error("%s: dims too large", name);
+    return KVQ_E_DIMS;
+  }
+  return 0;
+}
+
+}  // namespace kvq
+
+using namespace kvq;
+
+extern "C" {
+
+int kvq_window_compact(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st, void* out,
+                       const kvq_strides_t* out_st, int elem_size, int64_t window, const kvq_dims_t* d,
+                       void* stream) {
+  const char* name = "kvq_window_compact";
+  int rc = common_checks(in_base, in_ptrs, in_st, out, out_st, d, name);
+  if (rc) return rc;
+  if ((elem_size != 2 && elem_size != 4) || window < 0) {
+    set_error("%s: elem_size must be 2 or 4 and window >= 0", name);
+    return KVQ_E_DIMS;
+  }
+  const int64_t W = window < d->T ? window : d->T;
+  if (d->G * d->B * d->H * W * d->D == 0) return 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+  CopyArgs a;
+  a.isb = Strides{in_st->g * elem_size, in_st->b * elem_size, in_st->h * elem_size, in_st->t * elem_size};
+  a.osb = Strides{out_st->g * elem_size, out_st->b * elem_size, out_st->h * elem_size, out_st->t * elem_size};
+  a.BH = (uint32_t)(d->B * d->H);
+  a.H = (uint32_t)d->H;
+  const bool tcontig = in_st->t == d->D && out_st->t == d->D;
+  a.segs_per_bh = tcontig ? 1u : (uint32_t)W;
+  a.seg_bytes = (tcontig ? W * d->D : d->D) * elem_size;
+  a.cps = (uint32_t)((a.seg_bytes + kCopyChunk - 1) / kCopyChunk);
+  const int64_t blocks = (int64_t)a.BH * a.segs_per_bh * a.cps;
+  if (blocks >= (int64_t(1) << 31)) {
+    set_error("%s: too many segments", name);
+    return KVQ_E_DIMS;
+  }
+  const int64_t first_kept_bytes = (d->T - W) * a.isb.t;
+
+  for (int64_t g0 = 0; g0 < d->G; g0 += kPtrsPerLaunch) {
+    const int64_t gn = d->G - g0 < kPtrsPerLaunch ? d->G - g0 : kPtrsPerLaunch;
+    rc = fill_ptrs(a.in, in_base, in_ptrs, g0, gn, a.isb.g, first_kept_bytes, name);
+    if (rc) return rc;
+    a.out = static_cast<char*>(out) + g0 * a.osb.g;
+    bool vec = a.seg_bytes % 16 == 0 && aligned(a.out, 16) && a.isb.b % 16 == 0 && a.isb.h % 16 == 0 &&
+               a.isb.t % 16 == 0 && a.osb.g % 16 == 0 && a.osb.b % 16 == 0 && a.osb.h % 16 == 0 && a.osb.t % 16 == 0;
+    for (int64_t i = 0; i < gn && vec; ++i) vec = aligned(a.in.p[i], 16);
+    if (vec)
+      hipLaunchKernelGGL((copy_rows_k<true>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a);
+    else
+      hipLaunchKernelGGL((copy_rows_k<false>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a);
+    rc = check_launch(name);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int kvq_chunk_meanpool(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st, void* out,
+                       const kvq_strides_t* out_st, int dtype, int64_t chunk_size, int64_t keep_last,
+                       const kvq_dims_t* d, void* stream) {
+  const char* name = "kvq_chunk_meanpool";
+  int rc = common_checks(in_base, in_ptrs, in_st, out, out_st, d, name);
+  if (rc) return rc;
+  if (dtype != KVQ_F16 && dtype != KVQ_BF16 && dtype != KVQ_F32) {
+    set_error("%s: unknown dtype %d", name, dtype);
+    return KVQ_E_DTYPE;
+  }
+  if (chunk_size <= 0 || keep_last < 0 || chunk_size >= (int64_t(1) << 31)) {
+    set_error("%s: chunk_size must be > 0 and keep_last >= 0", name);
+    return KVQ_E_DIMS;
+  }
+  if (d->G * d->B * d->H * d->T * d->D == 0) return 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int esz = dtype == KVQ_F32 ? 4 : 2;
+  const int64_t keep = keep_last < d->T ? keep_last : d->T;
+  const int64_t old = d->T - keep;
+  const int64_t n_chunks = old > 0 ? (old + chunk_size - 1) / chunk_size : 0;
+  const int64_t Tout = n_chunks + keep;  // == T when old <= 0 (pure copy)
+
+  PoolArgs a;
+  a.is = to_strides(in_st);
+  a.os = to_strides(out_st);
+  a.B = (uint32_t)d->B;
+  a.H = (uint32_t)d->H;
+  a.D = (uint32_t)d->D;
+  a.T = (uint32_t)d->T;
+  a.Tout = (uint32_t)Tout;
+  a.old_len = (uint32_t)(old > 0 ? old : 0);
+  a.n_chunks = (uint32_t)n_chunks;
+  a.chunk = (uint32_t)chunk_size;
+  a.chunk_f = (float)chunk_size;
+
+  const int64_t items_vec = d->B * d->H * Tout * (d->D / 8);
+  const int64_t items_gen = d->B * d->H * Tout * d->D;
+  for (int64_t g0 = 0; g0 < d->G; g0 += kPtrsPerLaunch) {
+    const int64_t gn = d->G - g0 < kPtrsPerLaunch ? d->G - g0 : kPtrsPerLaunch;
+    rc = fill_ptrs(a.in, in_base, in_ptrs, g0, gn, a.is.g * esz, 0, name);
+    if (rc) return rc;
+    a.out = static_cast<char*>(out) + g0 * a.os.g * esz;
+    bool vec = d->D % 8 == 0 && items_vec < (int64_t(1) << 31) && aligned(a.out, 16) &&
+               (a.is.b * esz) % 16 == 0 && (a.is.h * esz) % 16 == 0 && (a.is.t * esz) % 16 == 0 &&
+               (a.os.g * esz) % 16 == 0 && (a.os.b * esz) % 16 == 0 && (a.os.h * esz) % 16 == 0 &&
+               (a.os.t * esz) % 16 == 0;
+    for (int64_t i = 0; i < gn && vec; ++i) vec = aligned(a.in.p[i], 16);
+    if (vec) {
+      const unsigned blocks = (unsigned)((items_vec + kBlock - 1) / kBlock);
+      switch (dtype) {
+        case KVQ_F16: hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_F16>), dim3(blocks, (unsigned)gn), dim3(kBlock), 0, st, a, (uint32_t)items_vec); break;
+        case KVQ_BF16: hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_BF16>), dim3(blocks, (unsigned)gn), dim3(kBlock), 0, st, a, (uint32_t)items_vec); break;
+        case KVQ_F32: hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_F32>), dim3(blocks, (unsigned)gn), dim3(kBlock), 0, st, a, (uint32_t)items_vec); break;
+      }
+    } else {
+      int64_t blocks = (items_gen + kBlock - 1) / kBlock;
+      if (blocks > 256 * 32) blocks = 256 * 32;
+      switch (dtype) {
+        case KVQ_F16: hipLaunchKernelGGL((chunk_pool_generic_k<KVQ_F16>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a, items_gen); break;
+        case KVQ_BF16: hipLaunchKernelGGL((chunk_pool_generic_k<KVQ_BF16>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a, items_gen); break;
+        case KVQ_F32: hipLaunchKernelGGL((chunk_pool_generic_k<KVQ_F32>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a, items_gen); break;
+      }
+    }
+    rc = check_launch(name);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,341 @@
+// kvq_quant.hip — per-token symmetric INT8 / packed-INT4 quantise kernels for gfx950.
+//
+// Replaces quantize_int8_per_tensor / quantize_int4_per_tensor_packed
+// (src/quantization/ops.py:10-65) as they are applied slice by slice ([B,H,1,D]) by
+// QuantizedLayerKV.append (ops.py:174-210): ONE scale per (group, token) over all B*H*D values.
+//
+//   s32    = max( max|x| / QMAX, eps )            fp32, IEEE division      (ops.py:28, :49)
+//   q      = clamp( rint(x32 / s32), QMIN, QMAX )  half-to-even, true division (ops.py:29, :50)
+//   stored = RN_in_dtype(s32), kept widened to fp32 in the scale table     (ops.py:30, :65)
+//   INT4: nibble = q + 8, even d -> high nibble, odd D padded with nibble 8 (ops.py:52-63)
+//
+// Roofline: HBM stream, single pass: 2 B in + 1 B (INT8) or 0.5 B (INT4) out per fp16 element.
+// Fused kernel: a workgroup owns a tile of TT tokens x all B*H rows of one group. Rows are T*D
+// apart in memory, so each row contributes one contiguous TT*D run (coalesced 16 B/lane
+// loads). The tile stays in registers between the abs-max pass and the quantise pass;
+// abs-max: per-lane -> wave64 shuffle over the D/8 lanes of a (row, token) -> LDS atomic max
+// across rows (per-token scales live in LDS).
+#include "kvq_common.h"
+
+namespace kvq {
+
+constexpr int kNVMax = 8;                         // 16-byte (8-element) vectors per thread per tile
+constexpr int kTileElems = kBlock * kNVMax * 8;   // 16384 elements
+constexpr int kMaxTT = 64;
+
+struct QuantArgs {
+  PtrTable in;  // per-group input base pointers (this launch's groups)
+  Strides is;   // input strides in elements (g unused)
+  uint8_t* q;   // store base for this launch's first group
+  Strides qs;   // store strides in bytes
+  float* scales;
+  int64_t ssg;
+  float* absmax_ws;  // [G, T] floats (two-pass path)
+  float eps;
+  uint32_t G, B, H, T, D;
+  // fused path
+  uint32_t R;        // B*H
+  uint32_t TT;       // tokens per tile (power of two)
+  int32_t dvshift;   // log2(D/8)
+  int32_t vshift;    // log2(TT * D/8)
+  uint32_t nvec;     // R * TT * D/8 vectors per full tile
+};
+
+template <int BITS>
+struct QRange;
+template <>
+struct QRange<8> {
+  static constexpr float qmax = 127.0f, qmin = -127.0f;
+};
+template <>
+struct QRange<4> {
+  static constexpr float qmax = 7.0f, qmin = -8.0f;
+};
+
+template <int BITS>
+__device__ inline int quant1(float x, float s32) {
+  const float r = rintf(x / s32);  // IEEE fp32 divide + round-half-even, as torch does
+  return (int)fminf(fmaxf(r, QRange<BITS>::qmin), QRange<BITS>::qmax);
+}
+
+// ---------------------------------------------------------------------------- fused single pass
+template <int IDT, int BITS>
+__global__ __launch_bounds__(kBlock) void quant_tokens_fused_k(const QuantArgs a) {
+  __shared__ uint32_t s_amax[kMaxTT];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t g = blockIdx.y;
+  const uint32_t t0 = blockIdx.x * a.TT;
+  const uint32_t DV = a.D >> 3;
+  const uint32_t wmask = (1u << a.vshift) - 1u;
+  const char* in = reinterpret_cast<const char*>(a.in.p[g]);
+
+  if (tid < kMaxTT) s_amax[tid] = 0u;
+  __syncthreads();
+
+  // pass 1: load the tile (kept in registers), per-vector abs-max
+  float x[kNVMax][8];
+  uint32_t vr[kNVMax], vtl[kNVMax], vdv[kNVMax];
+  bool valid[kNVMax];
+#pragma unroll
+  for (int i = 0; i < kNVMax; ++i) {
+    const uint32_t v = i * kBlock + tid;
+    const uint32_t r = v >> a.vshift;
+    const uint32_t wv = v & wmask;
+    const uint32_t tl = wv >> a.dvshift;
+    const uint32_t dv = wv & (DV - 1u);
+    vr[i] = r;
+    vtl[i] = tl;
+    vdv[i] = dv;
+    valid[i] = (v < a.nvec) && (t0 + tl < a.T);
+    float m = 0.0f;
+    if (valid[i]) {
+      const int64_t off = (int64_t)r * a.is.h + (int64_t)(t0 + tl) * a.is.t + (int64_t)dv * 8;
+      load8<IDT>(in + off * Elem<IDT>::size, x[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(x[i][j]));
+    }
+    // lanes of one (row, token) are DV consecutive lanes; whole waves reach the shuffles
+    if ((uint32_t)(i * kBlock) < a.nvec) {  // uniform: skip rounds no lane of the block uses
+      m = group_max(m, (int)DV);
+      if (valid[i] && dv == 0u) atomicMax(&s_amax[tl], __float_as_uint(m));
+    }
+  }
+  __syncthreads();
+
+  // pass 2: scale, round, clamp, pack, store
+#pragma unroll
+  for (int i = 0; i < kNVMax; ++i) {
+    if (!valid[i]) continue;
+    const uint32_t r = vr[i], tl = vtl[i], dv = vdv[i];
+    const float amax = __uint_as_float(s_amax[tl]);
+    const float s32 = fmaxf(amax / QRange<BITS>::qmax, a.eps);
+    uint8_t* qp = a.q + (int64_t)g * a.qs.g + (int64_t)r * a.qs.h + (int64_t)(t0 + tl) * a.qs.t;
+    if constexpr (BITS == 8) {
+      u32x2 w = {0u, 0u};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j >> 2] |= ((uint32_t)quant1<8>(x[i][j], s32) & 0xFFu) << (8 * (j & 3));
+      *reinterpret_cast<u32x2*>(qp + dv * 8) = w;
+    } else {
+      uint32_t w = 0u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t nib = (uint32_t)(quant1<4>(x[i][j], s32) + 8) & 0xFu;
+        w |= nib << (8 * (j >> 1) + ((j & 1) ? 0 : 4));  // even element = high nibble
+      }
+      *reinterpret_cast<uint32_t*>(qp + dv * 4) = w;
+    }
+    if (r == 0u && dv == 0u) a.scales[(int64_t)g * a.ssg + t0 + tl] = Elem<IDT>::round_trip(s32);
+  }
+}
+
+// ---------------------------------------------------------------------------- generic two-pass
+// Any D (odd included), any strides / alignment, any B*H*D size.
+template <int IDT>
+__global__ __launch_bounds__(kBlock) void absmax_tokens_generic_k(const QuantArgs a, uint32_t chunks_per_tok,
+                                                                  int64_t chunk_elems) {
+  __shared__ float s_red[kBlock / kWave];
+  const uint32_t g = blockIdx.y;
+  const uint32_t t = blockIdx.x / chunks_per_tok;
+  const uint32_t c = blockIdx.x - t * chunks_per_tok;
+  const int64_t RD = (int64_t)a.R * a.D;
+  const int64_t i0 = (int64_t)c * chunk_elems;
+  int64_t i1 = i0 + chunk_elems;
+  if (i1 > RD) i1 = RD;
+  const void* in = a.in.p[g];
+  float m = 0.0f;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += kBlock) {
+    const int64_t d = i % a.D;
+    const int64_t r = i / a.D;
+    const int64_t h = r % a.H;
+    const int64_t b = r / a.H;
+    m = fmaxf(m, fabsf(load1<IDT>(in, b * a.is.b + h * a.is.h + (int64_t)t * a.is.t + d)));
+  }
+  m = block_max_nonneg(m, s_red);
+  if (threadIdx.x == 0)
+    atomicMax(reinterpret_cast<uint32_t*>(a.absmax_ws) + (int64_t)g * a.T + t, __float_as_uint(m));
+}
+
+// One thread per output byte: INT8 one element, INT4 two elements (second may be the odd-D pad).
+template <int IDT, int BITS>
+__global__ __launch_bounds__(kBlock) void quant_tokens_generic_k(const QuantArgs a, int64_t total_bytes) {
+  const int64_t Dq = BITS == 8 ? a.D : (a.D + 1) / 2;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total_bytes; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t j = i % Dq;
+    int64_t r = i / Dq;
+    const int64_t t = r % a.T;
+    r /= a.T;
+    const int64_t h = r % a.H;
+    r /= a.H;
+    const int64_t b = r % a.B;
+    const int64_t g = r / a.B;
+    const float amax = a.absmax_ws[g * a.T + t];
+    const float s32 = fmaxf(amax / QRange<BITS>::qmax, a.eps);
+    const void* in = a.in.p[g];
+    const int64_t ioff = b * a.is.b + h * a.is.h + t * a.is.t;
+    uint8_t* qp = a.q + g * a.qs.g + b * a.qs.b + h * a.qs.h + t * a.qs.t;
+    if constexpr (BITS == 8) {
+      qp[j] = (uint8_t)(int8_t)quant1<8>(load1<IDT>(in, ioff + j), s32);
+    } else {
+      const int hi = quant1<4>(load1<IDT>(in, ioff + 2 * j), s32) + 8;
+      const int lo = (2 * j + 1 < (int64_t)a.D) ? quant1<4>(load1<IDT>(in, ioff + 2 * j + 1), s32) + 8 : 8;
+      qp[j] = (uint8_t)(((hi & 0xF) << 4) | (lo & 0xF));
+    }
+    if (b == 0 && h == 0 && j == 0) a.scales[g * a.ssg + t] = Elem<IDT>::round_trip(s32);
+  }
+}
+
+// ---------------------------------------------------------------------------- host side
+
+static uint32_t pow2_floor(uint64_t v) {
+  uint32_t p = 1;
+  while ((uint64_t)p * 2 <= v) p *= 2;
+  return p;
+}
+
+template <int IDT, int BITS>
+static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
+  if (fused) {
+    const unsigned tiles = (a.T + a.TT - 1) / a.TT;
+    hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
+  } else {
+    const int64_t RD = (int64_t)a.R * a.D;
+    const int64_t chunk_elems = (int64_t)kBlock * 16;
+    const uint32_t cpt = (uint32_t)((RD + chunk_elems - 1) / chunk_elems);
+    if (hipMemsetAsync(a.absmax_ws, 0, sizeof(float) * (size_t)a.G * a.T, st) != hipSuccess) return;  // surfaced by check_launch
+    hipLaunchKernelGGL((absmax_tokens_generic_k<IDT>), dim3(a.T * cpt, a.G), dim3(kBlock), 0, st, a, cpt, chunk_elems);
+    const int64_t Dq = BITS == 8 ? a.D : (a.D + 1) / 2;
+    const int64_t total = (int64_t)a.G * a.B * a.H * a.T * Dq;
+    int64_t blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL((quant_tokens_generic_k<IDT, BITS>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a, total);
+  }
+}
+
+template <int BITS>
+static int quant_tokens(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st, int in_dtype,
+                        uint8_t* q, const kvq_strides_t* q_st, float* scales, int64_t ssg, float* absmax_ws,
+                        float eps, const kvq_dims_t* d, void* stream, const char* name) {
+  if (!in_st || !q_st || !d || !q || !scales || (!in_base && !in_ptrs)) {
+    set_error("%s: NULL argument", name);
+    return KVQ_E_NULL;
+  }
+  if (in_base && in_ptrs) {
+    set_error("%s: pass in_base or in_ptrs, not both", name);
+    return KVQ_E_DIMS;
+  }
+  if (d->G < 0 || d->B < 0 || d->H < 0 || d->T < 0 || d->D < 0) {
+    set_error("%s: negative dim", name);
+    return KVQ_E_DIMS;
+  }
+  if (in_dtype != KVQ_F16 && in_dtype != KVQ_BF16 && in_dtype != KVQ_F32) {
+    set_error("%s: unknown in_dtype %d", name, in_dtype);
+    return KVQ_E_DTYPE;
+  }
+  if (d->G * d->B * d->H * d->T * d->D == 0) return 0;
+  if (d->B >= (int64_t(1) << 31) || d->H >= (int64_t(1) << 31) || d->T >= (int64_t(1) << 31) ||
+      d->D >= (int64_t(1) << 31) || d->B * d->H >= (int64_t(1) << 31)) {
+    set_error("%s: dims too large", name);
+    return KVQ_E_DIMS;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int esz = in_dtype == KVQ_F32 ? 4 : 2;
+  const int64_t R = d->B * d->H;
+  const int64_t Dq = BITS == 8 ? d->D : (d->D + 1) / 2;
+
+  QuantArgs a;
+  a.is = to_strides(in_st);
+  a.qs = to_strides(q_st);
+  a.ssg = ssg;
+  a.eps = eps;
+  a.B = (uint32_t)d->B;
+  a.H = (uint32_t)d->H;
+  a.T = (uint32_t)d->T;
+  a.D = (uint32_t)d->D;
+  a.R = (uint32_t)R;
+
+  // fused single-pass eligibility (layout); pointer alignment is checked per launch chunk below
+  const int dvshift = d->D % 8 == 0 ? ilog2_exact(d->D / 8) : -1;
+  const int64_t qvec = BITS == 8 ? 8 : 4;  // bytes stored per 8-element vector
+  bool fused = !tunables().quant_force_two_pass && dvshift >= 0 && d->D / 8 <= kWave &&
+               R * d->D <= kTileElems && (d->T == 1 || a.is.t == d->D) &&
+               (d->B == 1 || (a.is.b == d->H * a.is.h && a.qs.b == d->H * a.qs.h)) &&
+               (a.is.h * esz) % 16 == 0 && (a.is.t * esz) % 16 == 0 && a.qs.h % qvec == 0 &&
+               a.qs.t % qvec == 0 && a.qs.g % qvec == 0 && aligned(q, qvec);
+  if (fused) {
+    uint32_t tt = pow2_floor((uint64_t)(kTileElems / (R * d->D)));
+    if (tt > kMaxTT) tt = kMaxTT;
+    while (tt > 1 && tt / 2 >= (uint64_t)d->T) tt /= 2;  // do not over-tile short appends
+    a.TT = tt;
+    a.dvshift = dvshift;
+    a.vshift = dvshift + ilog2_exact(tt);
+    a.nvec = (uint32_t)(R * tt * (d->D / 8));
+  } else {
+    a.TT = 1;
+    a.dvshift = a.vshift = 0;
+    a.nvec = 0;
+    if (!absmax_ws) {
+      set_error("%s: absmax_ws workspace required for this shape (two-pass path)", name);
+      return KVQ_E_NULL;
+    }
+  }
+
+  for (int64_t g0 = 0; g0 < d->G; g0 += kPtrsPerLaunch) {
+    const int64_t gn = d->G - g0 < kPtrsPerLaunch ? d->G - g0 : kPtrsPerLaunch;
+    bool fused_here = fused;
+    for (int64_t i = 0; i < gn; ++i) {
+      const void* p = in_ptrs ? in_ptrs[g0 + i]
+                              : static_cast<const char*>(in_base) + (g0 + i) * a.is.g * (int64_t)esz;
+      if (!p) {
+        set_error("%s: in_ptrs[%lld] is NULL", name, (long long)(g0 + i));
+        return KVQ_E_NULL;
+      }
+      if (!aligned(p, 16)) fused_here = false;
+      a.in.p[i] = p;
+    }
+    if (!fused_here && !absmax_ws) {
+      set_error("%s: absmax_ws workspace required (unaligned input falls back to two-pass)", name);
+      return KVQ_E_NULL;
+    }
+    a.G = (uint32_t)gn;
+    a.q = q + g0 * a.qs.g;
+    a.scales = scales + g0 * ssg;
+    a.absmax_ws = absmax_ws ? absmax_ws + g0 * d->T : nullptr;
+    QuantArgs b = a;
+    if (!fused_here && fused) {  // re-derive generic fields
+      b.TT = 1;
+      b.dvshift = b.vshift = 0;
+      b.nvec = 0;
+    }
+    switch (in_dtype) {
+      case KVQ_F16: launch_quant<KVQ_F16, BITS>(b, fused_here, st); break;
+      case KVQ_BF16: launch_quant<KVQ_BF16, BITS>(b, fused_here, st); break;
+      case KVQ_F32: launch_quant<KVQ_F32, BITS>(b, fused_here, st); break;
+    }
+    const int rc = check_launch(name);
+    if (rc) return rc;
+  }
+  (void)Dq;
+  return 0;
+}
+
+}  // namespace kvq
+
+using namespace kvq;
+
+extern "C" {
+
+int kvq_quant_i8_tokens(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st, int in_dtype,
+                        int8_t* q, const kvq_strides_t* q_st, float* scales, int64_t scale_stride_g,
+                        float* absmax_ws, float eps, const kvq_dims_t* dims, void* stream) {
+  return quant_tokens<8>(in_base, in_ptrs, in_st, in_dtype, reinterpret_cast<uint8_t*>(q), q_st, scales,
+                         scale_stride_g, absmax_ws, eps, dims, stream, "kvq_quant_i8_tokens");
+}
+
+int kvq_quant_i4_tokens(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st, int in_dtype,
+                        uint8_t* packed, const kvq_strides_t* p_st, float* scales, int64_t scale_stride_g,
+                        float* absmax_ws, float eps, const kvq_dims_t* dims, void* stream) {
+  return quant_tokens<4>(in_base, in_ptrs, in_st, in_dtype, packed, p_st, scales, scale_stride_g, absmax_ws, eps,
+                         dims, stream, "kvq_quant_i4_tokens");
+}
+
+}  // extern "C"

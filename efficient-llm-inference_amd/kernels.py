@@ -1,0 +1,202 @@
+"""Tensor-level launchers over the C ABI (include/kvq_hip.h).
+
+Every function takes torch tensors that already live on the GPU, validates shapes on the host
+(a wrong shape must never reach a hand-written kernel), and enqueues ONE asynchronous launch
+on torch's current stream. Nothing here synchronises, allocates device memory behind the
+caller's back (except where a docstring says it returns a new tensor), or falls back to torch ops.
+
+KV sets are 5-D views ``[G, B, H, T, D]`` (G = independent scale groups: layer x K|V), or a
+list of G separately allocated ``[B, H, T, D]`` tensors (the reference's legacy tuple layout,
+reference src/quantization/ops.py:178-179).
+"""
+from __future__ import annotations
+
+from typing import Sequence, Union
+
+import torch
+
+from . import _lib
+from ._lib import KvqStrides, byref, c_void_p, check, dims5, dtype_code, require_gpu, strides4
+
+KIND_BITS = {"int8": 8, "int4": 4}
+QDTYPE = {"int8": torch.int8, "int4": torch.uint8}
+
+TensorOrList = Union[torch.Tensor, Sequence[torch.Tensor]]
+
+
+def packed_dim(kind: str, D: int) -> int:
+    """last dim of the quantised store: D int8 values or ceil(D/2) packed bytes (ops.py:54-63)"""
+    return D if kind == "int8" else (D + 1) // 2
+
+
+def _in_views(x: TensorOrList):
+    """-> (base_ptr|None, ptr_array|None, strides, (G,B,H,T,D), dtype, device, keepalive)"""
+    if isinstance(x, torch.Tensor):
+        if x.dim() != 5:
+            raise _lib.KvqError(f"kvq: expected [G,B,H,T,D], got shape {tuple(x.shape)}")
+        require_gpu(x, "input")
+        return c_void_p(x.data_ptr()), None, strides4(x), tuple(x.shape), x.dtype, x.device, x
+    xs = list(x)
+    if not xs:
+        raise _lib.KvqError("kvq: empty tensor list")
+    first = xs[0]
+    for t in xs:
+        if t.dim() != 4:
+            raise _lib.KvqError(f"kvq: expected a list of [B,H,T,D] tensors, got shape {tuple(t.shape)}")
+        require_gpu(t, "input")
+        if t.shape != first.shape or t.dtype != first.dtype or t.stride() != first.stride() or t.device != first.device:
+            # same shape, dtype AND strides: one stride triple describes every group of a launch
+            raise _lib.KvqError("kvq: all tensors of one launch must share shape, dtype, strides and device")
+    if first.size(3) > 1 and first.stride(3) != 1:
+        raise _lib.KvqError("kvq: last dim must be contiguous")
+    if len(xs) > 256:
+        raise _lib.KvqError("kvq: more than 256 tensors in one call")
+    sb, sh, st, _ = first.stride()
+    B, H, T, D = first.shape
+    arr = _lib.ptr_array([t.data_ptr() for t in xs])
+    return None, arr, KvqStrides(0, sb, sh, st), (len(xs), B, H, T, D), first.dtype, first.device, xs
+
+
+def quant_tokens(x: TensorOrList, q: torch.Tensor, scales: torch.Tensor, absmax_ws: torch.Tensor,
+                 kind: str, eps: float = 1e-8) -> None:
+    """Per-token symmetric quantise of ``x`` into the store window ``q`` and the scale table.
+
+    x       [G,B,H,T,D] (or list of G [B,H,T,D]) fp16 / bf16 / fp32
+    q       [G,B,H,T,Dq] int8 (kind="int8") or uint8 packed (kind="int4"); may be a T-window of
+            a larger [G,B,H,Tcap,Dq] store
+    scales  [G,T] fp32 window of the scale table (row stride arbitrary): receives the stored
+            scale (rounded to x's dtype) widened to fp32
+    absmax_ws fp32 workspace with >= G*T elements
+    Reference: quantize_int8_per_tensor / quantize_int4_per_tensor_packed per [B,H,1,D] slice
+    (ops.py:10-65 under ops.py:174-210, :333-342).
+    """
+    bits = KIND_BITS[kind]
+    base, arr, ist, (G, B, H, T, D), dt, dev, _keep = _in_views(x)
+    require_gpu(q, "q")
+    require_gpu(scales, "scales")
+    require_gpu(absmax_ws, "absmax_ws")
+    Dq = packed_dim(kind, D)
+    if tuple(q.shape) != (G, B, H, T, Dq) or q.dtype != QDTYPE[kind]:
+        raise _lib.KvqError(f"kvq: store window must be {(G, B, H, T, Dq)} {QDTYPE[kind]}, got {tuple(q.shape)} {q.dtype}")
+    if tuple(scales.shape) != (G, T) or scales.dtype != torch.float32 or (T > 1 and scales.stride(1) != 1):
+        raise _lib.KvqError(f"kvq: scales window must be fp32 {(G, T)} with unit token stride")
+    if absmax_ws.dtype != torch.float32 or absmax_ws.numel() < G * T or not absmax_ws.is_contiguous():
+        raise _lib.KvqError("kvq: absmax_ws must be a contiguous fp32 tensor with >= G*T elements")
+    if G * B * H * T * D == 0:
+        return
+    lib = _lib.load()
+    fn = lib.kvq_quant_i8_tokens if bits == 8 else lib.kvq_quant_i4_tokens
+    rc = fn(base, arr, byref(ist), dtype_code(dt), c_void_p(q.data_ptr()), byref(strides4(q)),
+            c_void_p(scales.data_ptr()), scales.stride(0), c_void_p(absmax_ws.data_ptr()), float(eps),
+            byref(dims5(G, B, H, T, D)), _lib.current_stream(dev))
+    check(rc, f"quant_tokens[{kind}]")
+
+
+def dequant_tokens(q: torch.Tensor, scales: torch.Tensor, out: torch.Tensor, kind: str) -> None:
+    """``out[g,b,h,t,:] = RN(float(q[g,b,h,t,:]) * scales[g,t])`` for a whole KV set, one launch.
+
+    q [G,B,H,T,Dq], scales [G,T] fp32, out [G,B,H,T,D] fp16/bf16/fp32 (windows of larger
+    buffers allowed). Reference: dequantize_*_per_tensor per slice + T-way torch.cat
+    (ops.py:68-133, :213-269).
+    """
+    bits = KIND_BITS[kind]
+    for t, n in ((q, "q"), (scales, "scales"), (out, "out")):
+        require_gpu(t, n)
+    if q.dim() != 5 or out.dim() != 5:
+        raise _lib.KvqError("kvq: q and out must be 5-D [G,B,H,T,D]")
+    G, B, H, T, D = out.shape
+    Dq = packed_dim(kind, D)
+    if tuple(q.shape) != (G, B, H, T, Dq) or q.dtype != QDTYPE[kind]:
+        raise _lib.KvqError(f"kvq: q must be {(G, B, H, T, Dq)} {QDTYPE[kind]}, got {tuple(q.shape)} {q.dtype}")
+    if tuple(scales.shape) != (G, T) or scales.dtype != torch.float32 or (T > 1 and scales.stride(1) != 1):
+        raise _lib.KvqError(f"kvq: scales must be fp32 {(G, T)} with unit token stride")
+    if G * B * H * T * D == 0:
+        return
+    lib = _lib.load()
+    fn = lib.kvq_dequant_i8_tokens if bits == 8 else lib.kvq_dequant_i4_tokens
+    rc = fn(c_void_p(q.data_ptr()), byref(strides4(q)), c_void_p(scales.data_ptr()), scales.stride(0),
+            c_void_p(out.data_ptr()), byref(strides4(out)), dtype_code(out.dtype),
+            byref(dims5(G, B, H, T, D)), _lib.current_stream(out.device))
+    check(rc, f"dequant_tokens[{kind}]")
+
+
+def dequant_i8_flat(q: torch.Tensor, scale: float) -> torch.Tensor:
+    """Reference entry ``kvq_ext.dequant_int8_to_fp16(q, scale)`` (extensions.py:70-86):
+    returns a new fp16 tensor of q's shape. q must be contiguous int8 on the GPU."""
+    require_gpu(q, "q")
+    if q.dtype != torch.int8:
+        raise _lib.KvqError("q must be int8")
+    if not q.is_contiguous():
+        raise _lib.KvqError("q must be contiguous")
+    out = torch.empty(q.shape, dtype=torch.float16, device=q.device)
+    rc = _lib.load().kvq_dequant_i8_f16_flat(c_void_p(q.data_ptr()), float(scale), c_void_p(out.data_ptr()),
+                                             q.numel(), _lib.current_stream(q.device))
+    check(rc, "dequant_i8_flat")
+    return out
+
+
+def dequant_i4_flat(packed: torch.Tensor, scale: float, orig_last_dim: int) -> torch.Tensor:
+    """Reference entry ``kvq_ext.dequant_int4_packed_to_fp16(packed, scale, orig_last_dim)``
+    (extensions.py:88-114): new fp16 tensor, last dim = 2*packed_last, pad column zeroed."""
+    require_gpu(packed, "packed")
+    if packed.dtype != torch.uint8:
+        raise _lib.KvqError("packed must be uint8")
+    if not packed.is_contiguous():
+        raise _lib.KvqError("packed must be contiguous")
+    if packed.dim() < 1:
+        raise _lib.KvqError("packed must have at least 1 dim")
+    sizes = list(packed.shape)
+    packed_last = sizes[-1]
+    sizes[-1] = packed_last * 2
+    out = torch.empty(sizes, dtype=torch.float16, device=packed.device)
+    rc = _lib.load().kvq_dequant_i4_f16_flat(c_void_p(packed.data_ptr()), float(scale), c_void_p(out.data_ptr()),
+                                             packed.numel(), packed_last, int(orig_last_dim),
+                                             _lib.current_stream(packed.device))
+    check(rc, "dequant_i4_flat")
+    return out
+
+
+def window_compact(x: TensorOrList, out: torch.Tensor, window: int) -> None:
+    """``out[g,b,h,0:W,:] = x[g,b,h,T-W:T,:]``, W = min(window, T). out: [G,B,H,W,D], same dtype.
+    Reference: trim_kv_sliding_window (src/cache/implementations.py:124-140), materialised."""
+    base, arr, ist, (G, B, H, T, D), dt, dev, _keep = _in_views(x)
+    require_gpu(out, "out")
+    W = min(int(window), T)
+    if window < 0 or tuple(out.shape) != (G, B, H, W, D) or out.dtype != dt:
+        raise _lib.KvqError(f"kvq: out must be {(G, B, H, W, D)} {dt}, got {tuple(out.shape)} {out.dtype}")
+    if dt.itemsize not in (2, 4):
+        raise _lib.KvqError(f"kvq: unsupported element size {dt.itemsize}")
+    if G * B * H * W * D == 0:
+        return
+    rc = _lib.load().kvq_window_compact(base, arr, byref(ist), c_void_p(out.data_ptr()), byref(strides4(out)),
+                                        dt.itemsize, int(window), byref(dims5(G, B, H, T, D)),
+                                        _lib.current_stream(dev))
+    check(rc, "window_compact")
+
+
+def chunk_summary_len(T: int, chunk_size: int, keep_last: int) -> int:
+    """output length of chunk_summarize_kv (implementations.py:313-345); pure host arithmetic"""
+    keep = min(int(keep_last), int(T))
+    old = T - keep
+    if old <= 0:
+        return int(T)
+    return (old + chunk_size - 1) // chunk_size + keep
+
+
+def chunk_meanpool(x: TensorOrList, out: torch.Tensor, chunk_size: int, keep_last: int) -> None:
+    """Chunk-summary mean-pool of the old tokens + exact copy of the last ``keep_last``.
+    out: [G,B,H,chunk_summary_len(T),D], same dtype. Reference: chunk_summarize_kv
+    (implementations.py:295-346)."""
+    base, arr, ist, (G, B, H, T, D), dt, dev, _keep = _in_views(x)
+    require_gpu(out, "out")
+    if chunk_size <= 0 or keep_last < 0:
+        raise _lib.KvqError("kvq: chunk_size must be > 0 and keep_last >= 0")
+    Tout = chunk_summary_len(T, chunk_size, keep_last)
+    if tuple(out.shape) != (G, B, H, Tout, D) or out.dtype != dt:
+        raise _lib.KvqError(f"kvq: out must be {(G, B, H, Tout, D)} {dt}, got {tuple(out.shape)} {out.dtype}")
+    if G * B * H * T * D == 0:
+        return
+    rc = _lib.load().kvq_chunk_meanpool(base, arr, byref(ist), c_void_p(out.data_ptr()), byref(strides4(out)),
+                                        dtype_code(dt), int(chunk_size), int(keep_last),
+                                        byref(dims5(G, B, H, T, D)), _lib.current_stream(dev))
+    check(rc, "chunk_meanpool")

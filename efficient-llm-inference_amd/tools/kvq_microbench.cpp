@@ -1,0 +1,200 @@
+// kvq_microbench — standalone HIP-event micro-benchmark of libkvq_hip.so on the GPU box.
+//
+//   kvq_microbench [dequant4|dequant8|quant4|quant8|pool|window|copy|all] [iters]
+//
+// Sweeps the dequantise tuning variants / grid sizes at the Llama-3-8B seq-16K KV shape
+// (BASELINE config 4: G=32, B=1, H=8, T=16384, D=128) and prints algorithmic GB/s
+// (SURVEY §8d bytes) per variant, next to two calibration kernels measured in the same process:
+// a 16 B/lane copy and a 16 B/lane fill (the box's achievable stream rates).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "kvq_hip.h"
+
+#define HIP_OK(x)                                                                      \
+  do {                                                                                 \
+    hipError_t e_ = (x);                                                               \
+    if (e_ != hipSuccess) {                                                            \
+      fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      exit(2);                                                                         \
+    }                                                                                  \
+  } while (0)
+#define KVQ_OK(x)                                                              \
+  do {                                                                         \
+    int rc_ = (x);                                                             \
+    if (rc_ != 0) {                                                            \
+      fprintf(stderr, "%s:%d %s -> %d %s\n", __FILE__, __LINE__, #x, rc_, kvq_last_error_string()); \
+      exit(3);                                                                 \
+    }                                                                          \
+  } while (0)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void copy16_k(const u32x4* __restrict__ in, u32x4* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = in[i];
+}
+__global__ __launch_bounds__(256) void fill16_k(u32x4* __restrict__ out, int64_t n, uint32_t v) {
+  u32x4 x = {v, v + 1, v + 2, v + 3};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = x;
+}
+__global__ __launch_bounds__(256) void read16_k(const u32x4* __restrict__ in, uint32_t* sink, int64_t n) {
+  u32x4 acc = {0, 0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc ^= in[i];
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
+}
+__global__ void rand_fill_k(uint32_t* p, int64_t n_words, uint32_t seed) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * 256) {
+    uint32_t x = (uint32_t)i * 2654435761u + seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    p[i] = x;
+  }
+}
+// fp16 N(0,1)-ish values from hashed bits (sum of 4 uniforms), so quantise sees realistic data
+__global__ void rand_f16_k(uint16_t* p, int64_t n, uint32_t seed) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    uint32_t x = (uint32_t)i * 2654435761u + seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    float u = ((x & 0xFF) + ((x >> 8) & 0xFF) + ((x >> 16) & 0xFF) + (x >> 24)) * (1.0f / 255.0f) - 2.0f;
+    _Float16 h = (_Float16)(u * 1.7f);
+    __builtin_memcpy(&p[i], &h, 2);
+  }
+}
+
+struct Timer {
+  hipEvent_t a, b;
+  Timer() { HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); }
+  template <class F>
+  double ms_per(F f, int iters, int warm = 3) {
+    for (int i = 0; i < warm; ++i) f();
+    HIP_OK(hipEventRecord(a, 0));
+    for (int i = 0; i < iters; ++i) f();
+    HIP_OK(hipEventRecord(b, 0));
+    HIP_OK(hipEventSynchronize(b));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, a, b));
+    return ms / iters;
+  }
+};
+
+static const int64_t G = 32, B = 1, H = 8, T = 16384, D = 128;
+
+int main(int argc, char** argv) {
+  std::string what = argc > 1 ? argv[1] : "all";
+  int iters = argc > 2 ? atoi(argv[2]) : 20;
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, 0));
+  printf("# device %s CUs=%d  shape G=%lld B=%lld H=%lld T=%lld D=%lld iters=%d\n", prop.gcnArchName,
+         prop.multiProcessorCount, (long long)G, (long long)B, (long long)H, (long long)T, (long long)D, iters);
+  const int64_t N = G * B * H * T * D;  // 536,870,912 elements
+  Timer tm;
+
+  void *q8, *q4, *out, *in16;
+  float *scales, *ws;
+  HIP_OK(hipMalloc(&q8, N));
+  HIP_OK(hipMalloc(&q4, N / 2));
+  HIP_OK(hipMalloc(&out, N * 2));
+  HIP_OK(hipMalloc(&in16, N * 2));
+  HIP_OK(hipMalloc(&scales, G * T * 4));
+  HIP_OK(hipMalloc(&ws, G * T * 4));
+  rand_fill_k<<<4096, 256>>>((uint32_t*)q8, N / 4, 1u);
+  rand_fill_k<<<4096, 256>>>((uint32_t*)q4, N / 8, 2u);
+  rand_f16_k<<<4096, 256>>>((uint16_t*)in16, N, 3u);
+  {
+    std::vector<float> s(G * T);
+    for (size_t i = 0; i < s.size(); ++i) s[i] = 0.01f + 1e-6f * (float)(i % 977);
+    HIP_OK(hipMemcpy(scales, s.data(), s.size() * 4, hipMemcpyHostToDevice));
+  }
+  HIP_OK(hipDeviceSynchronize());
+
+  kvq_dims_t dims = {G, B, H, T, D};
+  kvq_strides_t s_full = {B * H * T * D, H * T * D, T * D, D};
+  kvq_strides_t s_half = {B * H * T * D / 2, H * T * D / 2, T * D / 2, D / 2};
+
+  if (what == "copy" || what == "all") {
+    const int64_t n16 = N * 2 / 16;  // 1 GiB
+    for (int grid : {2048, 4096, 16384, 65536}) {
+      double ms = tm.ms_per([&] { copy16_k<<<grid, 256>>>((const u32x4*)in16, (u32x4*)out, n16); }, iters);
+      printf("calib copy16   grid=%6d  %8.3f ms  %8.1f GB/s (r+w)\n", grid, ms, 2.0 * N * 2 / ms / 1e6);
+    }
+    for (int grid : {2048, 4096, 16384, 65536}) {
+      double ms = tm.ms_per([&] { fill16_k<<<grid, 256>>>((u32x4*)out, n16, 7u); }, iters);
+      printf("calib fill16   grid=%6d  %8.3f ms  %8.1f GB/s (w)\n", grid, ms, 1.0 * N * 2 / ms / 1e6);
+    }
+    for (int grid : {2048, 4096, 16384}) {
+      double ms = tm.ms_per([&] { read16_k<<<grid, 256>>>((const u32x4*)in16, (uint32_t*)ws, n16); }, iters);
+      printf("calib read16   grid=%6d  %8.3f ms  %8.1f GB/s (r)\n", grid, ms, 1.0 * N * 2 / ms / 1e6);
+    }
+  }
+
+  auto sweep_dequant = [&](int bits) {
+    const double bytes = bits == 4 ? N * 2.5 : N * 3.0;
+    for (int v = 0; v < 12; ++v) {
+      for (int64_t grid : {(int64_t)0, (int64_t)2048, (int64_t)4096, (int64_t)8192}) {
+        KVQ_OK(kvq_set_tunable("dequant_variant", v));
+        KVQ_OK(kvq_set_tunable("dequant_grid", grid));
+        double ms = tm.ms_per(
+            [&] {
+              if (bits == 4)
+                KVQ_OK(kvq_dequant_i4_tokens((const uint8_t*)q4, &s_half, scales, T, out, &s_full, KVQ_F16, &dims, 0));
+              else
+                KVQ_OK(kvq_dequant_i8_tokens((const int8_t*)q8, &s_full, scales, T, out, &s_full, KVQ_F16, &dims, 0));
+            },
+            iters);
+        printf("dequant_i%d variant=%2d grid=%5lld  %8.3f ms  %8.1f GB/s  frac8T=%.3f\n", bits, v, (long long)grid, ms,
+               bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0);
+      }
+    }
+    KVQ_OK(kvq_set_tunable("dequant_variant", -1));
+    KVQ_OK(kvq_set_tunable("dequant_grid", 0));
+  };
+  if (what == "dequant4" || what == "all") sweep_dequant(4);
+  if (what == "dequant8" || what == "all") sweep_dequant(8);
+
+  auto run_quant = [&](int bits) {
+    const double bytes = bits == 4 ? N * 2.5 : N * 3.0;
+    for (int two_pass = 0; two_pass < 2; ++two_pass) {
+      KVQ_OK(kvq_set_tunable("quant_force_two_pass", two_pass));
+      double ms = tm.ms_per(
+          [&] {
+            if (bits == 4)
+              KVQ_OK(kvq_quant_i4_tokens(in16, nullptr, &s_full, KVQ_F16, (uint8_t*)q4, &s_half, scales, T, ws, 1e-8f, &dims, 0));
+            else
+              KVQ_OK(kvq_quant_i8_tokens(in16, nullptr, &s_full, KVQ_F16, (int8_t*)q8, &s_full, scales, T, ws, 1e-8f, &dims, 0));
+          },
+          two_pass ? 3 : iters, 1);
+      printf("quant_i%d  two_pass=%d  %8.3f ms  %8.1f GB/s (algorithmic single-pass bytes)  frac8T=%.3f\n", bits, two_pass,
+             ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0);
+    }
+    KVQ_OK(kvq_set_tunable("quant_force_two_pass", 0));
+  };
+  if (what == "quant4" || what == "all") run_quant(4);
+  if (what == "quant8" || what == "all") run_quant(8);
+
+  if (what == "pool" || what == "all") {
+    // chunk summary of the fp16 KV: chunk 64, keep_last 256 (CacheConfig defaults)
+    const int64_t Tout = kvq_chunk_summary_len(T, 64, 256);
+    kvq_strides_t s_out = {B * H * Tout * D, H * Tout * D, Tout * D, D};
+    const double bytes = 2.0 * G * B * H * D * (T + Tout);
+    double ms = tm.ms_per([&] { KVQ_OK(kvq_chunk_meanpool(in16, nullptr, &s_full, out, &s_out, KVQ_F16, 64, 256, &dims, 0)); }, iters);
+    printf("chunk_meanpool T=%lld->%lld  %8.3f ms  %8.1f GB/s  frac8T=%.3f\n", (long long)T, (long long)Tout, ms,
+           bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0);
+  }
+  if (what == "window" || what == "all") {
+    for (int64_t W : {(int64_t)256, (int64_t)8192}) {
+      kvq_strides_t s_out = {B * H * W * D, H * W * D, W * D, D};
+      const double bytes = 4.0 * G * B * H * W * D;
+      double ms = tm.ms_per([&] { KVQ_OK(kvq_window_compact(in16, nullptr, &s_full, out, &s_out, 2, W, &dims, 0)); }, iters);
+      printf("window_compact W=%lld  %8.3f ms  %8.1f GB/s  frac8T=%.3f\n", (long long)W, ms, bytes / ms / 1e6,
+             bytes / ms / 1e6 / 8000.0);
+    }
+  }
+  HIP_OK(hipDeviceSynchronize());
+  printf("# done\n");
+  return 0;
+}

@@ -1,0 +1,160 @@
+/*
+ * kvq_hip.h — C ABI of libkvq_hip.so: MI355X (gfx950) KV-cache quantize / dequantize /
+ * eviction kernels.
+ *
+ * This is the drop-in boundary for the reference's native plugin `kvq_ext`
+ * (reference src/cuda/extensions.py:116-119, a pybind11 module JIT-built from an inline
+ * CUDA string) and for the torch-op arithmetic of src/quantization/ops.py and
+ * src/cache/implementations.py that the MI355X build moves into HIP.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, sizes, strides; no torch / C++ types.
+ *   - the library never allocates, frees or retains memory; every buffer is the caller's.
+ *   - every entry point returns 0 on success, a negative KVQ_E_* code for argument errors,
+ *     or a positive hipError_t for launch errors; kvq_last_error_string() describes the last
+ *     failure on the calling thread.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream). All work is
+ *     enqueued asynchronously; there is NO host synchronisation anywhere on the path
+ *     (the reference syncs once per call through float(scale), ops.py:87,117).
+ *   - stateless and re-entrant; safe to call from several host threads.
+ *
+ * KV views.  A KV tensor set is addressed as [G, B, H, T, D] with the last dim contiguous:
+ *   G  independent scale groups (layer x K|V); never share a scale
+ *   B,H batch rows and heads; ONE scale spans all B*H*D values of a token (ops.py:27,48:
+ *       abs().max() over the whole [B,H,1,D] slice)
+ *   T  tokens, D head_dim.
+ * Strides are in ELEMENTS of the pointed-to type. The reference's legacy tuple
+ * tuple_L[(k, v)] of [B,H,T,D] tensors (ops.py:178-179,217) is G = 2L views that live in
+ * separate allocations: pass them as a host array of G device pointers (`*_ptrs`), or pass a
+ * single base + strides.g when they are one buffer.
+ *
+ * Scale tables.  scales[g * scale_stride_g + t] is the STORED scale of token t widened to
+ * fp32: the reference computes the scale in fp32, quantises with that fp32 value and stores
+ * it rounded to the input dtype (ops.py:26-30,47-50,65); dequantisation widens the stored
+ * value (ops.py:87,90,117,133). The quantise kernels reproduce exactly that split.
+ */
+#ifndef KVQ_HIP_H
+#define KVQ_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KVQ_VERSION 100 /* 0.1.0 */
+
+/* floating-point element types of KV tensors */
+#define KVQ_F16 0
+#define KVQ_BF16 1
+#define KVQ_F32 2
+
+/* argument errors (negative); launch errors are positive hipError_t values */
+#define KVQ_E_NULL (-1)      /* required pointer is NULL */
+#define KVQ_E_DIMS (-2)      /* negative / inconsistent dims or strides */
+#define KVQ_E_DTYPE (-3)     /* unknown dtype code */
+#define KVQ_E_ALIGN (-4)     /* flat entry point needs a layout it was not given */
+#define KVQ_E_TOO_MANY (-5)  /* more than KVQ_MAX_PTRS pointers in one call */
+
+#define KVQ_MAX_PTRS 256 /* pointer-list entry points chunk internally; this is the cap per call */
+
+typedef struct {
+  int64_t G, B, H, T, D;
+} kvq_dims_t;
+
+typedef struct {
+  int64_t g, b, h, t; /* element strides; the D stride is 1 */
+} kvq_strides_t;
+
+int kvq_version(void);
+const char* kvq_last_error_string(void);
+
+/* ---- reference-equivalent flat entry points (one host scalar scale per launch) ---------- */
+
+/* Replaces kvq_ext.dequant_int8_to_fp16(Tensor q, double scale) — extensions.py:70-86,
+ * kernel :37-48: out[i] = half(float(q[i]) * scale), n elements, q and out contiguous. */
+int kvq_dequant_i8_f16_flat(const int8_t* q, float scale, void* out_f16, int64_t n, void* stream);
+
+/* Replaces kvq_ext.dequant_int4_packed_to_fp16(Tensor packed, double scale, int64 orig_last_dim)
+ * — extensions.py:88-114, kernel :50-68. `packed` holds n_packed bytes, rows of `packed_last`
+ * bytes; out holds 2*n_packed halves, rows of 2*packed_last. Even index = HIGH nibble (:61),
+ * value (nibble-8)*scale, columns >= orig_last_dim written as 0 (:65-66). */
+int kvq_dequant_i4_f16_flat(const uint8_t* packed, float scale, void* out_f16, int64_t n_packed,
+                            int64_t packed_last, int64_t orig_last_dim, void* stream);
+
+/* ---- token-table dequantise: a whole layer set per launch -------------------------------- */
+
+/* Replaces the 2*L*T per-slice dequantize_int8_per_tensor calls + T-way torch.cat of
+ * QuantizedLayerKV.get_kv (ops.py:213-269) / QuantizedKVCache.to_past_key_values (:345-355).
+ * q [G,B,H,T,D] int8 (strides q_st) -> out [G,B,H,T,D] of out_dtype (strides out_st).
+ * out = RN_out(float(q) * scales[g,t]). */
+int kvq_dequant_i8_tokens(const int8_t* q, const kvq_strides_t* q_st, const float* scales,
+                          int64_t scale_stride_g, void* out, const kvq_strides_t* out_st,
+                          int out_dtype, const kvq_dims_t* dims, void* stream);
+
+/* Same for packed INT4 (dequantize_int4_per_tensor_packed, ops.py:93-133). dims->D is the
+ * UNPACKED head_dim (orig_last_dim); packed rows hold (D+1)/2 bytes; p_st strides are in bytes. */
+int kvq_dequant_i4_tokens(const uint8_t* packed, const kvq_strides_t* p_st, const float* scales,
+                          int64_t scale_stride_g, void* out, const kvq_strides_t* out_st,
+                          int out_dtype, const kvq_dims_t* dims, void* stream);
+
+/* ---- token-table quantise ---------------------------------------------------------------- */
+
+/* Replaces quantize_int8_per_tensor (ops.py:10-30) applied per token slice by
+ * QuantizedLayerKV.append (ops.py:174-210) under init_from_prompt_past (:333-342) /
+ * append_from_past (:323-330).
+ *   in:  [G,B,H,T,D] of in_dtype. Either in_ptrs (HOST array of G device pointers, strides.g
+ *        ignored) or in_base (+ in_st->g); exactly one of them non-NULL.
+ *   q:   [G,B,H,T,D] int8 store, strides q_st (a window of a larger [.., Tcap, D] store).
+ *   scales: stored scale widened to fp32, scales[g*scale_stride_g + t].
+ *   absmax_ws: caller workspace of G*T floats (used by the two-pass path; contents undefined
+ *        afterwards).
+ *   s32 = max(max|x| / 127, eps) in fp32; q = clamp(rint(x / s32), -127, 127);
+ *   stored = RN_in_dtype(s32). */
+int kvq_quant_i8_tokens(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st,
+                        int in_dtype, int8_t* q, const kvq_strides_t* q_st, float* scales,
+                        int64_t scale_stride_g, float* absmax_ws, float eps,
+                        const kvq_dims_t* dims, void* stream);
+
+/* Same for quantize_int4_per_tensor_packed (ops.py:33-65): s32 = max(max|x|/7, eps);
+ * q = clamp(rint(x/s32), -8, 7); nibble = q+8; even d -> high nibble; odd D padded with
+ * nibble 8 (ops.py:54-59). packed rows hold (D+1)/2 bytes; p_st in bytes. */
+int kvq_quant_i4_tokens(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st,
+                        int in_dtype, uint8_t* packed, const kvq_strides_t* p_st, float* scales,
+                        int64_t scale_stride_g, float* absmax_ws, float eps,
+                        const kvq_dims_t* dims, void* stream);
+
+/* ---- eviction ---------------------------------------------------------------------------- */
+
+/* Replaces trim_kv_sliding_window (src/cache/implementations.py:124-140), materialised:
+ * out[g,b,h,0:W,:] = in[g,b,h,T-W:T,:] with W = min(window, T). The reference returns views
+ * and leaves the byte movement to the next torch.cat; a persistent buffer must compact.
+ * in and out must not overlap. elem_size is 2 or 4 bytes. */
+int kvq_window_compact(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st,
+                       void* out, const kvq_strides_t* out_st, int elem_size, int64_t window,
+                       const kvq_dims_t* dims, void* stream);
+
+/* Replaces chunk_summarize_kv (implementations.py:295-346) on [G,B,H,T,D]:
+ *   keep = min(keep_last, T); old = T - keep; n = ceil(old / chunk_size)
+ *   out[.., j, :]     = RN_dtype( (sum_{i<chunk_size, j*chunk_size+i<old} in[.., j*chunk_size+i, :]) / chunk_size )   j < n
+ *   out[.., n + i, :] = in[.., old + i, :]                                                  i < keep
+ * fp32 accumulation, sequential in t; divisor is chunk_size even for the ragged last chunk
+ * (zero padding, :326-333). If old <= 0 the call copies in to out unchanged (T rows).
+ * Output has kvq_chunk_summary_len(T, chunk_size, keep_last) tokens. */
+int kvq_chunk_meanpool(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st,
+                       void* out, const kvq_strides_t* out_st, int dtype, int64_t chunk_size,
+                       int64_t keep_last, const kvq_dims_t* dims, void* stream);
+
+int64_t kvq_chunk_summary_len(int64_t T, int64_t chunk_size, int64_t keep_last);
+
+/* ---- tuning knobs (benchmarks only; defaults are what ships) ----------------------------- */
+
+/* key: "dequant_variant" (0..), "dequant_grid" (blocks, 0 = auto), "quant_force_two_pass" (0/1).
+ * Returns 0, or KVQ_E_DIMS for an unknown key. Process-global. */
+int kvq_set_tunable(const char* key, int64_t value);
+int64_t kvq_get_tunable(const char* key);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KVQ_HIP_H */

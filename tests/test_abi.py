@@ -1,0 +1,109 @@
+"""CPU-side checks of the drop-in boundary: libkvq_hip.so loads without a GPU, exports every
+symbol include/kvq_hip.h declares, and rejects bad arguments before touching the device.
+No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from tests.conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "kvq_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from efficient_llm_inference_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.load()
+
+
+def _declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(kvq_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(lib):
+    from efficient_llm_inference_amd import _lib
+    declared = _declared_symbols()
+    assert len(declared) >= 13
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in kvq_hip.h but not exported"
+    assert sorted(_lib.EXPORTS) == declared, "python binding list and header disagree"
+
+
+def test_version_and_error_string(lib):
+    assert lib.kvq_version() == 100
+    assert isinstance(lib.kvq_last_error_string(), bytes)
+
+
+def test_argument_errors_before_any_launch(lib):
+    from efficient_llm_inference_amd._lib import KvqDims, KvqStrides, byref
+    st, dm = KvqStrides(0, 0, 0, 0), KvqDims(1, 1, 1, 1, 8)
+    rc = lib.kvq_dequant_i8_tokens(None, byref(st), None, 0, None, byref(st), 0, byref(dm), None)
+    assert rc == -1 and b"NULL" in lib.kvq_last_error_string()
+    rc = lib.kvq_dequant_i4_f16_flat(None, 1.0, None, 10, 3, 5, None)  # 10 % 3 != 0
+    assert rc == -2
+    rc = lib.kvq_dequant_i8_f16_flat(None, 1.0, None, -1, None)
+    assert rc == -2
+    rc = lib.kvq_dequant_i8_f16_flat(None, 1.0, None, 0, None)  # empty input: ok, no launch
+    assert rc == 0
+    fake = ctypes.c_void_p(0x1000)
+    rc = lib.kvq_quant_i8_tokens(fake, None, byref(st), 7, fake, byref(st), fake, 0, fake, 1e-8, byref(dm), None)
+    assert rc == -3  # unknown dtype
+    dm0 = KvqDims(0, 1, 1, 1, 8)
+    rc = lib.kvq_quant_i8_tokens(fake, None, byref(st), 0, fake, byref(st), fake, 0, fake, 1e-8, byref(dm0), None)
+    assert rc == 0  # empty: nothing launched
+    rc = lib.kvq_window_compact(fake, None, byref(st), fake, byref(st), 3, 4, byref(dm), None)
+    assert rc == -2  # elem_size must be 2 or 4
+    rc = lib.kvq_chunk_meanpool(fake, None, byref(st), fake, byref(st), 0, 0, 4, byref(dm), None)
+    assert rc == -2  # chunk_size must be > 0
+
+
+def test_chunk_summary_len_matches_reference_trajectory(lib):
+    from efficient_llm_inference_amd.kernels import chunk_summary_len
+    T, lens = 32768, []
+    for _ in range(4):
+        T = lib.kvq_chunk_summary_len(T, 64, 256)
+        assert T == chunk_summary_len(lens[-1] + 1 if lens else 32768, 64, 256)
+        lens.append(T)
+        T += 1
+    assert lens == [764, 264, 257, 257]  # SURVEY §3.3, reference benchmarker.py:610-626
+    assert lib.kvq_chunk_summary_len(6, 8, 8) == 6 and lib.kvq_chunk_summary_len(33, 4, 0) == 9
+
+
+def test_tunables(lib):
+    assert lib.kvq_set_tunable(b"dequant_variant", 3) == 0 and lib.kvq_get_tunable(b"dequant_variant") == 3
+    assert lib.kvq_set_tunable(b"dequant_variant", -1) == 0
+    assert lib.kvq_set_tunable(b"nope", 1) == -2
+
+
+def test_no_cpu_fallback_in_product():
+    """The product package must not import the oracle nor compute on CPU tensors."""
+    import torch
+    import efficient_llm_inference_amd as E
+    pkg = os.path.join(ROOT, "efficient-llm-inference_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+    x = torch.randn(1, 2, 1, 8)
+    for fn in (E.quantize_int8_per_tensor, E.quantize_int4_per_tensor_packed):
+        with pytest.raises(RuntimeError):
+            fn(x)
+    with pytest.raises(RuntimeError):
+        E.dequantize_int8_per_tensor(torch.zeros(4, dtype=torch.int8), torch.tensor(1.0), torch.float16)
+    with pytest.raises(RuntimeError):
+        E.chunk_summarize_kv(((torch.randn(1, 1, 40, 8), torch.randn(1, 1, 40, 8)),), 8, 8)
+    qc = E.QuantizedKVCache(2, "mixed", device="cpu", compute_dtype=torch.float32)
+    with pytest.raises(RuntimeError):
+        qc.init_from_prompt_past(((x, x), (x, x)))
+    with pytest.raises(AssertionError):
+        E.QuantizedKVCache(1, "int2")
+    with pytest.raises(ValueError, match="Empty cache"):
+        E.QuantizedLayerKV("int8").get_kv()

@@ -1,0 +1,300 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs golden vectors captured from the
+reference and vs the CPU oracle on seeded inputs.  Run on a real MI355X: ``pytest -m gpu``.
+
+Bar: bit-exact for int8 values, packed nibbles, stored scales AND dequantised values
+(compared as raw bytes, so -0.0 != +0.0); chunk mean-pool bit-exact vs the oracle (same
+summation order) and within 1 storage ulp of the reference's goldens.
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kvq_oracle as O
+from tests.util import TD, bits, odt, seeded_kv, to_numpy, to_torch
+
+pytestmark = pytest.mark.gpu
+
+SLICES = ["gpt2", "gpt2m", "llama", "odd", "one", "b2"]
+DTYPES = ["f32", "f16", "bf16"]
+DISTS = ["normal", "heavy", "tiny"]
+
+
+@pytest.fixture(scope="module")
+def E():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import efficient_llm_inference_amd as pkg
+    from efficient_llm_inference_amd import _lib
+    _lib.load()  # fail loudly if the HIP library is missing
+    return pkg
+
+
+# ------------------------------------------------------------------ goldens: per-tensor API
+
+
+@pytest.mark.parametrize("sname", SLICES)
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_golden_quantize_per_tensor(E, g1, sname, dtype):
+    for dist in DISTS:
+        key = f"{sname}.{dtype}.{dist}"
+        x = to_torch(g1[key + ".x"], dtype)
+        q8, s8 = E.quantize_int8_per_tensor(x)
+        p4, s4, last = E.quantize_int4_per_tensor_packed(x)
+        assert q8.dtype == torch.int8 and p4.dtype == torch.uint8 and s8.dtype == x.dtype and s8.dim() == 0
+        assert np.array_equal(to_numpy(q8), g1[key + ".q8"]), key
+        assert np.array_equal(to_numpy(p4), g1[key + ".p4"]), key
+        assert np.array_equal(bits(s8.reshape(1)), bits(g1[key + ".s8"])), key
+        assert np.array_equal(bits(s4.reshape(1)), bits(g1[key + ".s4"])), key
+        assert last == int(g1[key + ".last"][0])
+
+
+@pytest.mark.parametrize("sname", SLICES)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("od", DTYPES)
+def test_golden_dequantize_per_tensor(E, g1, sname, dtype, od):
+    for dist in DISTS:
+        key = f"{sname}.{dtype}.{dist}"
+        q8 = to_torch(g1[key + ".q8"])
+        p4 = to_torch(g1[key + ".p4"])
+        s8 = to_torch(g1[key + ".s8"], dtype).reshape(())
+        s4 = to_torch(g1[key + ".s4"], dtype).reshape(())
+        d8 = E.dequantize_int8_per_tensor(q8, s8, TD[od])
+        d4 = E.dequantize_int4_per_tensor_packed(p4, s4, int(g1[key + ".last"][0]), TD[od])
+        assert np.array_equal(bits(d8), bits(g1[key + f".dq8.{od}"])), key
+        assert np.array_equal(bits(d4), bits(g1[key + f".dq4.{od}"])), key
+
+
+def test_golden_kat_and_zero(E, g2):
+    x = to_torch(g2["kat4.x"])
+    p4, s4, last = E.quantize_int4_per_tensor_packed(x)
+    assert bytes(to_numpy(p4)).hex() == "8aa86f1c" and float(s4) == 1.0 and last == 8
+    assert np.array_equal(to_numpy(E.dequantize_int4_per_tensor_packed(p4, s4, 8, torch.float16)), g2["kat4.dq.f16"])
+    q8, s8 = E.quantize_int8_per_tensor(to_torch(g2["kat8.x"]))
+    assert np.array_equal(to_numpy(q8), g2["kat8.q8"]) and float(s8) == 1.0
+    for dtype in DTYPES:
+        z = torch.zeros(1, 4, 1, 8, dtype=TD[dtype], device="cuda")
+        q8, s8 = E.quantize_int8_per_tensor(z)
+        p4, s4, _ = E.quantize_int4_per_tensor_packed(z)
+        assert np.array_equal(to_numpy(q8), g2[f"zero.{dtype}.q8"])
+        assert np.array_equal(to_numpy(p4), g2[f"zero.{dtype}.p4"])
+        assert np.array_equal(bits(s8.reshape(1)), bits(g2[f"zero.{dtype}.s8"]))
+        assert np.array_equal(bits(s4.reshape(1)), bits(g2[f"zero.{dtype}.s4"]))
+        assert np.array_equal(bits(E.dequantize_int8_per_tensor(q8, s8, torch.float16)), bits(g2[f"zero.{dtype}.dq8.f16"]))
+        assert np.array_equal(bits(E.dequantize_int4_per_tensor_packed(p4, s4, 8, torch.float16)), bits(g2[f"zero.{dtype}.dq4.f16"]))
+
+
+# ------------------------------------------------------------------ goldens: the container
+
+
+@pytest.mark.parametrize("cname", ["tiny", "gpt2ish", "llamaish", "odd"])
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("mode", ["int8", "int4", "mixed"])
+def test_golden_cache_end_to_end(E, g5, cname, dtype, mode):
+    kv = to_torch(g5[f"{cname}.{dtype}.kv"])  # [L,2,B,H,T+1,D]
+    key = f"{cname}.{dtype}.{mode}"
+    L, _, B, H, T1, D = kv.shape
+    T = T1 - 1
+    qc = E.QuantizedKVCache(n_layers=L, mode=mode, device="cuda", compute_dtype=TD[dtype])
+    with pytest.raises(ValueError, match="Empty cache"):
+        qc.layers[0].get_kv()
+    qc.init_from_prompt_past(tuple((kv[l, 0, :, :, :T], kv[l, 1, :, :, :T]) for l in range(L)))
+    qc.append_from_past(tuple((kv[l, 0], kv[l, 1]) for l in range(L)))
+    past = qc.to_past_key_values()
+    assert len(past) == L and past[0][0].shape == (B, H, T1, D) and past[0][0].dtype == TD[dtype]
+    deq = torch.stack([torch.stack([k, v]) for k, v in past])
+    assert np.array_equal(bits(deq), bits(g5[key + ".deq"]))
+    assert qc.estimated_bytes() == int(g5[key + ".bytes"][0])
+    # stored representation: the reference's lists, as views of the persistent buffers
+    kq = torch.stack([torch.cat(layer.k_store, dim=2) for layer in qc.layers])
+    vq = torch.stack([torch.cat(layer.v_store, dim=2) for layer in qc.layers])
+    assert np.array_equal(to_numpy(kq), g5[key + ".kq"]) and np.array_equal(to_numpy(vq), g5[key + ".vq"])
+    sc = torch.stack([torch.stack([torch.stack(l.k_scales), torch.stack(l.v_scales)]) for l in qc.layers])
+    assert np.array_equal(bits(sc), bits(g5[key + ".scales"]))
+    # per-layer API gives the same tensors
+    k0, v0 = qc.layers[0].get_kv()
+    assert torch.equal(k0, past[0][0]) and torch.equal(v0, past[0][1])
+
+
+# ------------------------------------------------------------------ oracle: seeded, both paths
+
+
+CASES = [  # (G, B, H, T, D)
+    (4, 1, 8, 300, 128),   # llama slice shape, ragged token tiles
+    (3, 1, 12, 129, 64),   # gpt2
+    (2, 1, 16, 64, 64),    # gpt2-medium
+    (2, 2, 4, 33, 32),     # batch > 1
+    (2, 8, 8, 5, 128),     # R*D = 8192 -> 2 tokens per tile
+    (1, 64, 8, 3, 128),    # R*D = 65536 > tile: two-pass path
+    (2, 2, 3, 7, 5),       # odd D: generic kernels
+    (1, 1, 2, 4, 24),      # D % 8 == 0 but D/8 not a power of two: generic quantise
+]
+
+
+def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3):
+    from efficient_llm_inference_amd import _lib, kernels
+    G, B, H, T, D = x_np.shape
+    x = to_torch(x_np, dtype)
+    Dq = kernels.packed_dim(kind, D)
+    store = torch.zeros(G, B, H, T + tcap_pad, Dq, dtype=kernels.QDTYPE[kind], device="cuda")
+    scales = torch.zeros(G, T + tcap_pad, dtype=torch.float32, device="cuda")
+    ws = torch.empty(G * T + 8, dtype=torch.float32, device="cuda")
+    _lib.set_tunable("quant_force_two_pass", int(force_two_pass))
+    try:
+        src = [x[g] for g in range(G)] if as_list else x
+        kernels.quant_tokens(src, store[:, :, :, 1:T + 1], scales[:, 1:T + 1], ws, kind)
+    finally:
+        _lib.set_tunable("quant_force_two_pass", 0)
+    torch.cuda.synchronize()
+    # the window [1, T+1) was written; the guard tokens around it must be untouched
+    assert int(store[:, :, :, 0].to(torch.int32).abs().sum()) == 0 and int(store[:, :, :, T + 1:].to(torch.int32).abs().sum()) == 0
+    assert float(scales[:, 0].abs().sum()) == 0.0 and float(scales[:, T + 1:].abs().sum()) == 0.0
+    return store, scales
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind", ["int8", "int4"])
+def test_oracle_quant_dequant_tokens(E, case, dtype, kind):
+    from efficient_llm_inference_amd import kernels
+    G, B, H, T, D = case
+    for dist, two_pass, as_list in (("normal", False, False), ("heavy", True, True), ("tiny", False, True)):
+        x_np = seeded_kv(case, dtype, seed=zlib.crc32(repr((case, dtype, kind, dist)).encode()), dist=dist)
+        q_ref, stored_ref, s32_ref = O.quantize_tokens(x_np, kind, dtype=odt(dtype))
+        store, scales = _quant_via_kernels(E, x_np, dtype, kind, two_pass, as_list)
+        assert np.array_equal(to_numpy(store[:, :, :, 1:T + 1]), q_ref), (dist, two_pass)
+        assert np.array_equal(bits(scales[:, 1:T + 1]), bits(s32_ref)), (dist, two_pass)
+        for od in DTYPES:
+            out = torch.zeros(G, B, H, T + 2, D, dtype=TD[od], device="cuda")  # strided output window
+            kernels.dequant_tokens(store[:, :, :, 1:T + 1], scales[:, 1:T + 1], out[:, :, :, :T], kind)
+            ref = O.dequantize_tokens(q_ref, s32_ref, kind, D, od)
+            assert np.array_equal(bits(out[:, :, :, :T]), bits(ref)), (dist, od)
+            assert float(out[:, :, :, T:].float().abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("kind", ["int8", "int4"])
+@pytest.mark.parametrize("od", DTYPES)
+def test_dequant_all_variants_bit_exact(E, kind, od):
+    """Every tuning variant of the fast dequantise kernel gives identical bytes."""
+    from efficient_llm_inference_amd import _lib, kernels
+    case = (3, 1, 8, 1031, 128)  # ragged: row length not a multiple of any chunk
+    x_np = seeded_kv(case, "f16", seed=77, dist="heavy")
+    q_ref, _, s32_ref = O.quantize_tokens(x_np, kind)
+    ref = O.dequantize_tokens(q_ref, s32_ref, kind, 128, od)
+    q, sc = to_torch(q_ref), to_torch(s32_ref)
+    try:
+        for v in range(12):
+            for grid in (0, 7):
+                _lib.set_tunable("dequant_variant", v)
+                _lib.set_tunable("dequant_grid", grid)
+                out = torch.empty(case, dtype=TD[od], device="cuda")
+                kernels.dequant_tokens(q, sc, out, kind)
+                assert np.array_equal(bits(out), bits(ref)), (v, grid)
+    finally:
+        _lib.set_tunable("dequant_variant", -1)
+        _lib.set_tunable("dequant_grid", 0)
+
+
+def test_flat_entry_points(E):
+    """The reference's own plugin entry points (extensions.py:70-114)."""
+    ext = E.get_hip_extension()
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 768, 1024, 4099):
+        q = rng.integers(-127, 128, size=(n,), dtype=np.int8)
+        out = ext.dequant_int8_to_fp16(to_torch(q), 0.0123)
+        assert out.dtype == torch.float16
+        assert np.array_equal(bits(out), bits(O.dequantize_int8_per_tensor(q, np.float32(0.0123), "f16")))
+    for shape, orig in (((2, 3, 1, 3), 5), ((1, 8, 1, 64), 128), ((5, 4), 8), ((3, 1), 1)):
+        p = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        out = ext.dequant_int4_packed_to_fp16(to_torch(p), 0.37, orig)
+        assert out.shape[-1] == 2 * shape[-1]
+        assert np.array_equal(bits(out), bits(O.dequant_int4_packed_kernel_full(p, np.float32(0.37), orig)))
+    with pytest.raises(RuntimeError):
+        ext.dequant_int8_to_fp16(torch.zeros(4, dtype=torch.int8), 1.0)  # CPU tensor
+    with pytest.raises(RuntimeError):
+        ext.dequant_int8_to_fp16(torch.zeros(4, 4, dtype=torch.int8, device="cuda").t(), 1.0)  # non-contiguous
+
+
+def test_cpu_tensors_fail_loudly(E):
+    with pytest.raises(RuntimeError, match="MI355X"):
+        E.quantize_int8_per_tensor(torch.randn(2, 2, 1, 8))
+    with pytest.raises(RuntimeError, match="MI355X"):
+        E.trim_kv_sliding_window(((torch.randn(1, 2, 9, 8), torch.randn(1, 2, 9, 8)),), 4)
+
+
+def test_layer_append_and_growth(E):
+    """Per-layer appends (the reference's own prefill loop, ops.py:339-342) through capacity
+    growth, vs one fused prefill."""
+    L, B, H, T, D = 2, 1, 4, 70, 64
+    kv = to_torch(seeded_kv((L, 2, B, H, T, D), "f16", 9, "heavy"))
+    a = E.QuantizedKVCache(L, "mixed")
+    for l in range(L):
+        for t in range(T):
+            a.layers[l].append(kv[l, 0, :, :, t:t + 1], kv[l, 1, :, :, t:t + 1])
+    b = E.QuantizedKVCache(L, "mixed")
+    b.init_from_prompt_past(tuple((kv[l, 0], kv[l, 1]) for l in range(L)))
+    for (ka, va), (kb, vb) in zip(a.to_past_key_values(), b.to_past_key_values()):
+        assert torch.equal(ka, kb) and torch.equal(va, vb)
+    assert a.estimated_bytes() == b.estimated_bytes() == O.estimated_bytes("mixed", L, B, H, T, D, 2)
+
+
+# ------------------------------------------------------------------ eviction
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+@pytest.mark.parametrize("T,W", [(5, 8), (8, 8), (13, 8), (40, 1)])
+def test_golden_sliding_window(E, g6, dtype, T, W):
+    x = to_torch(g6[f"win.{dtype}.T{T}.W{W}.x"])
+    v = x * 2
+    (k2, v2), = E.trim_kv_sliding_window(((x, v),), W)
+    assert np.array_equal(to_numpy(k2), g6[f"win.{dtype}.T{T}.W{W}.k"])
+    assert np.array_equal(to_numpy(v2), g6[f"win.{dtype}.T{T}.W{W}.v"])
+    if T <= W:
+        assert k2 is x and v2 is v  # unchanged objects, as the reference
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,chunk,keep", [(40, 8, 8), (45, 8, 8), (6, 8, 8), (33, 4, 0), (300, 64, 16), (19, 64, 3)])
+def test_golden_and_oracle_chunk_summary(E, g6, dtype, T, chunk, keep):
+    key = f"chunk.{dtype}.T{T}.c{chunk}.k{keep}"
+    x_np, ref = g6[key + ".x"], g6[key + ".k"]
+    x = to_torch(x_np, dtype)
+    (k2, v2), = E.chunk_summarize_kv(((x, -x),), chunk_size=chunk, keep_last=keep)
+    orc = O.chunk_summarize_kv(x_np, chunk, keep, dtype=odt(dtype))
+    assert np.array_equal(bits(k2), bits(orc))  # same summation order: bit-exact vs the oracle
+    assert torch.equal(v2, -k2) or T <= keep
+    # vs the reference's golden: recent tail exact, summaries within 1 storage ulp
+    n_sum = ref.shape[-2] - min(keep, T) if T > keep else 0
+    got = to_numpy(k2)
+    assert np.array_equal(got[..., n_sum:, :], ref[..., n_sum:, :])
+    a32 = O._widen(got[..., :n_sum, :], odt(dtype))
+    b32 = O._widen(ref[..., :n_sum, :], odt(dtype))
+    tol = {"f16": 2.0**-10, "bf16": 2.0**-7, "f32": 2.0**-22}[dtype]
+    xmax = np.abs(O._widen(x_np, odt(dtype))).max()
+    assert np.all(np.abs(a32 - b32) <= tol * np.abs(b32) + 8 * 2.0**-24 * xmax)
+
+
+@pytest.mark.parametrize("shape,chunk,keep,W", [((6, 1, 8, 1000, 128), 64, 256, 256), ((4, 2, 3, 77, 5), 8, 5, 20),
+                                                  ((2, 1, 4, 130, 24), 16, 2, 129)])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_oracle_eviction_multi_layer(E, shape, chunk, keep, W, dtype):
+    """2L tensors per launch (pointer table), vector and generic kernels."""
+    G, B, H, T, D = shape
+    x_np = seeded_kv(shape, dtype, 31, "heavy")
+    x = to_torch(x_np, dtype)
+    past = tuple((x[2 * l], x[2 * l + 1]) for l in range(G // 2))
+    res = E.chunk_summarize_kv(past, chunk, keep)
+    orc = O.chunk_summarize_kv(x_np, chunk, keep, dtype=odt(dtype))
+    for l in range(G // 2):
+        assert np.array_equal(bits(res[l][0]), bits(orc[2 * l])) and np.array_equal(bits(res[l][1]), bits(orc[2 * l + 1]))
+    res = E.trim_kv_sliding_window(past, W)
+    for l in range(G // 2):
+        assert np.array_equal(bits(res[l][0]), bits(x_np[2 * l][..., T - W:, :]))
+        assert np.array_equal(bits(res[l][1]), bits(x_np[2 * l + 1][..., T - W:, :]))
+    # strided inputs: windows of a larger cache (t not contiguous with the row)
+    big = torch.zeros(G, B, H, T + 9, D, dtype=x.dtype, device="cuda")
+    big[:, :, :, 4:T + 4] = x
+    past = tuple((big[2 * l, :, :, 4:T + 4], big[2 * l + 1, :, :, 4:T + 4]) for l in range(G // 2))
+    res = E.chunk_summarize_kv(past, chunk, keep)
+    for l in range(G // 2):
+        assert np.array_equal(bits(res[l][0]), bits(orc[2 * l]))

@@ -1,0 +1,48 @@
+"""Shared helpers for the parity tests (numpy <-> torch, dtype codes, seeded inputs)."""
+import numpy as np
+import torch
+
+TD = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+NAME = {v: k for k, v in TD.items()}
+
+
+def to_torch(a: np.ndarray, dtype: str = None, device="cuda") -> torch.Tensor:
+    """numpy -> torch on `device`; bf16 travels as uint16 bit patterns."""
+    if dtype == "bf16":
+        return torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16).to(device)
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def to_numpy(t: torch.Tensor) -> np.ndarray:
+    t = t.detach().contiguous().cpu()
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.int16).numpy().view(np.uint16).copy()
+    return t.numpy().copy()
+
+
+def bits(a) -> np.ndarray:
+    """byte view for bit-exact comparison (distinguishes -0.0 from +0.0)"""
+    if isinstance(a, torch.Tensor):
+        a = to_numpy(a)
+    return np.ascontiguousarray(a).view(np.uint8)
+
+
+def odt(dtype: str):
+    """oracle dtype argument"""
+    return "bf16" if dtype == "bf16" else None
+
+
+def seeded_kv(shape, dtype: str, seed: int, dist: str = "normal") -> np.ndarray:
+    """Synthetic KV as numpy in the oracle's representation (bf16 -> uint16 bits)."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(shape, dtype=np.float32)
+    if dist == "heavy":  # 1 % of values x10: outlier channels typical of K
+        x = np.where(rng.random(shape) < 0.01, x * 10.0, x).astype(np.float32)
+    elif dist == "tiny":  # drives fp16 stored scales to 0 and results to +-0
+        x = (x * 1e-6).astype(np.float32)
+    if dtype == "f32":
+        return x
+    if dtype == "f16":
+        return x.astype(np.float16)
+    from oracle import kvq_oracle as O
+    return O.f32_to_bf16_bits(x)
