@@ -153,6 +153,15 @@ __device__ inline void store1(void* base, int64_t idx, float v) {
   }
 }
 
+// fp32 product that stays an fp32 product. Without the opaque barrier hipcc folds
+// (f16)(a * b) into v_fma_mixlo_f16 a, b, +0.0, and (-0.0) + (+0.0) = +0.0 loses the sign of a
+// zero result (q < 0 with a stored fp16 scale of 0): the reference yields -0.0 there.
+__device__ inline float mul_exact(float a, float b) {
+  float p = a * b;
+  asm("" : "+v"(p));
+  return p;
+}
+
 // ------------------------------------------------------------------ wave64 reductions
 
 // max over aligned groups of `width` consecutive lanes (width = power of two <= 64); every

@@ -58,7 +58,7 @@ __device__ inline void expand8(const uint32_t* wq, float s, float (&x)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int v = (int)(int8_t)((wq[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-      x[i] = (float)v * s;
+      x[i] = mul_exact((float)v, s);
     }
   } else {
     const uint32_t w = wq[0];
@@ -66,7 +66,7 @@ __device__ inline void expand8(const uint32_t* wq, float s, float (&x)[8]) {
     for (int i = 0; i < 8; ++i) {
       const int sh = 8 * (i >> 1) + ((i & 1) ? 0 : 4);  // even element = high nibble
       const int v = (int)((w >> sh) & 0xFu) - 8;
-      x[i] = (float)v * s;
+      x[i] = mul_exact((float)v, s);
     }
   }
 }
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void dequant_tokens_generic_k(const Dequant
       const uint8_t byte = qp[d >> 1];
       v = (int)((d & 1) ? (byte & 0x0F) : (byte >> 4)) - 8;
     }
-    store1<ODT>(a.out, g * a.os.g + b * a.os.b + h * a.os.h + t * a.os.t + d, (float)v * s);
+    store1<ODT>(a.out, g * a.os.g + b * a.os.b + h * a.os.h + t * a.os.t + d, mul_exact((float)v, s));
   }
 }
 
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void dequant_flat_vec_k(const uint8_t* __re
 __global__ __launch_bounds__(kBlock) void dequant_i8_flat_scalar_k(const int8_t* __restrict__ q, float s,
                                                                    uint16_t* __restrict__ out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-    store1<KVQ_F16>(out, i, (float)(int)q[i] * s);
+    store1<KVQ_F16>(out, i, mul_exact((float)(int)q[i], s));
 }
 
 __global__ __launch_bounds__(kBlock) void dequant_i4_flat_scalar_k(const uint8_t* __restrict__ p, float s,
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void dequant_i4_flat_scalar_k(const uint8_t
     const uint8_t byte = p[i >> 1];
     const int v = (int)((i & 1) ? (byte & 0x0F) : (byte >> 4)) - 8;
     const int64_t last = i % total_last;
-    store1<KVQ_F16>(out, i, last < orig_last ? (float)v * s : 0.0f);
+    store1<KVQ_F16>(out, i, last < orig_last ? mul_exact((float)v, s) : 0.0f);
   }
 }
 
