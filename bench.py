@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X KV-cache dequantise hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload llama3_8b_mixed_seq16k]
+
+Workload (BASELINE.json configs[3], the one the target is quoted on): Llama-3-8B KV shape
+[L=32, 2, B=1, H_kv=8, T=16384, D=128], ``quant_mixed`` = INT8 keys + packed-INT4 values,
+synthetic N(0,1) fp16 KV (seed 42) quantised once by the HIP quantise kernels before timing.
+
+One STEP = one full ``QuantizedKVCache.to_past_key_values()`` of that cache — what the
+reference does before every decode forward (reference src/quantization/ops.py:345-355,
+src/benchmarking/benchmarker.py:470): dequantise all 32 layers of K (INT8 -> fp16) and V
+(INT4 -> fp16): exactly two kernel launches, inputs resident in HBM.
+
+value  = algorithmic bytes of the step (INT8 3.0 B/elt, INT4 2.5 B/elt) x ranks
+         / max-over-ranks wall time, GB/s.  Weak scaling: every rank holds its own prompt's
+         cache (batch shard, no data-path collective).
+roofline = the INT4 dequantise kernel (north-star kernel): algorithmic bytes per launch
+         (1,342,177,280) / its mean duration, timed with HIP events on the launch stream
+         inside the timed region; peak 8000 GB/s (MI355X HBM3E spec).
+cpu_baseline = the C restatement of the reference's algorithm (oracle/kvq_oracle.c, scalar,
+         1 core) on a bounded sample of the same INT4 workload, on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    # name: (L, B, H, T, D, mode)
+    "llama3_8b_mixed_seq16k": (32, 1, 8, 16384, 128, "mixed"),
+    "gpt2m_int4_seq4k": (24, 1, 16, 4096, 64, "int4"),
+    "gpt2_int8_seq1k": (12, 1, 12, 1024, 64, "int8"),
+}
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+BYTES_PER_ELT = {"int8": 3.0, "int4": 2.5}  # q read + fp16 write
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="llama3_8b_mixed_seq16k", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-layers", type=int, default=16)
+    return ap.parse_args()
+
+
+def cpu_baseline(L, B, H, T, D, sample_layers):
+    """Time the scalar C port of the reference's INT4 dequantise on `sample_layers` layers of
+    the same V set (host buffers, one thread)."""
+    import numpy as np
+    from oracle import c_oracle as C
+    n_layers = max(1, min(sample_layers, L))
+    rng = np.random.default_rng(42)
+    q = rng.integers(0, 256, size=(n_layers, B, H, T, D // 2), dtype=np.uint8)
+    sc = (rng.random((n_layers, T), dtype=np.float32) * 0.02 + 0.001).astype(np.float32)
+    C.dequantize_tokens(q[:1], sc[:1], "int4", D, "f16")  # warm (page in, load lib)
+    t0 = time.perf_counter()
+    C.dequantize_tokens(q, sc, "int4", D, "f16")
+    dt = time.perf_counter() - t0
+    n = n_layers * B * H * T * D
+    return {
+        "value": round(n * BYTES_PER_ELT["int4"] / dt / 1e9, 4),
+        "unit": "GB/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"INT4->fp16 dequantise of {n_layers}/{L} layers of the V set "
+                  f"[{n_layers},{B},{H},{T},{D}] ({n} elements, {dt:.2f} s), oracle/kvq_oracle.c scalar",
+        "host_cores_available": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import efficient_llm_inference_amd as E
+    from efficient_llm_inference_amd import _lib
+
+    _lib.load()
+    L, B, H, T, D, mode = WORKLOADS[args.workload]
+    kk, vk = {"int8": ("int8", "int8"), "int4": ("int4", "int4"), "mixed": ("int8", "int4")}[mode]
+
+    # ---- build the quantised cache once (each rank its own prompt: seed 42 + rank) ------------
+    torch.manual_seed(42 + rank)
+    qc = E.QuantizedKVCache(n_layers=L, mode=mode, device="cuda", compute_dtype=torch.float16)
+    qc.reserve(T)
+    past = []
+    for _ in range(L):  # the legacy tuple layout: 2L separately allocated [B,H,T,D] tensors
+        past.append((torch.randn(B, H, T, D, device=dev, dtype=torch.float16),
+                     torch.randn(B, H, T, D, device=dev, dtype=torch.float16)))
+    qc.init_from_prompt_past(tuple(past))
+    torch.cuda.synchronize()
+    est_mb = qc.estimated_bytes() / 2**20
+    del past
+    torch.cuda.empty_cache()
+
+    n_elts = L * B * H * T * D  # per K or V set
+    bytes_k = n_elts * BYTES_PER_ELT[kk]
+    bytes_v = n_elts * BYTES_PER_ELT[vk]
+    step_bytes = bytes_k + bytes_v
+
+    # two rotating output sets so consecutive steps never write the same lines
+    outs = [(torch.empty(L, B, H, T, D, device=dev, dtype=torch.float16),
+             torch.empty(L, B, H, T, D, device=dev, dtype=torch.float16)) for _ in range(2)]
+
+    def step(i, evs=None):
+        ko, vo = outs[i & 1]
+        if evs is not None:
+            evs[0].record()
+        qc._k.dequant(torch.float16, out=ko)  # all layers of K: one launch
+        if evs is not None:
+            evs[1].record()
+        qc._v.dequant(torch.float16, out=vo)  # all layers of V: one launch
+        if evs is not None:
+            evs[2].record()
+
+    for i in range(args.warmup):
+        step(i)
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, events[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    k_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
+    v_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = step_bytes * world / (elapsed / args.steps) / 1e9
+        target_ms, target_bytes, target_name = (v_ms, bytes_v, f"{vk} dequant (V set)")
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 PMC passes (see profiles/README.md)
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get(f"dequant_{vk}")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "KV dequant GB/s vs HBM roofline (quant_mixed step: INT8 K + INT4 V -> fp16)",
+            "value": round(value, 1),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8->f16 (fp32 multiply)",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "shape_LBHTD": [L, B, H, T, D], "mode": mode,
+                       "step": "QuantizedKVCache.to_past_key_values(): 2 launches (K set, V set)",
+                       "bytes_per_step": int(step_bytes), "parallelism": f"batch-shard x{world}, no collective"},
+            "roofline": {
+                "kernel": f"dequant_tokens_fast_k<{vk}>", "what": target_name, "bound": "hbm",
+                "achieved": round(target_bytes / (target_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(target_bytes / (target_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "traffic": traffic, "algorithmic_bytes_per_launch": int(target_bytes),
+                "avg_launch_ms": round(target_ms, 4), "timer": "HIP events on the launch stream, per launch, in the timed region",
+            },
+            "roofline_k": {
+                "kernel": f"dequant_tokens_fast_k<{kk}>", "bound": "hbm",
+                "achieved": round(bytes_k / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(bytes_k / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "algorithmic_bytes_per_launch": int(bytes_k), "avg_launch_ms": round(k_ms, 4),
+            },
+            "est_kv_cache_mb": round(est_mb, 3),
+            "fp16_kv_cache_mb": round(2 * n_elts * 2 / 2**20, 3),
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(L, B, H, T, D, args.cpu_sample_layers)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

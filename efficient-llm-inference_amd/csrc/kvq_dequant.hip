@@ -232,7 +232,10 @@ static const Variant kVariants[] = {
     {32, 2, false, true},  // 11
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-constexpr int kDefaultVariant = 0;
+// shipped defaults (profiles/r01_microbench.txt): contiguous 1 KiB stores per wave instruction;
+// non-temporal stores for the 80 %-write INT4 stream.
+constexpr int kDefaultVariantI4 = 1;
+constexpr int kDefaultVariantI8 = 0;
 
 template <int ODT, int BITS, int LE, int UNROLL, bool NT, bool LDS_SC>
 static void launch_fast(const DequantArgs& a, unsigned grid, hipStream_t st) {
@@ -291,7 +294,7 @@ static int dequant_tokens(const uint8_t* q, const kvq_strides_t* q_st, const flo
   const int esz = out_dtype == KVQ_F32 ? 4 : 2;
 
   int v = (int)tunables().dequant_variant;
-  if (v < 0 || v >= kNumVariants) v = kDefaultVariant;
+  if (v < 0 || v >= kNumVariants) v = BITS == 4 ? kDefaultVariantI4 : kDefaultVariantI8;
   const Variant var = kVariants[v];
   const int64_t chunk = (int64_t)kBlock * var.le * var.unroll;
 

@@ -1,0 +1,115 @@
+"""Full-size checks at BASELINE.json's shapes (too large for the CPU oracle): size-independent
+properties + an independent re-computation of the reference's formulas with plain torch ops on
+the GPU (the reference's own fallback expressions, ops.py:26-30, 47-63, 90, 122-133), layer by
+layer. Run on a real MI355X: ``pytest -m gpu``.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LLAMA = (32, 1, 8, 16384, 128)  # config 4: Llama-3-8B, seq 16K   [L,B,H,T,D]
+GPT2M = (24, 1, 16, 4096, 64)   # config 3: gpt2-medium, seq 4K
+
+
+@pytest.fixture(scope="module")
+def K():
+    assert torch.cuda.is_available()
+    from efficient_llm_inference_amd import _lib, kernels
+    _lib.load()
+    return kernels
+
+
+def _torch_unpack(p):  # ops.py:122-131
+    hi = (p >> 4) & 0x0F
+    lo = p & 0x0F
+    return torch.stack([hi, lo], dim=-1).flatten(-2).to(torch.int16) - 8
+
+
+def _torch_quant(x, qmax, qmin):  # ops.py:26-29 / 47-50 per token slice, vectorised over t
+    x32 = x.float()
+    amax = x32.abs().amax(dim=(0, 1, 3))  # [T] over B,H,D
+    # The scale is computed on the CPU: torch's GPU kernel for tensor / python-scalar multiplies by
+    # fl(1/qmax) instead of dividing (<= 1 ulp off the true quotient). The oracle — the
+    # reference as it runs in the build container, on CPU — divides; so does the HIP kernel.
+    s32 = (amax.cpu() / qmax).clamp(min=1e-8).to(x.device)
+    q = torch.clamp((x32 / s32[None, None, :, None]).round(), qmin, qmax).to(torch.int8)
+    return q, s32
+
+
+@pytest.mark.parametrize("shape", [LLAMA, GPT2M])
+@pytest.mark.parametrize("kind", ["int4", "int8"])
+def test_fullsize_dequant_matches_reference_formula(K, shape, kind):
+    L, B, H, T, D = shape
+    g = torch.Generator(device="cuda").manual_seed(1)
+    Dq = K.packed_dim(kind, D)
+    if kind == "int4":
+        q = torch.randint(0, 256, (L, B, H, T, Dq), dtype=torch.uint8, device="cuda", generator=g)
+    else:
+        q = torch.randint(-127, 128, (L, B, H, T, Dq), dtype=torch.int8, device="cuda", generator=g)
+    scales = (torch.rand(L, T, device="cuda", generator=g) * 0.05).half().float()  # stored fp16 scales, widened
+    scales[:, ::97] = 0.0  # underflowed scales: exercises the -0.0 results
+    out = torch.empty(L, B, H, T, D, dtype=torch.float16, device="cuda")
+    K.dequant_tokens(q, scales, out, kind)
+    for l in range(L):
+        qi = _torch_unpack(q[l]) if kind == "int4" else q[l]
+        ref = (qi.float() * scales[l][None, None, :, None]).half()
+        assert torch.equal(out[l].view(torch.int16), ref.view(torch.int16)), f"layer {l}"
+
+
+@pytest.mark.parametrize("shape", [LLAMA, GPT2M])
+@pytest.mark.parametrize("kind", ["int4", "int8"])
+def test_fullsize_quant_roundtrip(K, shape, kind):
+    """quantise -> dequantise at full size: packed bytes / int8 and stored scales equal the torch
+    re-computation; reconstruction error within half a quantisation step (+ fp16 rounding)."""
+    L, B, H, T, D = shape
+    qmax, qmin = (7.0, -8.0) if kind == "int4" else (127.0, -127.0)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    Dq = K.packed_dim(kind, D)
+    store = torch.empty(L, B, H, T, Dq, dtype=K.QDTYPE[kind], device="cuda")
+    scales = torch.empty(L, T, dtype=torch.float32, device="cuda")
+    ws = torch.empty(L * T, dtype=torch.float32, device="cuda")
+    xs = []
+    for l in range(L):  # separately allocated tensors: the pointer-table launch
+        x = torch.randn(B, H, T, D, device="cuda", generator=g)
+        x = torch.where(torch.rand(B, H, T, D, device="cuda", generator=g) < 0.01, x * 8, x).half()
+        xs.append(x)
+    K.quant_tokens(xs, store, scales, ws, kind)
+    out = torch.empty(L, B, H, T, D, dtype=torch.float16, device="cuda")
+    K.dequant_tokens(store, scales, out, kind)
+    for l in range(L):
+        q_ref, s32 = _torch_quant(xs[l], qmax, qmin)
+        s_stored = s32.half().float()
+        assert torch.equal(scales[l], s_stored), f"scales layer {l}"
+        got = _torch_unpack(store[l]).to(torch.int8) if kind == "int4" else store[l]
+        assert torch.equal(got, q_ref), f"q layer {l}"
+        # |x - deq| <= s/2 (rounding) + qmax*|s - s_stored| (stored-scale rounding) + fp16 ulp of the result
+        err = (xs[l].float() - out[l].float()).abs()
+        bound = (0.5 * s32 + qmax * (s32 - s_stored).abs())[None, None, :, None] + out[l].float().abs() * 2.0**-10 + 1e-7
+        assert bool((err <= bound).all()), f"round trip layer {l}"
+    # idempotence of the representation: dequantising twice gives identical bytes
+    out2 = torch.empty_like(out)
+    K.dequant_tokens(store, scales, out2, kind)
+    assert torch.equal(out.view(torch.int16), out2.view(torch.int16))
+
+
+def test_fullsize_eviction_properties(K):
+    """Config-5-shaped (per-GPU slice, fewer layers): window compaction is an exact gather;
+    chunk mean-pool is linear: pool(a) + pool(b) ~= pool(a + b) and equals torch's mean within
+    1 fp16 ulp; the kept tail is an exact copy."""
+    G, B, H, T, D = 4, 8, 8, 32768, 128
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(G, B, H, T, D, device="cuda", generator=g).half()
+    W = 256
+    out = torch.empty(G, B, H, W, D, dtype=torch.float16, device="cuda")
+    K.window_compact(x, out, W)
+    assert torch.equal(out, x[:, :, :, T - W:])
+    chunk, keep = 64, 256
+    Tout = K.chunk_summary_len(T, chunk, keep)
+    assert Tout == 764
+    pooled = torch.empty(G, B, H, Tout, D, dtype=torch.float16, device="cuda")
+    K.chunk_meanpool(x, pooled, chunk, keep)
+    assert torch.equal(pooled[:, :, :, Tout - keep:], x[:, :, :, T - keep:])
+    ref = x[:, :, :, : T - keep].float().view(G, B, H, -1, chunk, D).mean(dim=4)
+    got = pooled[:, :, :, : Tout - keep].float()
+    assert bool(((got - ref).abs() <= ref.abs() * 2.0**-10 + 1e-5).all())

@@ -1,0 +1,59 @@
+"""Pins the C oracle (oracle/kvq_oracle.c — checker + cpu_baseline leg) to the numpy oracle and,
+through the goldens, to the reference. CPU only."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as C
+from oracle import kvq_oracle as O
+from tests.util import seeded_kv
+
+
+def test_half_conversion_exhaustive():
+    lib = C.load()
+    allh = np.arange(65536, dtype=np.uint16)
+    f = allh.view(np.float16).astype(np.float32)
+    for h in range(0, 65536, 1):
+        if (h & 0x7C00) == 0x7C00 and (h & 0x3FF):
+            continue  # NaN payloads are not on the path
+        assert lib.kvq_oracle_h2f(h) == f[h] or (np.isinf(f[h]) and np.isinf(lib.kvq_oracle_h2f(h)))
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.standard_normal(20000).astype(np.float32) * s for s in (1e-8, 1e-6, 1e-4, 1.0, 300.0, 7e4)])
+    xs = np.concatenate([xs, np.array([65504.0, 65519.9, 65520.0, 2.0**-25, 2.0**-25 * 1.0001, 2.0**-24 * 1.5, 0.0, -0.0], np.float32)])
+    with np.errstate(over="ignore"):
+        want = xs.astype(np.float16).view(np.uint16)
+    got = np.array([lib.kvq_oracle_f2h(float(v)) for v in xs], dtype=np.uint16)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 8, 9, 128), (2, 2, 3, 7, 5), (1, 1, 12, 33, 64)])
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+@pytest.mark.parametrize("kind", ["int8", "int4"])
+@pytest.mark.parametrize("dist", ["normal", "heavy", "tiny"])
+def test_c_quant_dequant_equals_numpy_oracle(shape, dtype, kind, dist):
+    x = seeded_kv(shape, dtype, 11, dist)
+    q_ref, _, s32_ref = O.quantize_tokens(x, kind)
+    q, sc = C.quantize_tokens(x, kind)
+    assert np.array_equal(q, q_ref) and np.array_equal(sc.view(np.uint32), s32_ref.view(np.uint32))
+    for od in ("f16", "f32"):
+        d = C.dequantize_tokens(q, sc, kind, shape[-1], od)
+        assert np.array_equal(d.view(np.uint8), O.dequantize_tokens(q_ref, s32_ref, kind, shape[-1], od).view(np.uint8))
+
+
+@pytest.mark.parametrize("cname", ["tiny", "gpt2ish", "llamaish", "odd"])
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_c_oracle_vs_reference_goldens(g5, cname, dtype):
+    kv = g5[f"{cname}.{dtype}.kv"]
+    D = kv.shape[-1]
+    for kvi, kind in enumerate(("int8", "int4")):
+        q, sc = C.quantize_tokens(kv[:, kvi], kind)
+        key = f"{cname}.{dtype}.mixed"
+        assert np.array_equal(q, g5[key + (".kq" if kvi == 0 else ".vq")])
+        d = C.dequantize_tokens(q, sc, kind, D, dtype)
+        assert np.array_equal(d.view(np.uint8), g5[key + ".deq"][:, kvi].view(np.uint8))
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+@pytest.mark.parametrize("T,chunk,keep", [(40, 8, 8), (45, 8, 8), (6, 8, 8), (33, 4, 0), (300, 64, 16), (19, 64, 3)])
+def test_c_chunk_summary_equals_numpy_oracle(g6, dtype, T, chunk, keep):
+    x = g6[f"chunk.{dtype}.T{T}.c{chunk}.k{keep}.x"]
+    assert np.array_equal(C.chunk_summarize(x, chunk, keep).view(np.uint8), O.chunk_summarize_kv(x, chunk, keep).view(np.uint8))
