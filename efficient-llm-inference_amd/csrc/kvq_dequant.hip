@@ -230,12 +230,16 @@ static const Variant kVariants[] = {
     {8, 8, true, true},    // 9
     {16, 4, false, true},  // 10
     {32, 2, false, true},  // 11
+    {8, 2, true, true},    // 12
+    {8, 1, true, true},    // 13
+    {8, 4, true, false},   // 14
+    {8, 1, false, true},   // 15
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 // shipped defaults (profiles/r01_microbench.txt): contiguous 1 KiB stores per wave instruction;
 // non-temporal stores for the 80 %-write INT4 stream.
 constexpr int kDefaultVariantI4 = 1;
-constexpr int kDefaultVariantI8 = 0;
+constexpr int kDefaultVariantI8 = 12;
 
 template <int ODT, int BITS, int LE, int UNROLL, bool NT, bool LDS_SC>
 static void launch_fast(const DequantArgs& a, unsigned grid, hipStream_t st) {
@@ -257,6 +261,10 @@ static bool launch_fast_variant(int v, const DequantArgs& a, unsigned grid, hipS
     case 9: launch_fast<ODT, BITS, 8, 8, true, true>(a, grid, st); return true;
     case 10: launch_fast<ODT, BITS, 16, 4, false, true>(a, grid, st); return true;
     case 11: launch_fast<ODT, BITS, 32, 2, false, true>(a, grid, st); return true;
+    case 12: launch_fast<ODT, BITS, 8, 2, true, true>(a, grid, st); return true;
+    case 13: launch_fast<ODT, BITS, 8, 1, true, true>(a, grid, st); return true;
+    case 14: launch_fast<ODT, BITS, 8, 4, true, false>(a, grid, st); return true;
+    case 15: launch_fast<ODT, BITS, 8, 1, false, true>(a, grid, st); return true;
   }
   return false;
 }

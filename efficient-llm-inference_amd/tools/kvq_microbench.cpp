@@ -43,6 +43,24 @@ __global__ __launch_bounds__(256) void fill16_k(u32x4* __restrict__ out, int64_t
   u32x4 x = {v, v + 1, v + 2, v + 3};
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = x;
 }
+__global__ __launch_bounds__(256) void fill16_nt_k(u32x4* __restrict__ out, int64_t n, uint32_t v) {
+  u32x4 x = {v, v + 1, v + 2, v + 3};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    __builtin_nontemporal_store(x, &out[i]);
+}
+__global__ __launch_bounds__(256) void copy16_nt_k(const u32x4* __restrict__ in, u32x4* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    __builtin_nontemporal_store(__builtin_nontemporal_load(&in[i]), &out[i]);
+}
+// 1 byte read per 4 bytes written: the INT4 dequantise traffic mix with no arithmetic
+__global__ __launch_bounds__(256) void expand4_k(const uint32_t* __restrict__ in, u32x4* __restrict__ out, int64_t n, int nt) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint32_t w = in[i];
+    u32x4 x = {w, w ^ 1u, w ^ 2u, w ^ 3u};
+    if (nt) __builtin_nontemporal_store(x, &out[i]);
+    else out[i] = x;
+  }
+}
 __global__ __launch_bounds__(256) void read16_k(const u32x4* __restrict__ in, uint32_t* sink, int64_t n) {
   u32x4 acc = {0, 0, 0, 0};
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc ^= in[i];
@@ -87,6 +105,7 @@ static const int64_t G = 32, B = 1, H = 8, T = 16384, D = 128;
 int main(int argc, char** argv) {
   std::string what = argc > 1 ? argv[1] : "all";
   int iters = argc > 2 ? atoi(argv[2]) : 20;
+  int n_variants = argc > 3 ? atoi(argv[3]) : 12;
   hipDeviceProp_t prop;
   HIP_OK(hipGetDeviceProperties(&prop, 0));
   printf("# device %s CUs=%d  shape G=%lld B=%lld H=%lld T=%lld D=%lld iters=%d\n", prop.gcnArchName,
@@ -94,17 +113,34 @@ int main(int argc, char** argv) {
   const int64_t N = G * B * H * T * D;  // 536,870,912 elements
   Timer tm;
 
-  void *q8, *q4, *out, *in16;
+  // Rotating buffers: consecutive launches never touch the same lines, so the 256 MiB Infinity
+  // Cache cannot serve re-reads (a single 256 MiB INT4 input re-read every iteration does stay
+  // resident and inflates the rate: profiles/r01a_microbench_warm_cache.txt).
+  constexpr int NBUF = 4;
+  void *q8s[NBUF], *q4s[NBUF], *outs[2], *in16s[2];
   float *scales, *ws;
-  HIP_OK(hipMalloc(&q8, N));
-  HIP_OK(hipMalloc(&q4, N / 2));
-  HIP_OK(hipMalloc(&out, N * 2));
-  HIP_OK(hipMalloc(&in16, N * 2));
+  for (int i = 0; i < NBUF; ++i) {
+    HIP_OK(hipMalloc(&q8s[i], N));
+    HIP_OK(hipMalloc(&q4s[i], N / 2));
+    rand_fill_k<<<4096, 256>>>((uint32_t*)q8s[i], N / 4, 1u + i);
+    rand_fill_k<<<4096, 256>>>((uint32_t*)q4s[i], N / 8, 20u + i);
+  }
+  for (int i = 0; i < 2; ++i) {
+    HIP_OK(hipMalloc(&outs[i], N * 2));
+    HIP_OK(hipMalloc(&in16s[i], N * 2));
+    rand_f16_k<<<4096, 256>>>((uint16_t*)in16s[i], N, 3u + i);
+  }
   HIP_OK(hipMalloc(&scales, G * T * 4));
   HIP_OK(hipMalloc(&ws, G * T * 4));
-  rand_fill_k<<<4096, 256>>>((uint32_t*)q8, N / 4, 1u);
-  rand_fill_k<<<4096, 256>>>((uint32_t*)q4, N / 8, 2u);
-  rand_f16_k<<<4096, 256>>>((uint16_t*)in16, N, 3u);
+  int rot = 0;
+  void *q8 = q8s[0], *q4 = q4s[0], *out = outs[0], *in16 = in16s[0];
+  auto rotate = [&] {
+    ++rot;
+    q8 = q8s[rot % NBUF];
+    q4 = q4s[rot % NBUF];
+    out = outs[rot % 2];
+    in16 = in16s[rot % 2];
+  };
   {
     std::vector<float> s(G * T);
     for (size_t i = 0; i < s.size(); ++i) s[i] = 0.01f + 1e-6f * (float)(i % 977);
@@ -119,27 +155,41 @@ int main(int argc, char** argv) {
   if (what == "copy" || what == "all") {
     const int64_t n16 = N * 2 / 16;  // 1 GiB
     for (int grid : {2048, 4096, 16384, 65536}) {
-      double ms = tm.ms_per([&] { copy16_k<<<grid, 256>>>((const u32x4*)in16, (u32x4*)out, n16); }, iters);
+      double ms = tm.ms_per([&] { rotate(); copy16_k<<<grid, 256>>>((const u32x4*)in16, (u32x4*)out, n16); }, iters);
       printf("calib copy16   grid=%6d  %8.3f ms  %8.1f GB/s (r+w)\n", grid, ms, 2.0 * N * 2 / ms / 1e6);
     }
     for (int grid : {2048, 4096, 16384, 65536}) {
-      double ms = tm.ms_per([&] { fill16_k<<<grid, 256>>>((u32x4*)out, n16, 7u); }, iters);
+      double ms = tm.ms_per([&] { rotate(); fill16_k<<<grid, 256>>>((u32x4*)out, n16, 7u); }, iters);
       printf("calib fill16   grid=%6d  %8.3f ms  %8.1f GB/s (w)\n", grid, ms, 1.0 * N * 2 / ms / 1e6);
     }
+    for (int grid : {4096, 65536}) {
+      double ms = tm.ms_per([&] { rotate(); fill16_nt_k<<<grid, 256>>>((u32x4*)out, n16, 7u); }, iters);
+      printf("calib fill16nt grid=%6d  %8.3f ms  %8.1f GB/s (w)\n", grid, ms, 1.0 * N * 2 / ms / 1e6);
+    }
+    for (int grid : {4096, 65536}) {
+      double ms = tm.ms_per([&] { rotate(); copy16_nt_k<<<grid, 256>>>((const u32x4*)in16, (u32x4*)out, n16); }, iters);
+      printf("calib copy16nt grid=%6d  %8.3f ms  %8.1f GB/s (r+w)\n", grid, ms, 2.0 * N * 2 / ms / 1e6);
+    }
+    for (int nt = 0; nt < 2; ++nt)
+      for (int grid : {4096, 65536, 262144}) {
+        double ms = tm.ms_per([&] { rotate(); expand4_k<<<grid, 256>>>((const uint32_t*)q4, (u32x4*)out, n16, nt); }, iters);
+        printf("calib expand4 nt=%d grid=%6d  %8.3f ms  %8.1f GB/s (0.25r+1w: the INT4 dequant mix)\n", nt, grid, ms, 2.5 * N / ms / 1e6);
+      }
     for (int grid : {2048, 4096, 16384}) {
-      double ms = tm.ms_per([&] { read16_k<<<grid, 256>>>((const u32x4*)in16, (uint32_t*)ws, n16); }, iters);
+      double ms = tm.ms_per([&] { rotate(); read16_k<<<grid, 256>>>((const u32x4*)in16, (uint32_t*)ws, n16); }, iters);
       printf("calib read16   grid=%6d  %8.3f ms  %8.1f GB/s (r)\n", grid, ms, 1.0 * N * 2 / ms / 1e6);
     }
   }
 
   auto sweep_dequant = [&](int bits) {
     const double bytes = bits == 4 ? N * 2.5 : N * 3.0;
-    for (int v = 0; v < 12; ++v) {
-      for (int64_t grid : {(int64_t)0, (int64_t)2048, (int64_t)4096, (int64_t)8192}) {
+    for (int v = 0; v < n_variants; ++v) {
+      for (int64_t grid : {(int64_t)0, (int64_t)4096}) {
         KVQ_OK(kvq_set_tunable("dequant_variant", v));
         KVQ_OK(kvq_set_tunable("dequant_grid", grid));
         double ms = tm.ms_per(
             [&] {
+              rotate();
               if (bits == 4)
                 KVQ_OK(kvq_dequant_i4_tokens((const uint8_t*)q4, &s_half, scales, T, out, &s_full, KVQ_F16, &dims, 0));
               else
@@ -156,12 +206,38 @@ int main(int argc, char** argv) {
   if (what == "dequant4" || what == "all") sweep_dequant(4);
   if (what == "dequant8" || what == "all") sweep_dequant(8);
 
+  if (what == "mixed" || what == "all") {
+    hipEvent_t e0, e1, e2;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1)); HIP_OK(hipEventCreate(&e2));
+    for (int v8 : {0, 1, 8, 12}) for (int v4 : {0, 1, 12}) {
+      double t8 = 0, t4 = 0;
+      for (int it = 0; it < iters + 3; ++it) {
+        rotate();
+        HIP_OK(hipEventRecord(e0, 0));
+        KVQ_OK(kvq_set_tunable("dequant_variant", v8));
+        KVQ_OK(kvq_dequant_i8_tokens((const int8_t*)q8, &s_full, scales, T, outs[0], &s_full, KVQ_F16, &dims, 0));
+        HIP_OK(hipEventRecord(e1, 0));
+        KVQ_OK(kvq_set_tunable("dequant_variant", v4));
+        KVQ_OK(kvq_dequant_i4_tokens((const uint8_t*)q4, &s_half, scales, T, outs[1], &s_full, KVQ_F16, &dims, 0));
+        HIP_OK(hipEventRecord(e2, 0));
+        HIP_OK(hipEventSynchronize(e2));
+        float a = 0, b = 0;
+        HIP_OK(hipEventElapsedTime(&a, e0, e1)); HIP_OK(hipEventElapsedTime(&b, e1, e2));
+        if (it >= 3) { t8 += a; t4 += b; }
+      }
+      printf("mixed step v8=%2d v4=%2d  i8 %7.3f ms %7.1f GB/s | i4 %7.3f ms %7.1f GB/s | step %7.1f GB/s\n", v8, v4,
+             t8 / iters, N * 3.0 / (t8 / iters) / 1e6, t4 / iters, N * 2.5 / (t4 / iters) / 1e6, N * 5.5 / ((t8 + t4) / iters) / 1e6);
+    }
+    KVQ_OK(kvq_set_tunable("dequant_variant", -1));
+  }
+
   auto run_quant = [&](int bits) {
     const double bytes = bits == 4 ? N * 2.5 : N * 3.0;
     for (int two_pass = 0; two_pass < 2; ++two_pass) {
       KVQ_OK(kvq_set_tunable("quant_force_two_pass", two_pass));
       double ms = tm.ms_per(
           [&] {
+            rotate();
             if (bits == 4)
               KVQ_OK(kvq_quant_i4_tokens(in16, nullptr, &s_full, KVQ_F16, (uint8_t*)q4, &s_half, scales, T, ws, 1e-8f, &dims, 0));
             else
@@ -181,7 +257,7 @@ int main(int argc, char** argv) {
     const int64_t Tout = kvq_chunk_summary_len(T, 64, 256);
     kvq_strides_t s_out = {B * H * Tout * D, H * Tout * D, Tout * D, D};
     const double bytes = 2.0 * G * B * H * D * (T + Tout);
-    double ms = tm.ms_per([&] { KVQ_OK(kvq_chunk_meanpool(in16, nullptr, &s_full, out, &s_out, KVQ_F16, 64, 256, &dims, 0)); }, iters);
+    double ms = tm.ms_per([&] { rotate(); KVQ_OK(kvq_chunk_meanpool(in16, nullptr, &s_full, out, &s_out, KVQ_F16, 64, 256, &dims, 0)); }, iters);
     printf("chunk_meanpool T=%lld->%lld  %8.3f ms  %8.1f GB/s  frac8T=%.3f\n", (long long)T, (long long)Tout, ms,
            bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0);
   }
@@ -189,7 +265,7 @@ int main(int argc, char** argv) {
     for (int64_t W : {(int64_t)256, (int64_t)8192}) {
       kvq_strides_t s_out = {B * H * W * D, H * W * D, W * D, D};
       const double bytes = 4.0 * G * B * H * W * D;
-      double ms = tm.ms_per([&] { KVQ_OK(kvq_window_compact(in16, nullptr, &s_full, out, &s_out, 2, W, &dims, 0)); }, iters);
+      double ms = tm.ms_per([&] { rotate(); KVQ_OK(kvq_window_compact(in16, nullptr, &s_full, out, &s_out, 2, W, &dims, 0)); }, iters);
       printf("window_compact W=%lld  %8.3f ms  %8.1f GB/s  frac8T=%.3f\n", (long long)W, ms, bytes / ms / 1e6,
              bytes / ms / 1e6 / 8000.0);
     }
