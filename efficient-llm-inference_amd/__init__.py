@@ -19,11 +19,12 @@ from .quantization import (  # noqa: F401
     quantize_int8_per_tensor,
 )
 from .hip import get_hip_extension  # noqa: F401
+from .benchmarking import KVCacheBenchmarker  # noqa: F401
 
 __all__ = [
     "Config", "QuantizationConfig", "CacheConfig", "BenchmarkConfig",
     "QuantizedKVCache", "QuantizedLayerKV",
     "quantize_int8_per_tensor", "quantize_int4_per_tensor_packed",
     "dequantize_int8_per_tensor", "dequantize_int4_per_tensor_packed",
-    "trim_kv_sliding_window", "chunk_summarize_kv", "get_hip_extension", "__version__",
+    "trim_kv_sliding_window", "chunk_summarize_kv", "get_hip_extension", "KVCacheBenchmarker", "__version__",
 ]

@@ -1,0 +1,130 @@
+"""Host-logic tests of the benchmarker, the cache-format shim and the sharding helpers (CPU).
+BASELINE config 1: gpt2-family full_cache on CPU (plumbing, no GPU)."""
+import math
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.conftest import ROOT
+
+REF_KEYS = ["method", "elapsed_sec", "total_new_tokens", "tokens_per_sec", "cpu_mem_used_mb", "gpu_peak_mb",
+            "window_size", "block_size", "chunk_size", "est_kv_cache_mb_avg", "prefix_len", "stride",
+            "keep_per_block", "old_budget"]  # reference benchmarker.py:811-832, in order
+
+
+@pytest.fixture(scope="module")
+def bench_cpu():
+    from efficient_llm_inference_amd import KVCacheBenchmarker
+    from efficient_llm_inference_amd.benchmarking.offline import load_model
+    model, tok = load_model("gpt2-tiny", "cpu", torch.float32)
+    return KVCacheBenchmarker(model, tok, device="cpu")
+
+
+def test_full_cache_plumbing_on_cpu(bench_cpu):
+    res = bench_cpu.benchmark_method(["The quick brown fox", "<40>"], method="full_cache", max_new_tokens=64)
+    assert list(res.keys()) == REF_KEYS
+    assert res["method"] == "full_cache" and res["total_new_tokens"] == 128
+    assert res["tokens_per_sec"] > 0 and math.isnan(res["est_kv_cache_mb_avg"]) and res["gpu_peak_mb"] is None
+    assert res["window_size"] is None and res["chunk_size"] is None
+
+
+def test_cache_equals_no_cache_tokens(bench_cpu):
+    """greedy decoding with and without the KV cache yields the same text (fp32, CPU)."""
+    t1, n1 = bench_cpu.generate_with_cache("<12>", 10)
+    t2, n2 = bench_cpu.generate_no_cache("<12>", 10)
+    assert n1 == 10 and (n2 == 10 or n2 < 10)  # no_cache may stop at EOS (reference :97-98)
+    if n2 == 10:
+        assert t1 == t2
+
+
+def test_method_validation(bench_cpu):
+    with pytest.raises(AssertionError, match="Invalid method"):
+        bench_cpu.benchmark_method(["x"], method="quant_int2")
+    for m in ("paged_attention", "prefix_window", "strided_cache", "block_cache", "budget_cache"):
+        with pytest.raises(NotImplementedError):
+            bench_cpu.benchmark_method(["x"], method=m)
+    for m in ("quant_int8", "quant_int4", "quant_mixed", "sliding_window", "chunked_cache"):
+        with pytest.raises(RuntimeError, match="MI355X"):  # hot path has no CPU implementation
+            bench_cpu.benchmark_method(["<40>"], method=m, max_new_tokens=2, window_size=8, keep_last=8, chunk_size=4)
+
+
+def test_cache_format_shim_roundtrip():
+    from efficient_llm_inference_amd.benchmarking import from_legacy_tuple, to_legacy_tuple
+    tup = tuple((torch.randn(1, 2, 5, 4), torch.randn(1, 2, 5, 4)) for _ in range(3))
+    cache = from_legacy_tuple(tup)
+    back = to_legacy_tuple(cache)
+    assert len(back) == 3 and all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(tup, back))
+    assert to_legacy_tuple(tup) == tup
+
+
+def test_config_surface():
+    from efficient_llm_inference_amd import BenchmarkConfig, CacheConfig, Config, QuantizationConfig
+    c = Config(device="cpu")
+    assert (c.model_name, c.seed, c.max_new_tokens, c.batch_size) == ("gpt2", 42, 64, 1)
+    a = torch.rand(3)
+    Config(device="cpu")  # re-seeds: same stream again (reference config.py:32-37)
+    b = torch.rand(3)
+    assert torch.equal(a, b)
+    assert (QuantizationConfig().mode, QuantizationConfig().eps) == ("int8", 1e-8)
+    cc = CacheConfig()
+    assert (cc.window_size, cc.block_size, cc.chunk_size, cc.keep_last) == (256, 64, 64, 256)
+    assert BenchmarkConfig().window_sizes == [64, 128, 256, 512]
+
+
+def test_sharding_helpers_single_process():
+    from efficient_llm_inference_amd import sharding
+    prompts = [f"p{i}" for i in range(10)]
+    parts = [sharding.shard_prompts(prompts, r, 4) for r in range(4)]
+    assert sorted(sum(parts, [])) == sorted(prompts) and [len(p) for p in parts] == [3, 3, 2, 2]
+    rows = [sharding.shard_batch_rows(64, r, 8) for r in range(8)]
+    assert all(len(r) == 8 for r in rows) and rows[3][0] == 24
+    rows = [sharding.shard_batch_rows(10, r, 4) for r in range(4)]
+    assert [list(r) for r in rows] == [[0, 1, 2], [3, 4, 5], [6, 7], [8, 9]]
+    assert sharding.aggregate_results({"total_new_tokens": 5, "elapsed_sec": 1.0})["n_ranks"] == 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world_size, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from efficient_llm_inference_amd import KVCacheBenchmarker, sharding
+        from efficient_llm_inference_amd.benchmarking.offline import load_model
+        model, tok = load_model("gpt2-tiny", "cpu", torch.float32)
+        b = KVCacheBenchmarker(model, tok, device="cpu")
+        prompts = ["<8>", "<9>", "<10>", "<11>", "<12>"]
+        res = sharding.benchmark_sharded(b, prompts, "full_cache", max_new_tokens=4)
+        q.put((rank, res["total_new_tokens"], res["n_prompts"], res["n_ranks"], res["elapsed_sec"], res["tokens_per_sec"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_benchmark_world_size_2_gloo():
+    """N>1 path: prompts sharded over 2 ranks, counters aggregated by one all_reduce pair."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, total, n_prompts, n_ranks, elapsed, tps in out:
+        assert total == 20 and n_prompts == 5 and n_ranks == 2  # 5 prompts x 4 tokens, both ranks agree
+        assert abs(tps - total / elapsed) < 1e-9
+    assert out[0][4] == out[1][4]  # max-over-ranks elapsed identical on every rank

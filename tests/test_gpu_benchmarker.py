@@ -1,0 +1,100 @@
+"""End-to-end decode loops on the MI355X vs a reference-style emulation whose cache arithmetic is
+the CPU oracle: because the HIP path is bit-exact, the model sees identical KV and must emit
+identical tokens. BASELINE config 2 in miniature (random-init GPT-2 family, offline)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kvq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rig():
+    assert torch.cuda.is_available()
+    from efficient_llm_inference_amd import KVCacheBenchmarker
+    from efficient_llm_inference_amd.benchmarking import from_legacy_tuple, to_legacy_tuple
+    from efficient_llm_inference_amd.benchmarking.offline import load_model
+    model, tok = load_model("gpt2-tiny", "cuda", torch.float16)
+    return KVCacheBenchmarker(model, tok, device="cuda"), model, tok, from_legacy_tuple, to_legacy_tuple
+
+
+def _emulate(model, ids, n_new, policy, from_legacy, to_legacy):
+    """The reference's loop shape (benchmarker.py:441-486) with `policy(kv_tuple) -> kv_tuple`
+    evaluated by the oracle on the host."""
+    out = model(input_ids=ids, use_cache=True)
+    logits = out.logits[:, -1, :]
+    past = policy(to_legacy(out.past_key_values), first=True)
+    gen = ids.clone()
+    for _ in range(n_new):
+        nxt = torch.argmax(logits, dim=-1, keepdim=True)
+        gen = torch.cat([gen, nxt], dim=-1)
+        out = model(input_ids=nxt, use_cache=True, past_key_values=from_legacy(past))
+        logits = out.logits[:, -1, :]
+        past = policy(to_legacy(out.past_key_values), first=False)
+    return gen
+
+
+@pytest.mark.parametrize("mode", ["int8", "int4", "mixed"])
+def test_quantized_decode_matches_oracle_emulation(rig, mode):
+    bench, model, tok, from_legacy, to_legacy = rig
+    kinds = {"int8": ("int8", "int8"), "int4": ("int4", "int4"), "mixed": ("int8", "int4")}[mode]
+    store = {}
+
+    def policy(kv, first):
+        # quantise what is new (all prompt tokens first, then the last token), keep q + scales,
+        # return the full dequantised cache: ops.py:323-355 semantics through the oracle
+        outs = []
+        for l, pair in enumerate(kv):
+            both = []
+            for i, kind in enumerate(kinds):
+                x = pair[i].cpu().numpy()[None]  # [1,B,H,T,D]
+                new = x if first else x[:, :, :, -1:]
+                q, _, s32 = O.quantize_tokens(new, kind)
+                if first:
+                    store[(l, i)] = (q, s32)
+                else:
+                    q0, s0 = store[(l, i)]
+                    store[(l, i)] = (np.concatenate([q0, q], axis=3), np.concatenate([s0, s32], axis=1))
+                q, s32 = store[(l, i)]
+                both.append(torch.from_numpy(O.dequantize_tokens(q, s32, kind, x.shape[-1], "f16")[0]).cuda())
+            outs.append(tuple(both))
+        return tuple(outs)
+
+    with torch.no_grad():
+        ids = tok("<37>", return_tensors="pt").input_ids.cuda()
+        want = _emulate(model, ids, 12, policy, from_legacy, to_legacy)
+        text, n_new, est_mb = bench.generate_with_quantized_kv("<37>", 12, mode=mode)
+    assert n_new == 12 and text == tok.decode(want[0])
+    cfg = model.config
+    want_bytes = O.estimated_bytes(mode, cfg.n_layer, 1, cfg.n_head, 37 + 12, cfg.n_embd // cfg.n_head, 2)
+    assert abs(est_mb - want_bytes / 2**20) < 1e-9
+
+
+def test_sliding_window_and_chunked_decode_match_emulation(rig):
+    bench, model, tok, from_legacy, to_legacy = rig
+    with torch.no_grad():
+        ids = tok("<60>", return_tensors="pt").input_ids.cuda()
+        win = lambda kv, first: tuple((k[:, :, -16:, :].contiguous(), v[:, :, -16:, :].contiguous()) for k, v in kv)
+        want = _emulate(model, ids, 10, win, from_legacy, to_legacy)
+        text, n_new = bench.generate_with_sliding_window("<60>", 10, window_size=16)
+        assert n_new == 10 and text == tok.decode(want[0])
+
+        def pool(kv, first):
+            return tuple(tuple(torch.from_numpy(O.chunk_summarize_kv(t.cpu().numpy(), 8, 12)).cuda() for t in pair)
+                         for pair in kv)
+        want = _emulate(model, ids, 10, pool, from_legacy, to_legacy)
+        text, n_new, est_mb = bench.generate_with_chunked_cache("<60>", 10, chunk_size=8, keep_last=12)
+        assert n_new == 10 and text == tok.decode(want[0]) and est_mb > 0
+
+
+def test_benchmark_method_dict_on_gpu(rig):
+    bench = rig[0]
+    for method in ("full_cache", "quant_int8", "quant_int4", "quant_mixed", "sliding_window", "chunked_cache"):
+        res = bench.benchmark_method(["<50>", "<70>"], method=method, max_new_tokens=6, window_size=32,
+                                     chunk_size=8, keep_last=16)
+        assert res["method"] == method and res["total_new_tokens"] == 12 and res["tokens_per_sec"] > 0
+        assert res["gpu_peak_mb"] is not None
+        if method.startswith("quant") or method == "chunked_cache":
+            assert res["est_kv_cache_mb_avg"] > 0
