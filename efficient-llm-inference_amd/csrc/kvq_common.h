@@ -38,6 +38,8 @@ struct Tunables {
   int64_t dequant_grid;          // 0 = auto
   int64_t quant_force_two_pass;  // 0/1
   int64_t pool_variant;
+  int64_t quant_ablate;  // benchmarks only
+  int64_t quant_direct_stores;  // 1 = skip the LDS-staged 16 B stores (tests / A-B)
 };
 Tunables& tunables();
 

@@ -59,72 +59,233 @@ __device__ inline int quant1(float x, float s32) {
 }
 
 // ---------------------------------------------------------------------------- fused single pass
-template <int IDT, int BITS>
+
+// DPP lane exchange inside a 16-lane row (single VALU op, no LDS traffic)
+template <int CTRL>
+__device__ inline uint32_t dpp_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+// unsigned max over aligned groups of 2^LOGW consecutive lanes; every lane gets the group max.
+// Order-preserving for the bit patterns of non-negative floats / halves.
+__device__ inline uint32_t group_umax(uint32_t v, int logw) {
+  if (logw > 0) v = max(v, dpp_u32<0xB1>(v));   // quad_perm(1,0,3,2): lane ^ 1
+  if (logw > 1) v = max(v, dpp_u32<0x4E>(v));   // quad_perm(2,3,0,1): lane ^ 2
+  if (logw > 2) v = max(v, dpp_u32<0x141>(v));  // row_half_mirror: quads of an 8-lane half
+  if (logw > 3) v = max(v, dpp_u32<0x140>(v));  // row_mirror: halves of a 16-lane row
+  if (logw > 4) v = max(v, (uint32_t)__shfl_xor((int)v, 16));
+  if (logw > 5) v = max(v, (uint32_t)__shfl_xor((int)v, 32));
+  return v;
+}
+
+// Tile element storage: 2-byte dtypes stay PACKED in registers (4 VGPRs per 8 elements) between
+// the abs-max pass and the quantise pass; fp32 keeps 8 floats.
+template <int IDT>
+struct Vec8 {
+  u32x4 w;
+  __device__ inline void load(const void* p) { w = *reinterpret_cast<const u32x4*>(p); }
+  // max |x| as an order-preserving bit pattern: sign-masked halves compared as unsigned ints
+  __device__ inline uint32_t absmax_bits() const {
+    typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+    u16x2 h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t a = w[i] & 0x7FFF7FFFu;
+      __builtin_memcpy(&h[i], &a, 4);
+    }
+    const u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(h[0], h[1]),
+                                              __builtin_elementwise_max(h[2], h[3]));  // v_pk_max_u16
+    return max((uint32_t)m[0], (uint32_t)m[1]);
+  }
+  __device__ static inline float bits_to_f32(uint32_t b) { return Elem<IDT>::widen((uint16_t)b); }
+  __device__ inline float get(int j) const {
+    return Elem<IDT>::widen((uint16_t)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xFFFFu)));
+  }
+};
+template <>
+struct Vec8<KVQ_F32> {
+  float x[8];
+  __device__ inline void load(const void* p) { load8<KVQ_F32>(p, x); }
+  __device__ inline uint32_t absmax_bits() const {
+    float m = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(x[j]));
+    return __float_as_uint(m);
+  }
+  __device__ static inline float bits_to_f32(uint32_t b) { return __uint_as_float(b); }
+  __device__ inline float get(int j) const { return x[j]; }
+};
+
+// rint(x / s32) + BIAS for 8 elements, returned in the low mantissa bits of
+// (1.5 * 2^23 + BIAS + q): bit-exact with IEEE division at a fraction of its cost.
+// Fast path: p = x * r with r = RN(1/s32). |p - x/s32| <= 2^-23 |p| (two roundings) and the
+// correctly rounded quotient RN(x/s32) is within 2^-24 |p| of x/s32, with |p| <= QMAX (1 + 2^-22)
+// because |x| <= amax and s32 >= RN(amax/QMAX). So if p is farther than
+// m = 1.5 * 2^-22 * QMAX (twice the error bound) from every half-integer, then p, x/s32 and
+// RN(x/s32) all round to the same integer. d = p - rint(p) is exact, and "within m of a
+// half-integer" is d*d >= (0.5 - m)^2. Otherwise (INT8: ~1 element in 11,000; INT4: ~1 in
+// 200,000) the 8-element vector is redone with the IEEE divide.
+// Rounding: adding 1.5 * 2^23 (even) rounds p to the nearest integer, ties to even — the same
+// integer as rint(p) — and leaves it in two's complement in the low mantissa bits.
+// No clamp is needed for finite inputs: the quotient is bounded by QMAX (1 + 2^-23), which
+// rounds to QMAX (the reference's clamp never fires either).
+template <int BITS, class V>
+__device__ inline void quotient_bits8(const V& v, float s32, float r, uint32_t (&qb)[8]) {
+  constexpr float kBias = BITS == 8 ? 0.0f : 8.0f;
+  constexpr float kMagic = 12582912.0f + kBias;  // 1.5 * 2^23 + BIAS
+  constexpr float kM = 1.5f * QRange<BITS>::qmax * 0x1p-22f;
+  constexpr float kThr = (0.5f - kM) * (0.5f - kM);
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 r2 = {r, r}, magic2 = {kMagic, kMagic};
+  float worst = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {  // two elements per v_pk_*_f32
+    const f32x2 x2 = {v.get(2 * k), v.get(2 * k + 1)};
+    const f32x2 p = x2 * r2;
+    const f32x2 sum = p + magic2;  // = kMagic + rint(p), exactly
+    const f32x2 d = p - (sum - magic2);
+    const f32x2 dd = d * d;
+    worst = fmaxf(worst, fmaxf(dd[0], dd[1]));
+    qb[2 * k] = __float_as_uint(sum[0]);
+    qb[2 * k + 1] = __float_as_uint(sum[1]);
+  }
+  if (__builtin_expect(worst >= kThr, 0)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qb[j] = __float_as_uint(rintf(v.get(j) / s32) + kMagic);
+  }
+}
+
+// low bytes of 4 words -> one word {b0, b1, b2, b3} (3 ops per 4 elements)
+__device__ inline uint32_t gather_low_bytes(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3) {
+  const uint32_t lo = __builtin_amdgcn_perm(q1, q0, 0x0C0C0400u);  // {q0.b0, q1.b0, 0, 0}
+  const uint32_t hi = __builtin_amdgcn_perm(q3, q2, 0x04000C0Cu);  // {0, 0, q2.b0, q3.b0}
+  return lo | hi;
+}
+// INT8: the two's complement low byte of the magic sum is q
+__device__ inline u32x2 pack_i8(const uint32_t (&qb)[8]) {
+  u32x2 w;
+  w[0] = gather_low_bytes(qb[0], qb[1], qb[2], qb[3]);
+  w[1] = gather_low_bytes(qb[4], qb[5], qb[6], qb[7]);
+  return w;
+}
+// INT4: low byte = q + 8 in [1, 15] (clean high nibble); even element -> HIGH nibble (ops.py:61-63)
+__device__ inline uint32_t pack_i4(const uint32_t (&qb)[8]) {
+  const uint32_t a = gather_low_bytes(qb[0], qb[1], qb[2], qb[3]);  // bytes n0..n3
+  const uint32_t b = gather_low_bytes(qb[4], qb[5], qb[6], qb[7]);  // bytes n4..n7
+  const uint32_t ta = (a << 4) | (a >> 8);  // byte0 = n0<<4|n1, byte2 = n2<<4|n3
+  const uint32_t tb = (b << 4) | (b >> 8);
+  return __builtin_amdgcn_perm(tb, ta, 0x06040200u);  // {ta.b0, ta.b2, tb.b0, tb.b2}
+}
+
+// ROWU: the tile has >= 256 vectors per row, so in round i every lane of the block works on the
+// same row (row index and its offsets are scalar) and (t, d) offsets collapse to wv * 8.
+template <int IDT, int BITS, bool ROWU, bool LDS_OUT>
 __global__ __launch_bounds__(kBlock) void quant_tokens_fused_k(const QuantArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_out[LDS_OUT ? kTileElems * BITS / 32 : 4];
   __shared__ uint32_t s_amax[kMaxTT];
+  __shared__ float s_scale[kMaxTT], s_rcp[kMaxTT];
   const uint32_t tid = threadIdx.x;
   const uint32_t g = blockIdx.y;
   const uint32_t t0 = blockIdx.x * a.TT;
   const uint32_t DV = a.D >> 3;
   const uint32_t wmask = (1u << a.vshift) - 1u;
-  const char* in = reinterpret_cast<const char*>(a.in.p[g]);
+  // is.t == D and qs.t == Dq (or a single token per tile), so within a row the tile is one
+  // contiguous run: element offset = wv * 8
+  const char* in = reinterpret_cast<const char*>(a.in.p[g]) + (int64_t)t0 * a.is.t * Elem<IDT>::size;
+  uint8_t* qbase = a.q + (int64_t)g * a.qs.g + (int64_t)t0 * a.qs.t;
+  constexpr int QV = BITS;  // bytes stored per 8-element vector: 8 (INT8) or 4 (INT4)
 
   if (tid < kMaxTT) s_amax[tid] = 0u;
   __syncthreads();
 
-  // pass 1: load the tile (kept in registers), per-vector abs-max
-  float x[kNVMax][8];
-  uint32_t vr[kNVMax], vtl[kNVMax], vdv[kNVMax];
+  // pass 1: load the tile (stays in registers), per-(row, token) abs-max -> LDS max across rows
+  Vec8<IDT> x[kNVMax];
   bool valid[kNVMax];
 #pragma unroll
   for (int i = 0; i < kNVMax; ++i) {
-    const uint32_t v = i * kBlock + tid;
-    const uint32_t r = v >> a.vshift;
-    const uint32_t wv = v & wmask;
-    const uint32_t tl = wv >> a.dvshift;
-    const uint32_t dv = wv & (DV - 1u);
-    vr[i] = r;
-    vtl[i] = tl;
-    vdv[i] = dv;
-    valid[i] = (v < a.nvec) && (t0 + tl < a.T);
-    float m = 0.0f;
-    if (valid[i]) {
-      const int64_t off = (int64_t)r * a.is.h + (int64_t)(t0 + tl) * a.is.t + (int64_t)dv * 8;
-      load8<IDT>(in + off * Elem<IDT>::size, x[i]);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(x[i][j]));
+    uint32_t r, wv;
+    if constexpr (ROWU) {
+      r = (uint32_t)(i * kBlock) >> a.vshift;
+      wv = ((uint32_t)(i * kBlock) & wmask) + tid;
+    } else {
+      const uint32_t v = i * kBlock + tid;
+      r = v >> a.vshift;
+      wv = v & wmask;
     }
-    // lanes of one (row, token) are DV consecutive lanes; whole waves reach the shuffles
-    if ((uint32_t)(i * kBlock) < a.nvec) {  // uniform: skip rounds no lane of the block uses
-      m = group_max(m, (int)DV);
-      if (valid[i] && dv == 0u) atomicMax(&s_amax[tl], __float_as_uint(m));
+    valid[i] = ((uint32_t)(i * kBlock) + tid < a.nvec) && (t0 + (wv >> a.dvshift) < a.T);
+    if (valid[i]) x[i].load(in + ((int64_t)r * a.is.h + (int64_t)wv * 8) * Elem<IDT>::size);
+  }
+#pragma unroll
+  for (int i = 0; i < kNVMax; ++i) {
+    if ((uint32_t)(i * kBlock) < a.nvec) {  // uniform: whole waves reach the lane exchanges
+      const uint32_t wv = ((uint32_t)(i * kBlock) + tid) & wmask;
+      uint32_t m = valid[i] ? x[i].absmax_bits() : 0u;
+      m = group_umax(m, a.dvshift);  // the D/8 lanes of one (row, token)
+      if (valid[i] && (wv & (DV - 1u)) == 0u) atomicMax(&s_amax[wv >> a.dvshift], m);
     }
   }
   __syncthreads();
 
-  // pass 2: scale, round, clamp, pack, store
+  // per-token scale, its reciprocal (both IEEE divides, once per token) and the stored scale
+  if (tid < a.TT && t0 + tid < a.T) {
+    const float amax = Vec8<IDT>::bits_to_f32(s_amax[tid]);
+    const float s32 = fmaxf(amax / QRange<BITS>::qmax, a.eps);
+    s_scale[tid] = s32;
+    s_rcp[tid] = 1.0f / s32;
+    a.scales[(int64_t)g * a.ssg + t0 + tid] = Elem<IDT>::round_trip(s32);
+  }
+  __syncthreads();
+
+  // pass 2: scale, round, pack, store
 #pragma unroll
   for (int i = 0; i < kNVMax; ++i) {
     if (!valid[i]) continue;
-    const uint32_t r = vr[i], tl = vtl[i], dv = vdv[i];
-    const float amax = __uint_as_float(s_amax[tl]);
-    const float s32 = fmaxf(amax / QRange<BITS>::qmax, a.eps);
-    uint8_t* qp = a.q + (int64_t)g * a.qs.g + (int64_t)r * a.qs.h + (int64_t)(t0 + tl) * a.qs.t;
-    if constexpr (BITS == 8) {
-      u32x2 w = {0u, 0u};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) w[j >> 2] |= ((uint32_t)quant1<8>(x[i][j], s32) & 0xFFu) << (8 * (j & 3));
-      *reinterpret_cast<u32x2*>(qp + dv * 8) = w;
+    uint32_t r, wv;
+    if constexpr (ROWU) {
+      r = (uint32_t)(i * kBlock) >> a.vshift;
+      wv = ((uint32_t)(i * kBlock) & wmask) + tid;
     } else {
-      uint32_t w = 0u;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const uint32_t nib = (uint32_t)(quant1<4>(x[i][j], s32) + 8) & 0xFu;
-        w |= nib << (8 * (j >> 1) + ((j & 1) ? 0 : 4));  // even element = high nibble
-      }
-      *reinterpret_cast<uint32_t*>(qp + dv * 4) = w;
+      const uint32_t v = i * kBlock + tid;
+      r = v >> a.vshift;
+      wv = v & wmask;
     }
-    if (r == 0u && dv == 0u) a.scales[(int64_t)g * a.ssg + t0 + tl] = Elem<IDT>::round_trip(s32);
+    const uint32_t tl = wv >> a.dvshift;
+    uint32_t qb[8];
+    quotient_bits8<BITS>(x[i], s_scale[tl], s_rcp[tl], qb);
+    if constexpr (LDS_OUT) {
+      // stage the packed bytes in LDS in output order (row-major, wv * QV within the row run)
+      const uint32_t widx = ((r << a.vshift) + wv) * (QV / 4);
+      if constexpr (BITS == 8) {
+        const u32x2 w = pack_i8(qb);
+        s_out[widx] = w[0];
+        s_out[widx + 1] = w[1];
+      } else {
+        s_out[widx] = pack_i4(qb);
+      }
+    } else {
+      uint8_t* qp = qbase + (int64_t)r * a.qs.h + (int64_t)wv * QV;
+      if constexpr (BITS == 8) *reinterpret_cast<u32x2*>(qp) = pack_i8(qb);
+      else *reinterpret_cast<uint32_t*>(qp) = pack_i4(qb);
+    }
+  }
+
+  if constexpr (LDS_OUT) {
+    // 16 B per lane, 1 KiB contiguous per wave store: each row of the tile is one run of
+    // TT * Dq bytes in the store (ablation: the direct 4 B/lane stores cost ~100 us of 354)
+    __syncthreads();
+    const uint32_t row_shift = a.vshift + (BITS == 8 ? 3 : 2);  // log2(bytes per full row run)
+    const uint32_t row_bytes = 1u << row_shift;
+    uint32_t nt = a.T - t0;
+    if (nt > a.TT) nt = a.TT;
+    const uint32_t valid_bytes = nt * (a.D * BITS / 8);  // ragged last tile: shorter runs
+    const uint32_t total = a.R << row_shift;
+    for (uint32_t k = tid * 16u; k < total; k += kBlock * 16u) {
+      const uint32_t r = k >> row_shift;
+      const uint32_t off = k & (row_bytes - 1u);
+      if (off < valid_bytes) {
+        const u32x4 w = *reinterpret_cast<const u32x4*>(&s_out[k >> 2]);
+        *reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off) = w;
+      }
+    }
   }
 }
 
@@ -196,7 +357,18 @@ template <int IDT, int BITS>
 static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
   if (fused) {
     const unsigned tiles = (a.T + a.TT - 1) / a.TT;
-    hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
+    // LDS-staged 16 B stores need 16-byte aligned row runs in the store
+    const int64_t dq = (int64_t)a.D * BITS / 8;
+    const bool lds_out = !tunables().quant_direct_stores && dq % 16 == 0 && a.qs.g % 16 == 0 && a.qs.h % 16 == 0 &&
+                         a.qs.t % 16 == 0 && aligned(a.q, 16);
+    if (a.vshift >= 8 && lds_out)
+      hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
+    else if (a.vshift >= 8)
+      hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, false>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
+    else if (lds_out)
+      hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, false, true>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
+    else
+      hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, false, false>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
   } else {
     const int64_t RD = (int64_t)a.R * a.D;
     const int64_t chunk_elems = (int64_t)kBlock * 16;
@@ -257,7 +429,7 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
   const int dvshift = d->D % 8 == 0 ? ilog2_exact(d->D / 8) : -1;
   const int64_t qvec = BITS == 8 ? 8 : 4;  // bytes stored per 8-element vector
   bool fused = !tunables().quant_force_two_pass && dvshift >= 0 && d->D / 8 <= kWave &&
-               R * d->D <= kTileElems && (d->T == 1 || a.is.t == d->D) &&
+               R * d->D <= kTileElems && (d->T == 1 || (a.is.t == d->D && a.qs.t == Dq)) &&
                (d->B == 1 || (a.is.b == d->H * a.is.h && a.qs.b == d->H * a.qs.h)) &&
                (a.is.h * esz) % 16 == 0 && (a.is.t * esz) % 16 == 0 && a.qs.h % qvec == 0 &&
                a.qs.t % qvec == 0 && a.qs.g % qvec == 0 && aligned(q, qvec);

@@ -73,13 +73,18 @@ __global__ void rand_fill_k(uint32_t* p, int64_t n_words, uint32_t seed) {
     p[i] = x;
   }
 }
-// fp16 N(0,1)-ish values from hashed bits (sum of 4 uniforms), so quantise sees realistic data
+// fp16 N(0,1) values (Box-Muller on hashed bits). A coarse lattice (e.g. sums of a few bytes)
+// makes x / scale hit exact half-integers constantly, which is not what KV tensors look like
+// and sends the quantise kernel down its rare exact-division path.
 __global__ void rand_f16_k(uint16_t* p, int64_t n, uint32_t seed) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     uint32_t x = (uint32_t)i * 2654435761u + seed;
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-    float u = ((x & 0xFF) + ((x >> 8) & 0xFF) + ((x >> 16) & 0xFF) + (x >> 24)) * (1.0f / 255.0f) - 2.0f;
-    _Float16 h = (_Float16)(u * 1.7f);
+    uint32_t y = x * 747796405u + 2891336453u;
+    y ^= y >> 15; y *= 0x2c1b3c6du; y ^= y >> 12;
+    const float u1 = ((x >> 8) + 1) * (1.0f / 16777217.0f), u2 = (y >> 8) * (1.0f / 16777216.0f);
+    const float g = sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);
+    _Float16 h = (_Float16)g;
     __builtin_memcpy(&p[i], &h, 2);
   }
 }
