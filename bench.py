@@ -40,6 +40,9 @@ WORKLOADS = {
     "gpt2m_int4_seq4k": (24, 1, 16, 4096, 64, "int4"),
     "gpt2_int8_seq1k": (12, 1, 12, 1024, 64, "int8"),
 }
+# BASELINE.json configs[1]/[2] as decode loops through KVCacheBenchmarker (random-init weights of
+# the named architecture; see benchmarking/offline.py): --workload decode:<arch>:<method>
+DECODE_DEFAULT = ("gpt2", "quant_int8", 512, 512)  # arch, method, prompt tokens, new tokens
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 BYTES_PER_ELT = {"int8": 3.0, "int4": 2.5}  # q read + fp16 write
 
@@ -49,7 +52,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="llama3_8b_mixed_seq16k", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="llama3_8b_mixed_seq16k",
+                    help="one of %s, or decode:<arch>:<method>[:<prompt_tokens>:<new_tokens>] "
+                         "(e.g. decode:gpt2:quant_int8:512:512; steps = prompts per rank)" % sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-layers", type=int, default=16)
     return ap.parse_args()
@@ -80,6 +85,45 @@ def cpu_baseline(L, B, H, T, D, sample_layers):
     }
 
 
+def run_decode(args, rank, world, dev):
+    """BASELINE configs[1]: decode tokens/sec + KV-cache MB through KVCacheBenchmarker.benchmark_method
+    (reference benchmarker.py:643-832), prompts sharded over ranks, counters aggregated once."""
+    import efficient_llm_inference_amd as E
+    from efficient_llm_inference_amd import sharding
+    from efficient_llm_inference_amd.benchmarking.offline import load_model
+    parts = args.workload.split(":")
+    arch = parts[1] if len(parts) > 1 else DECODE_DEFAULT[0]
+    method = parts[2] if len(parts) > 2 else DECODE_DEFAULT[1]
+    n_prompt = int(parts[3]) if len(parts) > 3 else DECODE_DEFAULT[2]
+    n_new = int(parts[4]) if len(parts) > 4 else DECODE_DEFAULT[3]
+    model, tok = load_model(arch, "cuda", torch.float16)
+    bm = E.KVCacheBenchmarker(model, tok, device="cuda")
+    prompts = [f"<{n_prompt}>"] * (args.steps * world)
+    for _ in range(args.warmup):
+        bm.benchmark_method([f"<{min(n_prompt, 64)}>"], method=method, max_new_tokens=8)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    res = sharding.benchmark_sharded(bm, prompts, method, max_new_tokens=n_new)
+    base = sharding.benchmark_sharded(bm, prompts, "full_cache", max_new_tokens=n_new)
+    if rank == 0:
+        cfg = model.config
+        print(json.dumps({
+            "metric": "decode tokens/sec + KV-cache MB", "value": round(res["tokens_per_sec"], 2), "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(res["elapsed_sec"] / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16 model, u8/u4 KV", "data": "synthetic",
+            "config": {"workload": args.workload, "arch": arch, "method": method, "prompt_tokens": n_prompt,
+                       "new_tokens": n_new, "weights": "random-init (offline)", "layers": cfg.n_layer,
+                       "heads": cfg.n_head, "head_dim": cfg.n_embd // cfg.n_head,
+                       "parallelism": f"prompt-shard x{world}, one all_reduce of counters"},
+            "est_kv_cache_mb": round(res["est_kv_cache_mb_avg"], 3),
+            "full_cache_tokens_per_sec": round(base["tokens_per_sec"], 2),
+            "vs_full_cache": round(res["tokens_per_sec"] / base["tokens_per_sec"], 3),
+            "gpu_peak_mb": res["gpu_peak_mb"],
+        }), flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -99,6 +143,14 @@ def main():
     from efficient_llm_inference_amd import _lib
 
     _lib.load()
+    if args.workload.startswith("decode"):
+        run_decode(args, rank, world, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if args.workload not in WORKLOADS:
+        raise SystemExit(f"unknown workload {args.workload}")
     L, B, H, T, D, mode = WORKLOADS[args.workload]
     kk, vk = {"int8": ("int8", "int8"), "int4": ("int4", "int4"), "mixed": ("int8", "int4")}[mode]
 
@@ -202,7 +254,7 @@ def main():
             "est_kv_cache_mb": round(est_mb, 3),
             "fp16_kv_cache_mb": round(2 * n_elts * 2 / 2**20, 3),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(L, B, H, T, D, args.cpu_sample_layers)
         print(json.dumps(line), flush=True)
     if world > 1:
