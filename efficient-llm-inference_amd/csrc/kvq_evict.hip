@@ -73,13 +73,18 @@ struct PoolArgs {
   float chunk_f;  // (float)chunk_size: the divisor, also for the ragged last chunk
 };
 
-constexpr int kPoolBatch = 8;  // independent 16-byte loads in flight per lane
+// independent 16-byte loads in flight per lane (raw packed registers: 4 VGPRs each for fp16/bf16)
+template <int DT>
+struct PoolBatch {
+  static constexpr int n = DT == KVQ_F32 ? 8 : 16;
+};
 
 // Fast path: D % 8 == 0, 16-byte aligned rows. One lane owns 8 consecutive d of one output
 // token; the D/8 lanes of a token read one contiguous row per step. fp32 accumulation is
 // sequential in t (bit-reproducible, mirrored by the oracle).
 template <int DT>
 __global__ __launch_bounds__(kBlock) void chunk_pool_vec_k(const PoolArgs a, uint32_t items_per_g) {
+  constexpr int NB = PoolBatch<DT>::n;
   const uint32_t g = blockIdx.y;
   const uint32_t DV = a.D >> 3;
   const uint32_t item = blockIdx.x * kBlock + threadIdx.x;
@@ -106,21 +111,22 @@ __global__ __launch_bounds__(kBlock) void chunk_pool_vec_k(const PoolArgs a, uin
   const uint32_t t0 = j * a.chunk;
   uint32_t n = a.old_len - t0;
   if (n > a.chunk) n = a.chunk;
+  const char* p = in + (int64_t)t0 * tstride;
   uint32_t i = 0;
-  for (; i + kPoolBatch <= n; i += kPoolBatch) {
-    float x[kPoolBatch][8];
+  for (; i + NB <= n; i += NB) {
+    Vec8<DT> x[NB];
 #pragma unroll
-    for (int u = 0; u < kPoolBatch; ++u) load8<DT>(in + (int64_t)(t0 + i + u) * tstride, x[u]);
+    for (int u = 0; u < NB; ++u) x[u].load(p + (int64_t)(i + u) * tstride);
 #pragma unroll
-    for (int u = 0; u < kPoolBatch; ++u)
+    for (int u = 0; u < NB; ++u)
 #pragma unroll
-      for (int k = 0; k < 8; ++k) acc[k] += x[u][k];
+      for (int k = 0; k < 8; ++k) acc[k] += x[u].get(k);
   }
   for (; i < n; ++i) {
-    float x[8];
-    load8<DT>(in + (int64_t)(t0 + i) * tstride, x);
+    Vec8<DT> x;
+    x.load(p + (int64_t)i * tstride);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] += x[k];
+    for (int k = 0; k < 8; ++k) acc[k] += x.get(k);
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = acc[k] / a.chunk_f;

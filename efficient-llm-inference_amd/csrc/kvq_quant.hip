@@ -77,44 +77,6 @@ __device__ inline uint32_t group_umax(uint32_t v, int logw) {
   return v;
 }
 
-// Tile element storage: 2-byte dtypes stay PACKED in registers (4 VGPRs per 8 elements) between
-// the abs-max pass and the quantise pass; fp32 keeps 8 floats.
-template <int IDT>
-struct Vec8 {
-  u32x4 w;
-  __device__ inline void load(const void* p) { w = *reinterpret_cast<const u32x4*>(p); }
-  // max |x| as an order-preserving bit pattern: sign-masked halves compared as unsigned ints
-  __device__ inline uint32_t absmax_bits() const {
-    typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
-    u16x2 h[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t a = w[i] & 0x7FFF7FFFu;
-      __builtin_memcpy(&h[i], &a, 4);
-    }
-    const u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(h[0], h[1]),
-                                              __builtin_elementwise_max(h[2], h[3]));  // v_pk_max_u16
-    return max((uint32_t)m[0], (uint32_t)m[1]);
-  }
-  __device__ static inline float bits_to_f32(uint32_t b) { return Elem<IDT>::widen((uint16_t)b); }
-  __device__ inline float get(int j) const {
-    return Elem<IDT>::widen((uint16_t)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xFFFFu)));
-  }
-};
-template <>
-struct Vec8<KVQ_F32> {
-  float x[8];
-  __device__ inline void load(const void* p) { load8<KVQ_F32>(p, x); }
-  __device__ inline uint32_t absmax_bits() const {
-    float m = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(x[j]));
-    return __float_as_uint(m);
-  }
-  __device__ static inline float bits_to_f32(uint32_t b) { return __uint_as_float(b); }
-  __device__ inline float get(int j) const { return x[j]; }
-};
-
 // rint(x / s32) + BIAS for 8 elements, returned in the low mantissa bits of
 // (1.5 * 2^23 + BIAS + q): bit-exact with IEEE division at a fraction of its cost.
 // Fast path: p = x * r with r = RN(1/s32). |p - x/s32| <= 2^-23 |p| (two roundings) and the
