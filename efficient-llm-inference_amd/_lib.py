@@ -35,6 +35,7 @@ EXPORTS = (
     "kvq_window_compact",
     "kvq_chunk_meanpool",
     "kvq_chunk_summary_len",
+    "kvq_gather_tokens",
     "kvq_set_tunable",
     "kvq_get_tunable",
 )
@@ -87,6 +88,8 @@ def _declare(lib):
     lib.kvq_window_compact.argtypes = [P, POINTER(c_void_p), ST, P, ST, c_int, c_int64, DM, P]
     lib.kvq_chunk_meanpool.restype = c_int
     lib.kvq_chunk_meanpool.argtypes = [P, POINTER(c_void_p), ST, P, ST, c_int, c_int64, c_int64, DM, P]
+    lib.kvq_gather_tokens.restype = c_int
+    lib.kvq_gather_tokens.argtypes = [P, POINTER(c_void_p), ST, P, ST, c_int, P, c_int64, DM, P]
     lib.kvq_chunk_summary_len.restype = c_int64
     lib.kvq_chunk_summary_len.argtypes = [c_int64, c_int64, c_int64]
     lib.kvq_set_tunable.restype = c_int

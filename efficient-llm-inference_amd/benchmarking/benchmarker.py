@@ -16,9 +16,8 @@ What is different underneath:
   * a shim bridges transformers >= 5 (``DynamicCache(ddp_cache_data=...)``, ``cache.layers[i]``)
     and 4.x (``from_legacy_cache`` / ``to_legacy_cache``, which the reference calls at 32 sites).
 
-Methods whose policies are outside this round's scope (paged_attention,
-prefix_window, strided_cache, block_cache, budget_cache) are accepted as names and raise
-``NotImplementedError``.
+All 12 method names of the reference are implemented; the index-select policies and the paged
+layout share one row-gather / block-stitch kernel each.
 """
 from __future__ import annotations
 
@@ -28,7 +27,15 @@ from typing import Callable, Optional, Tuple
 
 import torch
 
-from ..cache import chunk_summarize_kv, trim_kv_sliding_window
+from ..cache import (
+    PagedKVCache,
+    chunk_summarize_kv,
+    trim_kv_block_old,
+    trim_kv_budget_old,
+    trim_kv_prefix_window,
+    trim_kv_sliding_window,
+    trim_kv_strided,
+)
 from ..core.utils import get_cpu_mem_mb, get_gpu_peak_mb, mb, reset_gpu_peak
 from ..quantization import QuantizedKVCache
 
@@ -41,7 +48,6 @@ VALID_METHODS = [
     "no_cache", "full_cache", "sliding_window", "quant_int8", "quant_int4", "quant_mixed",
     "paged_attention", "chunked_cache", "prefix_window", "strided_cache", "block_cache", "budget_cache",
 ]
-_NEXT_ROUND = {"paged_attention", "prefix_window", "strided_cache", "block_cache", "budget_cache"}
 
 
 # ----------------------------------------------------------------------------- cache-format shim
@@ -207,25 +213,78 @@ class KVCacheBenchmarker:
         text, n_new = self._finish(generated, input_ids)
         return text, n_new, est_bytes / (1024**2)
 
-    def _not_this_round(self, name: str):
-        raise NotImplementedError(
-            f"kvq: '{name}' is scope row N3 (index-select eviction / paged layout), not built yet — see DESIGN.md §8")
+    @torch.no_grad()
+    def generate_with_prefix_window(self, prompt: str, max_new_tokens: int = 32, window_size: int = 256,
+                                    prefix_len: int = 32) -> Tuple[str, int]:
+        """Keep the first ``prefix_len`` + the last ``window_size`` tokens (reference
+        benchmarker.py:213-268; prompt truncated to 1024 tokens like the reference)."""
+        input_ids = self._encode(prompt, truncate=True)
+        generated = self._decode_with_policy(
+            input_ids, max_new_tokens,
+            lambda kv: from_legacy_tuple(trim_kv_prefix_window(kv, prefix_len=prefix_len, window_size=window_size)))
+        return self._finish(generated, input_ids)
 
-    def generate_with_paged_attention(self, prompt, max_new_tokens=32, block_size=64):
-        self._not_this_round("paged_attention")
+    @torch.no_grad()
+    def generate_with_strided_cache(self, prompt: str, max_new_tokens: int = 32, window_size: int = 256,
+                                    stride: int = 4, prefix_len: int = 0) -> Tuple[str, int]:
+        """Dense tail + every ``stride``-th older token (reference benchmarker.py:270-318)."""
+        input_ids = self._encode(prompt, truncate=True)
+        generated = self._decode_with_policy(
+            input_ids, max_new_tokens,
+            lambda kv: from_legacy_tuple(trim_kv_strided(kv, window_size=window_size, stride=stride,
+                                                         prefix_len=prefix_len)))
+        return self._finish(generated, input_ids)
 
-    def generate_with_prefix_window(self, prompt, max_new_tokens=32, window_size=256, prefix_len=32):
-        self._not_this_round("prefix_window")
+    @torch.no_grad()
+    def generate_with_block_cache(self, prompt: str, max_new_tokens: int = 32, window_size: int = 256,
+                                  block_size: int = 64, keep_per_block: int = 8, prefix_len: int = 0) -> Tuple[str, int]:
+        """Dense tail + the last ``keep_per_block`` tokens of every older block (reference
+        benchmarker.py:320-370)."""
+        input_ids = self._encode(prompt, truncate=True)
+        generated = self._decode_with_policy(
+            input_ids, max_new_tokens,
+            lambda kv: from_legacy_tuple(trim_kv_block_old(kv, window_size=window_size, block_size=block_size,
+                                                           keep_per_block=keep_per_block, prefix_len=prefix_len)))
+        return self._finish(generated, input_ids)
 
-    def generate_with_strided_cache(self, prompt, max_new_tokens=32, window_size=256, stride=4, prefix_len=0):
-        self._not_this_round("strided_cache")
+    @torch.no_grad()
+    def generate_with_budget_cache(self, prompt: str, max_new_tokens: int = 32, window_size: int = 256,
+                                   old_budget: int = 64, prefix_len: int = 0) -> Tuple[str, int]:
+        """Dense tail + a fixed budget of uniformly sampled older tokens (reference
+        benchmarker.py:372-420)."""
+        input_ids = self._encode(prompt, truncate=True)
+        generated = self._decode_with_policy(
+            input_ids, max_new_tokens,
+            lambda kv: from_legacy_tuple(trim_kv_budget_old(kv, window_size=window_size, old_budget=old_budget,
+                                                            prefix_len=prefix_len)))
+        return self._finish(generated, input_ids)
 
-    def generate_with_block_cache(self, prompt, max_new_tokens=32, window_size=256, block_size=64,
-                                  keep_per_block=8, prefix_len=0):
-        self._not_this_round("block_cache")
-
-    def generate_with_budget_cache(self, prompt, max_new_tokens=32, window_size=256, old_budget=64, prefix_len=0):
-        self._not_this_round("budget_cache")
+    @torch.no_grad()
+    def generate_with_paged_attention(self, prompt: str, max_new_tokens: int = 32,
+                                      block_size: int = 64) -> Tuple[str, int, float, float, int]:
+        """Simulated paged attention: KV kept in fixed-size blocks, stitched before every forward;
+        returns ``(text, n_new, alloc_mb, used_mb, num_blocks)`` (reference benchmarker.py:493-568)."""
+        input_ids = self._encode(prompt, truncate=False)
+        out = self.model(input_ids=input_ids, use_cache=True)
+        logits = out.logits[:, -1, :]
+        past_kv_tuple = to_legacy_tuple(out.past_key_values)
+        dtype = torch.float16 if self.device == "cuda" else torch.float32
+        paged = [PagedKVCache(block_size=block_size, device=self.device, dtype=dtype) for _ in past_kv_tuple]
+        for layer_cache, (k, v) in zip(paged, past_kv_tuple):
+            layer_cache.extend(k, v)  # == T single-token appends (reference :524-526)
+        generated = input_ids.clone()
+        for _ in range(max_new_tokens):
+            next_token = torch.argmax(logits, dim=-1, keepdim=True)
+            generated = torch.cat([generated, next_token], dim=-1)
+            past = from_legacy_tuple(tuple(layer_cache.get_kv() for layer_cache in paged))
+            out = self.model(input_ids=next_token, use_cache=True, past_key_values=past)
+            logits = out.logits[:, -1, :]
+            for layer_cache, (k, v) in zip(paged, to_legacy_tuple(out.past_key_values)):
+                layer_cache.append(k[:, :, -1:, :], v[:, :, -1:, :])
+        text, n_new = self._finish(generated, input_ids)
+        alloc = sum(lc.allocated_bytes() for lc in paged)
+        used = sum(lc.used_bytes() for lc in paged)
+        return text, n_new, mb(alloc), mb(used), sum(lc.num_blocks() for lc in paged)
 
     # ------------------------------------------------------------------ benchmarking
 
@@ -236,8 +295,6 @@ class KVCacheBenchmarker:
         """Run ``method`` over ``prompts`` (serially, B = 1 each, like the reference) and return
         the reference's result dict (benchmarker.py:811-832)."""
         assert method in VALID_METHODS, f"Invalid method: {method}"
-        if method in _NEXT_ROUND:
-            self._not_this_round(method)
 
         reset_gpu_peak(self.device)
         start_cpu = get_cpu_mem_mb()
@@ -265,9 +322,30 @@ class KVCacheBenchmarker:
             elif method in ("quant_int8", "quant_int4", "quant_mixed"):
                 # the mode comes from the method name; the `mode` argument is ignored (reference :719-735)
                 _, n_new, est = self.generate_with_quantized_kv(prompt, max_new_tokens, mode=method[len("quant_"):])
-            else:  # chunked_cache
+            elif method == "chunked_cache":
                 _, n_new, est = self.generate_with_chunked_cache(prompt, max_new_tokens, chunk_size=chunk_size,
                                                                  keep_last=keep_last)
+            elif method == "paged_attention":
+                _, n_new, est, _used, _nb = self.generate_with_paged_attention(prompt, max_new_tokens,
+                                                                               block_size=block_size)
+            elif method == "prefix_window":
+                _, n_new = self.generate_with_prefix_window(prompt, max_new_tokens=max_new_tokens,
+                                                            window_size=window_size, prefix_len=prefix_len)
+                est = float("nan")
+            elif method == "strided_cache":
+                _, n_new = self.generate_with_strided_cache(prompt, max_new_tokens=max_new_tokens,
+                                                            window_size=window_size, stride=stride, prefix_len=prefix_len)
+                est = float("nan")
+            elif method == "block_cache":
+                _, n_new = self.generate_with_block_cache(prompt, max_new_tokens=max_new_tokens,
+                                                          window_size=window_size, block_size=block_size,
+                                                          keep_per_block=keep_per_block, prefix_len=prefix_len)
+                est = float("nan")
+            else:  # budget_cache
+                _, n_new = self.generate_with_budget_cache(prompt, max_new_tokens=max_new_tokens,
+                                                           window_size=window_size, old_budget=old_budget,
+                                                           prefix_len=prefix_len)
+                est = float("nan")
             est_cache_mbs.append(est)
             total_new_tokens += n_new
 

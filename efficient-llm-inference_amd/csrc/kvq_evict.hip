@@ -60,6 +60,41 @@ __global__ __launch_bounds__(kBlock) void copy_rows_k(const CopyArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------- token gather
+
+struct GatherArgs {
+  PtrTable in;
+  Strides isb;  // bytes
+  char* out;
+  Strides osb;  // bytes
+  const int32_t* idx;
+  uint32_t H, n_idx;
+  uint32_t row_bytes;  // D * elem_size
+  uint32_t vecs;       // 16-byte vectors per token row (VEC) or 2-byte units (scalar)
+};
+
+// One lane = one 16-byte piece of one output token row; the lanes of a row read one contiguous
+// source row (HBM-bound row gather: 2 * elem_size bytes per kept element).
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void gather_tokens_k(const GatherArgs a, uint32_t items_per_g) {
+  const uint32_t g = blockIdx.y;
+  constexpr uint32_t kUnit = VEC ? 16u : 2u;
+  for (uint32_t item = blockIdx.x * kBlock + threadIdx.x; item < items_per_g; item += gridDim.x * kBlock) {
+    const uint32_t v = item % a.vecs;
+    uint32_t r = item / a.vecs;
+    const uint32_t j = r % a.n_idx;
+    r /= a.n_idx;
+    const uint32_t h = r % a.H, b = r / a.H;
+    const int64_t t = a.idx[j];
+    const char* src = reinterpret_cast<const char*>(a.in.p[g]) + (int64_t)b * a.isb.b + (int64_t)h * a.isb.h +
+                      t * a.isb.t + (int64_t)v * kUnit;
+    char* dst = a.out + (int64_t)g * a.osb.g + (int64_t)b * a.osb.b + (int64_t)h * a.osb.h + (int64_t)j * a.osb.t +
+                (int64_t)v * kUnit;
+    if constexpr (VEC) *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+    else *reinterpret_cast<uint16_t*>(dst) = *reinterpret_cast<const uint16_t*>(src);
+  }
+}
+
 // ---------------------------------------------------------------------------- chunk mean-pool
 
 struct PoolArgs {
@@ -245,6 +280,55 @@ int kvq_window_compact(const void* in_base, const void* const* in_ptrs, const kv
       hipLaunchKernelGGL((copy_rows_k<true>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a);
     else
       hipLaunchKernelGGL((copy_rows_k<false>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a);
+    rc = check_launch(name);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int kvq_gather_tokens(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st, void* out,
+                      const kvq_strides_t* out_st, int elem_size, const int32_t* idx, int64_t n_idx,
+                      const kvq_dims_t* d, void* stream) {
+  const char* name = "kvq_gather_tokens";
+  int rc = common_checks(in_base, in_ptrs, in_st, out, out_st, d, name);
+  if (rc) return rc;
+  if ((elem_size != 2 && elem_size != 4) || n_idx < 0 || n_idx >= (int64_t(1) << 31)) {
+    set_error("%s: elem_size must be 2 or 4 and 0 <= n_idx < 2^31", name);
+    return KVQ_E_DIMS;
+  }
+  if (d->G * d->B * d->H * n_idx * d->D == 0) return 0;
+  if (!idx) {
+    set_error("%s: idx is NULL", name);
+    return KVQ_E_NULL;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  GatherArgs a;
+  a.isb = Strides{in_st->g * elem_size, in_st->b * elem_size, in_st->h * elem_size, in_st->t * elem_size};
+  a.osb = Strides{out_st->g * elem_size, out_st->b * elem_size, out_st->h * elem_size, out_st->t * elem_size};
+  a.idx = idx;
+  a.H = (uint32_t)d->H;
+  a.n_idx = (uint32_t)n_idx;
+  a.row_bytes = (uint32_t)(d->D * elem_size);
+  for (int64_t g0 = 0; g0 < d->G; g0 += kPtrsPerLaunch) {
+    const int64_t gn = d->G - g0 < kPtrsPerLaunch ? d->G - g0 : kPtrsPerLaunch;
+    rc = fill_ptrs(a.in, in_base, in_ptrs, g0, gn, a.isb.g, 0, name);
+    if (rc) return rc;
+    a.out = static_cast<char*>(out) + g0 * a.osb.g;
+    bool vec = a.row_bytes % 16 == 0 && aligned(a.out, 16) && a.isb.b % 16 == 0 && a.isb.h % 16 == 0 &&
+               a.isb.t % 16 == 0 && a.osb.g % 16 == 0 && a.osb.b % 16 == 0 && a.osb.h % 16 == 0 && a.osb.t % 16 == 0;
+    for (int64_t i = 0; i < gn && vec; ++i) vec = aligned(a.in.p[i], 16);
+    a.vecs = a.row_bytes / (vec ? 16u : 2u);
+    const int64_t items = d->B * d->H * n_idx * (int64_t)a.vecs;
+    if (items >= (int64_t(1) << 32)) {
+      set_error("%s: too many elements per group", name);
+      return KVQ_E_DIMS;
+    }
+    int64_t blocks = (items + kBlock - 1) / kBlock;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    if (vec)
+      hipLaunchKernelGGL((gather_tokens_k<true>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a, (uint32_t)items);
+    else
+      hipLaunchKernelGGL((gather_tokens_k<false>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a, (uint32_t)items);
     rc = check_launch(name);
     if (rc) return rc;
   }

@@ -200,3 +200,25 @@ def chunk_meanpool(x: TensorOrList, out: torch.Tensor, chunk_size: int, keep_las
                                         dtype_code(dt), int(chunk_size), int(keep_last),
                                         byref(dims5(G, B, H, T, D)), _lib.current_stream(dev))
     check(rc, "chunk_meanpool")
+
+
+def gather_tokens(x: TensorOrList, out: torch.Tensor, idx: torch.Tensor) -> None:
+    """``out[g,b,h,j,:] = x[g,b,h,idx[j],:]``; idx: int32 DEVICE tensor [n]. out: [G,B,H,n,D], same
+    dtype. Reference: ``index_select(2, idx)`` + ``torch.cat`` of the sparse eviction family
+    (src/cache/implementations.py:143-292)."""
+    base, arr, ist, (G, B, H, T, D), dt, dev, _keep = _in_views(x)
+    require_gpu(out, "out")
+    require_gpu(idx, "idx")
+    n = idx.numel()
+    if idx.dtype != torch.int32 or idx.dim() != 1 or not idx.is_contiguous():
+        raise _lib.KvqError("kvq: idx must be a contiguous 1-D int32 tensor")
+    if tuple(out.shape) != (G, B, H, n, D) or out.dtype != dt:
+        raise _lib.KvqError(f"kvq: out must be {(G, B, H, n, D)} {dt}, got {tuple(out.shape)} {out.dtype}")
+    if dt.itemsize not in (2, 4):
+        raise _lib.KvqError(f"kvq: unsupported element size {dt.itemsize}")
+    if G * B * H * n * D == 0:
+        return
+    rc = _lib.load().kvq_gather_tokens(base, arr, byref(ist), c_void_p(out.data_ptr()), byref(strides4(out)),
+                                       dt.itemsize, c_void_p(idx.data_ptr()), n, byref(dims5(G, B, H, T, D)),
+                                       _lib.current_stream(dev))
+    check(rc, "gather_tokens")

@@ -147,6 +147,15 @@ int kvq_chunk_meanpool(const void* in_base, const void* const* in_ptrs, const kv
 
 int64_t kvq_chunk_summary_len(int64_t T, int64_t chunk_size, int64_t keep_last);
 
+/* Replaces the index_select + torch.cat of the sparse eviction family — trim_kv_prefix_window,
+ * trim_kv_strided, trim_kv_block_old, trim_kv_budget_old (src/cache/implementations.py:143-292):
+ *   out[g,b,h,j,:] = in[g,b,h,idx[j],:]   j < n_idx
+ * idx is a DEVICE array of n_idx int32 token indices in [0, dims->T) (built by the host from the
+ * policy; the library does not validate its contents). elem_size is 2 or 4 bytes. */
+int kvq_gather_tokens(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st,
+                      void* out, const kvq_strides_t* out_st, int elem_size, const int32_t* idx,
+                      int64_t n_idx, const kvq_dims_t* dims, void* stream);
+
 /* ---- tuning knobs (benchmarks only; defaults are what ships) ----------------------------- */
 
 /* key: "dequant_variant" (0..), "dequant_grid" (blocks, 0 = auto), "quant_force_two_pass" (0/1).

@@ -253,3 +253,83 @@ def chunk_summarize_kv(x: np.ndarray, chunk_size: int, keep_last: int, dtype: st
     pooled = (acc / F32(chunk_size)).astype(F32)
     pooled_st = _round_to_storage(pooled, x, dtype)
     return np.concatenate([pooled_st, x[..., old:, :]], axis=-2)
+
+
+# ------------------------------------------------ N3: index-select eviction family + paged layout
+# All four policies keep [optional prefix] + [selected older tokens] + [dense tail]; they differ
+# only in which older tokens are selected. Restated as index lists (host integers).
+
+
+def _tail_start(T: int, prefix_len: int, window_size: int) -> int:
+    return max(prefix_len, T - window_size)
+
+
+def keep_indices_prefix_window(T: int, prefix_len: int, window_size: int):
+    """``trim_kv_prefix_window`` (src/cache/implementations.py:143-154): first prefix_len + last
+    window_size tokens; None = unchanged (T <= prefix_len + window_size)."""
+    if T <= prefix_len + window_size:
+        return None
+    return list(range(prefix_len)) + list(range(T - window_size, T))
+
+
+def keep_indices_strided(T: int, window_size: int, stride: int, prefix_len: int = 0):
+    """``trim_kv_strided`` (implementations.py:157-190)."""
+    assert stride >= 1
+    if T <= prefix_len + window_size:
+        return None
+    ts = _tail_start(T, prefix_len, window_size)
+    return list(range(prefix_len)) + list(range(prefix_len, ts, stride)) + list(range(ts, T))
+
+
+def keep_indices_block_old(T: int, window_size: int, block_size: int = 64, keep_per_block: int = 8, prefix_len: int = 0):
+    """``trim_kv_block_old`` (implementations.py:193-245): last keep_per_block tokens of every
+    block_size-block of the older region (the ragged last block included)."""
+    assert block_size >= 1 and 1 <= keep_per_block <= block_size
+    if T <= prefix_len + window_size:
+        return None
+    ts = _tail_start(T, prefix_len, window_size)
+    old = []
+    start = prefix_len
+    while start < ts:
+        end = min(start + block_size, ts)
+        old += list(range(max(start, end - keep_per_block), end))
+        start = end
+    return list(range(prefix_len)) + old + list(range(ts, T))
+
+
+def keep_indices_budget_old(T: int, window_size: int, old_budget: int = 64, prefix_len: int = 0):
+    """``trim_kv_budget_old`` (implementations.py:248-292): old_budget tokens sampled with
+    ``torch.linspace(prefix_len, tail_start-1, steps=old_budget).long()`` (fp32 linspace, truncation)
+    then ``unique_consecutive`` (:279-282). numpy restatement of torch's symmetric fp32 linspace."""
+    assert old_budget >= 0
+    if T <= prefix_len + window_size:
+        return None
+    ts = _tail_start(T, prefix_len, window_size)
+    old_len = ts - prefix_len
+    old = []
+    if old_len > 0 and old_budget > 0:
+        if old_len <= old_budget:
+            old = list(range(prefix_len, ts))
+        else:
+            start, end, steps = np.float32(prefix_len), np.float32(ts - 1), old_budget
+            if steps == 1:
+                vals = np.array([start], dtype=np.float32)
+            else:
+                step = np.float32((end - start) / np.float32(steps - 1))
+                i = np.arange(steps)
+                half = steps // 2
+                lo = (start + step * i.astype(np.float32)).astype(np.float32)
+                hi = (end - step * (steps - 1 - i).astype(np.float32)).astype(np.float32)
+                vals = np.where(i < half, lo, hi).astype(np.float32)
+            idx = vals.astype(np.int64)  # .long(): truncation toward zero (values are >= 0)
+            keep = np.ones(len(idx), dtype=bool)
+            keep[1:] = idx[1:] != idx[:-1]  # unique_consecutive
+            old = idx[keep].tolist()
+    return list(range(prefix_len)) + old + list(range(ts, T))
+
+
+def gather_tokens(x: np.ndarray, idx) -> np.ndarray:
+    """index_select along the token axis of [..., T, D]; idx None = unchanged."""
+    if idx is None:
+        return x
+    return x[..., np.asarray(idx, dtype=np.int64), :]

@@ -28,7 +28,15 @@ import torch
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 sys.path.insert(0, REF)
 
-from src.cache.implementations import chunk_summarize_kv, trim_kv_sliding_window  # noqa: E402
+from src.cache.implementations import (  # noqa: E402
+    PagedKVCache,
+    chunk_summarize_kv,
+    trim_kv_block_old,
+    trim_kv_budget_old,
+    trim_kv_prefix_window,
+    trim_kv_sliding_window,
+    trim_kv_strided,
+)
 from src.quantization.ops import (  # noqa: E402
     QuantizedKVCache,
     dequantize_int4_per_tensor_packed,
@@ -183,9 +191,45 @@ def gen_evict():
     print("g6_evict:", len(out), "arrays; trajectory", lens)
 
 
+def gen_sparse():
+    """N3: index-select eviction family + PagedKVCache. Token rows are made identifiable
+    (value = token index + small per-channel offset) so the kept index list can be read back."""
+    out = {}
+    cases = []
+    for T in (5, 40, 41, 100, 300, 1000):
+        x = (torch.arange(T, dtype=torch.float32)[None, None, :, None] + torch.arange(8)[None, None, None, :] / 16.0)
+        x = x.expand(1, 2, T, 8).contiguous().half()
+        for (W, P) in ((8, 0), (8, 4), (32, 3), (256, 32)):
+            (k, _), = trim_kv_prefix_window(((x, x),), prefix_len=P, window_size=W)
+            out[f"prefix.T{T}.W{W}.P{P}"] = to_np(k[0, 0, :, 0].float().round().long())
+            for stride in (1, 3, 4):
+                (k, _), = trim_kv_strided(((x, x),), window_size=W, stride=stride, prefix_len=P)
+                out[f"strided.T{T}.W{W}.P{P}.s{stride}"] = to_np(k[0, 0, :, 0].float().round().long())
+            for (bs, kpb) in ((16, 4), (64, 8), (7, 7)):
+                (k, _), = trim_kv_block_old(((x, x),), window_size=W, block_size=bs, keep_per_block=kpb, prefix_len=P)
+                out[f"block.T{T}.W{W}.P{P}.b{bs}.k{kpb}"] = to_np(k[0, 0, :, 0].float().round().long())
+            for budget in (0, 1, 5, 64):
+                (k, _), = trim_kv_budget_old(((x, x),), window_size=W, old_budget=budget, prefix_len=P)
+                out[f"budget.T{T}.W{W}.P{P}.n{budget}"] = to_np(k[0, 0, :, 0].float().round().long())
+    # paged cache: append 21 tokens with block_size 8 -> 3 blocks, stitched back
+    g = torch.Generator().manual_seed(5000)
+    kv = torch.randn(2, 2, 3, 21, 8, generator=g).half()
+    pc = PagedKVCache(block_size=8, device="cpu", dtype=torch.float16)
+    for t in range(21):
+        pc.append(kv[0, :, :, t:t + 1], kv[1, :, :, t:t + 1])
+    k, v = pc.get_kv()
+    out["paged.kv"] = to_np(kv)
+    out["paged.k"] = to_np(k)
+    out["paged.v"] = to_np(v)
+    out["paged.meta"] = np.array([pc.num_blocks(), pc.allocated_bytes(), pc.used_bytes()], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "g7_sparse.npz"), **out)
+    print("g7_sparse:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     torch.manual_seed(42)
     gen_slices()
     gen_kat()
     gen_cache()
     gen_evict()
+    gen_sparse()

@@ -45,12 +45,11 @@ def test_cache_equals_no_cache_tokens(bench_cpu):
 def test_method_validation(bench_cpu):
     with pytest.raises(AssertionError, match="Invalid method"):
         bench_cpu.benchmark_method(["x"], method="quant_int2")
-    for m in ("paged_attention", "prefix_window", "strided_cache", "block_cache", "budget_cache"):
-        with pytest.raises(NotImplementedError):
-            bench_cpu.benchmark_method(["x"], method=m)
-    for m in ("quant_int8", "quant_int4", "quant_mixed", "sliding_window", "chunked_cache"):
+    for m in ("quant_int8", "quant_int4", "quant_mixed", "sliding_window", "chunked_cache", "paged_attention",
+              "prefix_window", "strided_cache", "block_cache", "budget_cache"):
         with pytest.raises(RuntimeError, match="MI355X"):  # hot path has no CPU implementation
-            bench_cpu.benchmark_method(["<40>"], method=m, max_new_tokens=2, window_size=8, keep_last=8, chunk_size=4)
+            bench_cpu.benchmark_method(["<40>"], method=m, max_new_tokens=2, window_size=8, keep_last=8, chunk_size=4,
+                                       prefix_len=2, block_size=8, keep_per_block=2, old_budget=4)
 
 
 def test_cache_format_shim_roundtrip():
