@@ -139,6 +139,10 @@ class _KVStore:
         self.B = self.H = self.D = None
         self.in_dtype: Optional[torch.dtype] = None
         self._want = 0  # capacity requested before the first append fixed B, H, D
+        # persistent dequantised staging (scope row N1): [G,B,H,cap,D] in the compute dtype; tokens
+        # [0, staged) of every group are already dequantised, so a decode step only adds the new one
+        self.stage: Optional[torch.Tensor] = None
+        self.staged = 0
 
     # -- allocation ---------------------------------------------------------------------------
     def reserve(self, T: int) -> None:
@@ -155,6 +159,11 @@ class _KVStore:
             q[:, :, :, :used] = self.q[:, :, :, :used]
             sc[:, :used] = self.scales[:, :used]
         self.q, self.scales, self.cap = q, sc, new_cap
+        if self.stage is not None:  # keep what is already dequantised
+            st = torch.empty(self.G, self.B, self.H, new_cap, self.D, dtype=self.stage.dtype, device=self.device)
+            if self.staged:
+                st[:, :, :, :self.staged] = self.stage[:, :, :, :self.staged]
+            self.stage = st
 
     def _bind(self, x: torch.Tensor) -> None:
         B, H, _, D = x.shape
@@ -205,6 +214,26 @@ class _KVStore:
             out = torch.empty(n, self.B, self.H, T, self.D, dtype=out_dtype, device=self.device)
         kernels.dequant_tokens(self.q[g0:g0 + n, :, :, :T], self.scales[g0:g0 + n, :T], out, self.kind)
         return out
+
+    def dequant_staged(self, out_dtype: torch.dtype) -> torch.Tensor:
+        """All groups, all tokens, as a VIEW ``[G,B,H,T,D]`` of the persistent staging buffer:
+        only tokens appended since the last call are dequantised (one launch, O(new tokens)
+        instead of the reference's O(T) re-dequantise + T-way cat per step, ops.py:213-269).
+        Values are identical to :meth:`dequant`. Earlier views stay valid: staged tokens are
+        never rewritten."""
+        T = self.lens[0]
+        if T == 0 or self.q is None:
+            raise ValueError("Empty cache")
+        if any(n != T for n in self.lens):
+            raise ValueError("kvq: groups dequantised together must hold the same number of tokens")
+        if self.stage is None or self.stage.dtype != out_dtype:
+            self.stage = torch.empty(self.G, self.B, self.H, self.cap, self.D, dtype=out_dtype, device=self.device)
+            self.staged = 0
+        if self.staged < T:
+            s0 = self.staged
+            kernels.dequant_tokens(self.q[:, :, :, s0:T], self.scales[:, s0:T], self.stage[:, :, :, s0:T], self.kind)
+            self.staged = T
+        return self.stage[:, :, :, :T]
 
     # -- accounting ---------------------------------------------------------------------------
     def stored_bytes(self, g: int) -> int:
@@ -303,8 +332,9 @@ class QuantizedKVCache:
     buffer and one launch, likewise V."""
 
     def __init__(self, n_layers: int, mode: str = "int8", device: str = "cuda",
-                 compute_dtype: torch.dtype = torch.float16):
+                 compute_dtype: torch.dtype = torch.float16, incremental: bool = True):
         assert mode in ["int8", "int4", "mixed"], f"Invalid mode: {mode}"
+        self.incremental = incremental
         self.mode = mode
         self.device = device
         self.compute_dtype = compute_dtype
@@ -345,11 +375,19 @@ class QuantizedKVCache:
     @torch.no_grad()
     def to_past_key_values(self) -> tuple:
         """Dequantise to the legacy tuple ``tuple_L[(K, V)]``, each ``[B,H,T,D]`` in compute_dtype
-        (reference ops.py:345-355): two launches; the tuple holds views of two fresh buffers."""
+        (reference ops.py:345-355): two launches. With ``incremental=True`` (default) the tuple
+        holds views of two persistent staging buffers and only tokens appended since the previous
+        call are dequantised; ``incremental=False`` re-dequantises everything into fresh buffers,
+        as the reference does. Same values either way."""
         if not self.layers:
             return tuple()
-        k = self._k.dequant(self.compute_dtype)
-        v = self._v.dequant(self.compute_dtype)
+        if self.incremental and len(set(self._k.lens)) == 1 and len(set(self._v.lens)) == 1:
+            # persistent staging: dequantise only what was appended since the last call
+            k = self._k.dequant_staged(self.compute_dtype)
+            v = self._v.dequant_staged(self.compute_dtype)
+        else:
+            k = self._k.dequant(self.compute_dtype)
+            v = self._v.dequant(self.compute_dtype)
         return tuple((k[i], v[i]) for i in range(len(self.layers)))
 
     def estimated_bytes(self) -> int:

@@ -301,3 +301,26 @@ def test_oracle_eviction_multi_layer(E, shape, chunk, keep, W, dtype):
     res = E.chunk_summarize_kv(past, chunk, keep)
     for l in range(G // 2):
         assert np.array_equal(bits(res[l][0]), bits(orc[2 * l]))
+
+
+def test_incremental_staging_equals_full_dequant(E):
+    """Scope row N1: persistent staging (dequantise only new tokens) returns the same bytes as a
+    full re-dequantise, across appends and capacity growth; earlier views stay valid."""
+    L, B, H, D = 3, 1, 4, 64
+    kv = to_torch(seeded_kv((L, 2, B, H, 90, D), "f16", 23, "heavy"))
+    inc = E.QuantizedKVCache(L, "mixed", incremental=True)
+    ref = E.QuantizedKVCache(L, "mixed", incremental=False)
+    first = None
+    for T in (17, 18, 19, 40, 41, 90):  # growth past the initial capacity happens on the way
+        t0 = len(inc.layers[0])
+        chunk = tuple((kv[l, 0, :, :, t0:T], kv[l, 1, :, :, t0:T]) for l in range(L))
+        for c in (inc, ref):
+            c._k.append([k for k, _ in chunk])
+            c._v.append([v for _, v in chunk])
+        a, b = inc.to_past_key_values(), ref.to_past_key_values()
+        if first is None:
+            first = (a[0][0], a[0][0].clone())
+        for (ka, va), (kb, vb) in zip(a, b):
+            assert ka.shape == (B, H, T, D) and torch.equal(ka, kb) and torch.equal(va, vb)
+        assert torch.equal(first[0], first[1])  # an old view is never rewritten
+    assert inc._k.staged == 90 and inc.to_past_key_values()[1][1].data_ptr() == a[1][1].data_ptr()
