@@ -43,6 +43,9 @@ WORKLOADS = {
 # BASELINE.json configs[1]/[2] as decode loops through KVCacheBenchmarker (random-init weights of
 # the named architecture; see benchmarking/offline.py): --workload decode:<arch>:<method>
 DECODE_DEFAULT = ("gpt2", "quant_int8", 512, 512)  # arch, method, prompt tokens, new tokens
+# BASELINE.json configs[4]: Llama-3-8B sliding_window + chunk_summary, seq 32K, batch 64 sharded
+# over 8 GPUs = 8 batch rows per GPU: per-rank KV [L=32, 2, B=8, H=8, T=32768, D=128] fp16 = 32 GiB
+EVICT = {"llama3_8b_evict_seq32k": (32, 8, 8, 32768, 128, 256, 64, 256)}  # L,B,H,T,D,window,chunk,keep_last
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 BYTES_PER_ELT = {"int8": 3.0, "int4": 2.5}  # q read + fp16 write
 
@@ -124,6 +127,73 @@ def run_decode(args, rank, world, dev):
         }), flush=True)
 
 
+def run_evict(args, rank, world, dev):
+    """configs[4] per-rank slice: one STEP = trim_kv_sliding_window + chunk_summarize_kv over the
+    whole legacy tuple (64 tensors of [8,8,32768,128] fp16): two launches, inputs resident."""
+    import efficient_llm_inference_amd as E
+    L, B, H, T, D, W, chunk, keep = EVICT[args.workload]
+    torch.manual_seed(42 + rank)
+    past = tuple((torch.randn(B, H, T, D, device=dev, dtype=torch.float16),
+                  torch.randn(B, H, T, D, device=dev, dtype=torch.float16)) for _ in range(L))
+    from efficient_llm_inference_amd.kernels import chunk_summary_len
+    Tout = chunk_summary_len(T, chunk, keep)
+    n_t = 2 * L
+    bytes_win = 4.0 * n_t * B * H * W * D                      # 2 B read + 2 B write per kept element
+    bytes_pool = 2.0 * n_t * B * H * D * (T + Tout)            # read every token once, write Tout rows
+    step_bytes = bytes_win + bytes_pool
+
+    def step(evs=None):
+        if evs is not None:
+            evs[0].record()
+        E.trim_kv_sliding_window(past, W)
+        if evs is not None:
+            evs[1].record()
+        E.chunk_summarize_kv(past, chunk_size=chunk, keep_last=keep)
+        if evs is not None:
+            evs[2].record()
+
+    for _ in range(args.warmup):
+        step()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(events[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    w_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
+    p_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "KV eviction GB/s vs HBM roofline (sliding_window + chunk_summary step)",
+            "value": round(step_bytes * world / (elapsed / args.steps) / 1e9, 1), "unit": "GB/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 (fp32 accumulate)",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "shape_per_rank_L2BHTD": [L, 2, B, H, T, D], "window": W,
+                       "chunk_size": chunk, "keep_last": keep, "global_batch": B * world,
+                       "parallelism": f"batch-shard x{world} (8 rows per GPU), no collective"},
+            "roofline": {"kernel": "chunk_pool_vec_k<f16>", "bound": "hbm",
+                         "achieved": round(bytes_pool / (p_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(bytes_pool / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(bytes_pool), "avg_launch_ms": round(p_ms, 4)},
+            "roofline_window": {"kernel": "copy_rows_k", "achieved": round(bytes_win / (w_ms * 1e-3) / 1e9, 1),
+                                "frac": round(bytes_win / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                "algorithmic_bytes_per_launch": int(bytes_win), "avg_launch_ms": round(w_ms, 4),
+                                "note": "includes torch.empty + host launch path; 0.5 GB per launch"},
+        }), flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -145,6 +215,12 @@ def main():
     _lib.load()
     if args.workload.startswith("decode"):
         run_decode(args, rank, world, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if args.workload in EVICT:
+        run_evict(args, rank, world, dev)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -223,7 +299,7 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "KV dequant GB/s vs HBM roofline (quant_mixed step: INT8 K + INT4 V -> fp16)",
+            "metric": f"KV dequant GB/s vs HBM roofline (quant_{mode} step: {kk.upper()} K + {vk.upper()} V -> fp16)",
             "value": round(value, 1),
             "unit": "GB/s",
             "n_gpus": world,
