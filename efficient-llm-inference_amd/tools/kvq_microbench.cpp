@@ -105,12 +105,14 @@ struct Timer {
   }
 };
 
-static const int64_t G = 32, B = 1, H = 8, T = 16384, D = 128;
+static int64_t G = 32, B = 1, H = 8, T = 16384, D = 128;  // override: KVQ_G / KVQ_T (G*T kept = 524288 by the caller)
 
 int main(int argc, char** argv) {
   std::string what = argc > 1 ? argv[1] : "all";
   int iters = argc > 2 ? atoi(argv[2]) : 20;
   int n_variants = argc > 3 ? atoi(argv[3]) : 12;
+  if (getenv("KVQ_G")) G = atoll(getenv("KVQ_G"));
+  if (getenv("KVQ_T")) T = atoll(getenv("KVQ_T"));
   hipDeviceProp_t prop;
   HIP_OK(hipGetDeviceProperties(&prop, 0));
   printf("# device %s CUs=%d  shape G=%lld B=%lld H=%lld T=%lld D=%lld iters=%d\n", prop.gcnArchName,
