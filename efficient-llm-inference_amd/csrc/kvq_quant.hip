@@ -39,6 +39,8 @@ struct QuantArgs {
   int32_t dvshift;   // log2(D/8)
   int32_t vshift;    // log2(TT * D/8)
   uint32_t nvec;     // R * TT * D/8 vectors per full tile
+  uint32_t rpc;      // sweep kernel: rows per sweep step
+  int32_t bh_contig; // rows addressable as r * stride_h on both sides
 };
 
 template <int BITS>
@@ -251,6 +253,85 @@ __global__ __launch_bounds__(kBlock) void quant_tokens_fused_k(const QuantArgs a
   }
 }
 
+// ---------------------------------------------------------------------------- swept tile (any R)
+// Batched slices whose B*H*D exceeds the register tile (e.g. B = 64): the workgroup still owns
+// TT tokens x all R rows of one group, but sweeps the rows twice in steps of `rpc` rows — once for
+// the per-token abs-max (LDS), once to quantise. The second sweep re-reads what the workgroup has
+// just read (tile sized to stay cache-resident), no global atomics, no workspace.
+template <int IDT, int BITS>
+__global__ __launch_bounds__(kBlock) void quant_tokens_sweep_k(const QuantArgs a) {
+  __shared__ uint32_t s_amax[kMaxTT];
+  __shared__ float s_scale[kMaxTT], s_rcp[kMaxTT];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t g = blockIdx.y;
+  const uint32_t t0 = blockIdx.x * a.TT;
+  const uint32_t DV = a.D >> 3;
+  const uint32_t wmask = (1u << a.vshift) - 1u;
+  const char* in = reinterpret_cast<const char*>(a.in.p[g]) + (int64_t)t0 * a.is.t * Elem<IDT>::size;
+  uint8_t* qbase = a.q + (int64_t)g * a.qs.g + (int64_t)t0 * a.qs.t;
+  constexpr int QV = BITS;
+  auto in_row = [&](uint32_t r) -> int64_t {
+    return a.bh_contig ? (int64_t)r * a.is.h : (int64_t)(r / a.H) * a.is.b + (int64_t)(r % a.H) * a.is.h;
+  };
+  auto q_row = [&](uint32_t r) -> int64_t {
+    return a.bh_contig ? (int64_t)r * a.qs.h : (int64_t)(r / a.H) * a.qs.b + (int64_t)(r % a.H) * a.qs.h;
+  };
+
+  if (tid < kMaxTT) s_amax[tid] = 0u;
+  __syncthreads();
+
+  for (uint32_t r0 = 0; r0 < a.R; r0 += a.rpc) {  // sweep 1: abs-max
+    const uint32_t rows = a.R - r0 < a.rpc ? a.R - r0 : a.rpc;
+    const uint32_t nv = rows << a.vshift;
+#pragma unroll
+    for (int i = 0; i < kNVMax; ++i) {
+      if ((uint32_t)(i * kBlock) < nv) {  // uniform
+        const uint32_t v = i * kBlock + tid;
+        const uint32_t wv = v & wmask;
+        const bool ok = v < nv && t0 + (wv >> a.dvshift) < a.T;
+        uint32_t m = 0u;
+        if (ok) {
+          Vec8<IDT> x;
+          x.load(in + (in_row(r0 + (v >> a.vshift)) + (int64_t)wv * 8) * Elem<IDT>::size);
+          m = x.absmax_bits();
+        }
+        m = group_umax(m, a.dvshift);
+        if (ok && (wv & (DV - 1u)) == 0u) atomicMax(&s_amax[wv >> a.dvshift], m);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < a.TT && t0 + tid < a.T) {
+    const float amax = Vec8<IDT>::bits_to_f32(s_amax[tid]);
+    const float s32 = fmaxf(amax / QRange<BITS>::qmax, a.eps);
+    s_scale[tid] = s32;
+    s_rcp[tid] = 1.0f / s32;
+    a.scales[(int64_t)g * a.ssg + t0 + tid] = Elem<IDT>::round_trip(s32);
+  }
+  __syncthreads();
+
+  for (uint32_t r0 = 0; r0 < a.R; r0 += a.rpc) {  // sweep 2: quantise
+    const uint32_t rows = a.R - r0 < a.rpc ? a.R - r0 : a.rpc;
+    const uint32_t nv = rows << a.vshift;
+#pragma unroll
+    for (int i = 0; i < kNVMax; ++i) {
+      const uint32_t v = i * kBlock + tid;
+      const uint32_t wv = v & wmask;
+      const uint32_t tl = wv >> a.dvshift;
+      if (v < nv && t0 + tl < a.T) {
+        const uint32_t r = r0 + (v >> a.vshift);
+        Vec8<IDT> x;
+        x.load(in + (in_row(r) + (int64_t)wv * 8) * Elem<IDT>::size);
+        uint32_t qb[8];
+        quotient_bits8<BITS>(x, s_scale[tl], s_rcp[tl], qb);
+        uint8_t* qp = qbase + q_row(r) + (int64_t)wv * QV;
+        if constexpr (BITS == 8) *reinterpret_cast<u32x2*>(qp) = pack_i8(qb);
+        else *reinterpret_cast<uint32_t*>(qp) = pack_i4(qb);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------- generic two-pass
 // Any D (odd included), any strides / alignment, any B*H*D size.
 template <int IDT>
@@ -317,7 +398,10 @@ static uint32_t pow2_floor(uint64_t v) {
 
 template <int IDT, int BITS>
 static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
-  if (fused) {
+  if (fused && a.rpc) {  // swept tile: B*H*D larger than the register tile
+    const unsigned tiles = (a.T + a.TT - 1) / a.TT;
+    hipLaunchKernelGGL((quant_tokens_sweep_k<IDT, BITS>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
+  } else if (fused) {
     const unsigned tiles = (a.T + a.TT - 1) / a.TT;
     // LDS-staged 16 B stores need 16-byte aligned row runs in the store
     const int64_t dq = (int64_t)a.D * BITS / 8;
@@ -390,12 +474,27 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
   // fused single-pass eligibility (layout); pointer alignment is checked per launch chunk below
   const int dvshift = d->D % 8 == 0 ? ilog2_exact(d->D / 8) : -1;
   const int64_t qvec = BITS == 8 ? 8 : 4;  // bytes stored per 8-element vector
-  bool fused = !tunables().quant_force_two_pass && dvshift >= 0 && d->D / 8 <= kWave &&
-               R * d->D <= kTileElems && (d->T == 1 || (a.is.t == d->D && a.qs.t == Dq)) &&
-               (d->B == 1 || (a.is.b == d->H * a.is.h && a.qs.b == d->H * a.qs.h)) &&
+  const bool bh_contig = d->B == 1 || (a.is.b == d->H * a.is.h && a.qs.b == d->H * a.qs.h);
+  const bool big = R * d->D > kTileElems;  // swept-tile kernel instead of the register tile
+  bool fused = !tunables().quant_force_two_pass && dvshift >= 0 && d->D / 8 <= kWave && d->D <= kTileElems &&
+               (d->T == 1 || (a.is.t == d->D && a.qs.t == Dq)) && (big || bh_contig) &&
+               (a.is.b * esz) % 16 == 0 && a.qs.b % qvec == 0 &&
                (a.is.h * esz) % 16 == 0 && (a.is.t * esz) % 16 == 0 && a.qs.h % qvec == 0 &&
                a.qs.t % qvec == 0 && a.qs.g % qvec == 0 && aligned(q, qvec);
-  if (fused) {
+  a.rpc = 0;
+  a.bh_contig = bh_contig ? 1 : 0;
+  if (fused && big) {
+    // tile = R x TT tokens, kept around 256 KiB so the second sweep is served from cache
+    uint64_t tt = pow2_floor((uint64_t)((256 * 1024) / (R * d->D * esz) > 0 ? (256 * 1024) / (R * d->D * esz) : 1));
+    if (tt > (uint64_t)kMaxTT) tt = kMaxTT;
+    while (tt > 1 && tt * d->D > (uint64_t)kTileElems) tt /= 2;
+    while (tt > 1 && tt / 2 >= (uint64_t)d->T) tt /= 2;
+    a.TT = (uint32_t)tt;
+    a.dvshift = dvshift;
+    a.vshift = dvshift + ilog2_exact((int64_t)tt);
+    a.nvec = 0;
+    a.rpc = (uint32_t)((kBlock * kNVMax) >> a.vshift);  // rows covered by one sweep step (>= 1)
+  } else if (fused) {
     uint32_t tt = pow2_floor((uint64_t)(kTileElems / (R * d->D)));
     if (tt > kMaxTT) tt = kMaxTT;
     while (tt > 1 && tt / 2 >= (uint64_t)d->T) tt /= 2;  // do not over-tile short appends
@@ -407,6 +506,7 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
     a.TT = 1;
     a.dvshift = a.vshift = 0;
     a.nvec = 0;
+    a.rpc = 0;
     if (!absmax_ws) {
       set_error("%s: absmax_ws workspace required for this shape (two-pass path)", name);
       return KVQ_E_NULL;
@@ -439,6 +539,7 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
       b.TT = 1;
       b.dvshift = b.vshift = 0;
       b.nvec = 0;
+      b.rpc = 0;
     }
     switch (in_dtype) {
       case KVQ_F16: launch_quant<KVQ_F16, BITS>(b, fused_here, st); break;

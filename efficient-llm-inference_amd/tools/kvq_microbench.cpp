@@ -113,6 +113,8 @@ int main(int argc, char** argv) {
   int n_variants = argc > 3 ? atoi(argv[3]) : 12;
   if (getenv("KVQ_G")) G = atoll(getenv("KVQ_G"));
   if (getenv("KVQ_T")) T = atoll(getenv("KVQ_T"));
+  if (getenv("KVQ_B")) B = atoll(getenv("KVQ_B"));
+  if (getenv("KVQ_H")) H = atoll(getenv("KVQ_H"));
   hipDeviceProp_t prop;
   HIP_OK(hipGetDeviceProperties(&prop, 0));
   printf("# device %s CUs=%d  shape G=%lld B=%lld H=%lld T=%lld D=%lld iters=%d\n", prop.gcnArchName,

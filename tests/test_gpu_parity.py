@@ -125,7 +125,8 @@ CASES = [  # (G, B, H, T, D)
     (2, 1, 16, 64, 64),    # gpt2-medium
     (2, 2, 4, 33, 32),     # batch > 1
     (2, 8, 8, 5, 128),     # R*D = 8192 -> 2 tokens per tile
-    (1, 64, 8, 3, 128),    # R*D = 65536 > tile: two-pass path
+    (1, 64, 8, 3, 128),    # R*D = 65536 > register tile: swept-tile kernel
+    (2, 40, 8, 21, 64),    # R*D = 20480: swept tile, several tokens per tile, ragged last tile
     (2, 2, 3, 7, 5),       # odd D: generic kernels
     (1, 1, 2, 4, 24),      # D % 8 == 0 but D/8 not a power of two: generic quantise
 ]
@@ -324,3 +325,21 @@ def test_incremental_staging_equals_full_dequant(E):
             assert ka.shape == (B, H, T, D) and torch.equal(ka, kb) and torch.equal(va, vb)
         assert torch.equal(first[0], first[1])  # an old view is never rewritten
     assert inc._k.staged == 90 and inc.to_past_key_values()[1][1].data_ptr() == a[1][1].data_ptr()
+
+
+@pytest.mark.parametrize("kind", ["int8", "int4"])
+def test_quant_batch_strided_input(E, kind):
+    """B > 1 with a batch stride that is not H * stride_h (every other batch row of a larger
+    tensor): register-tile kernel is not eligible, swept-tile / generic paths must agree."""
+    from efficient_llm_inference_amd import kernels
+    for (G, B, H, T, D) in ((2, 3, 4, 9, 64), (1, 40, 8, 5, 128)):
+        big_np = seeded_kv((G, 2 * B, H, T, D), "f16", 41, "heavy")
+        x = to_torch(big_np)[:, ::2]
+        x_np = big_np[:, ::2]
+        q_ref, _, s32_ref = O.quantize_tokens(np.ascontiguousarray(x_np), kind)
+        Dq = kernels.packed_dim(kind, D)
+        store = torch.zeros(G, B, H, T, Dq, dtype=kernels.QDTYPE[kind], device="cuda")
+        scales = torch.zeros(G, T, dtype=torch.float32, device="cuda")
+        ws = torch.empty(G * T, dtype=torch.float32, device="cuda")
+        kernels.quant_tokens(x, store, scales, ws, kind)
+        assert np.array_equal(to_numpy(store), q_ref) and np.array_equal(bits(scales), bits(s32_ref))
