@@ -127,3 +127,16 @@ def test_sharded_benchmark_world_size_2_gloo():
         assert total == 20 and n_prompts == 5 and n_ranks == 2  # 5 prompts x 4 tokens, both ranks agree
         assert abs(tps - total / elapsed) < 1e-9
     assert out[0][4] == out[1][4]  # max-over-ranks elapsed identical on every rank
+
+
+def test_quality_helpers(bench_cpu):
+    from efficient_llm_inference_amd.evaluation import (compute_perplexity, compute_sliding_window_nll,
+                                                        text_similarity, token_agreement_rate)
+    assert text_similarity("abc", "abc") == 1.0 and text_similarity("abc", "xyz") == 0.0
+    assert token_agreement_rate([1, 2, 3, 4], [1, 9, 3]) == 2 / 3 and token_agreement_rate([], [1]) == 0.0
+    nll, ppl = compute_perplexity(bench_cpu.model, bench_cpu.tokenizer, ["<24>", "hello there"], device="cpu")
+    assert nll > 0 and abs(ppl - __import__("math").exp(nll)) < 1e-9
+    # a window longer than the text equals no trimming at all
+    a = compute_sliding_window_nll(bench_cpu.model, bench_cpu.tokenizer, "<20>", window_size=64, device="cpu")
+    b = compute_sliding_window_nll(bench_cpu.model, bench_cpu.tokenizer, "<20>", window_size=4, device="cpu")
+    assert a[0] > 0 and b[0] > 0 and a != b
