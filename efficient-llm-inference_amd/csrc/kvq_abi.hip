@@ -27,7 +27,7 @@ int check_launch(const char* what) {
 }
 
 Tunables& tunables() {
-  static Tunables t = {-1, 0, 0, -1, 0, 0};
+  static Tunables t = {-1, 0, 0, 0};
   return t;
 }
 
@@ -45,8 +45,6 @@ int kvq_set_tunable(const char* key, int64_t value) {
   if (!strcmp(key, "dequant_variant")) t.dequant_variant = value;
   else if (!strcmp(key, "dequant_grid")) t.dequant_grid = value;
   else if (!strcmp(key, "quant_force_two_pass")) t.quant_force_two_pass = value;
-  else if (!strcmp(key, "pool_variant")) t.pool_variant = value;
-  else if (!strcmp(key, "quant_ablate")) t.quant_ablate = value;
   else if (!strcmp(key, "quant_direct_stores")) t.quant_direct_stores = value;
   else {
     kvq::set_error("kvq_set_tunable: unknown key '%s'", key);
@@ -61,8 +59,6 @@ int64_t kvq_get_tunable(const char* key) {
   if (!strcmp(key, "dequant_variant")) return t.dequant_variant;
   if (!strcmp(key, "dequant_grid")) return t.dequant_grid;
   if (!strcmp(key, "quant_force_two_pass")) return t.quant_force_two_pass;
-  if (!strcmp(key, "pool_variant")) return t.pool_variant;
-  if (!strcmp(key, "quant_ablate")) return t.quant_ablate;
   if (!strcmp(key, "quant_direct_stores")) return t.quant_direct_stores;
   return 0;
 }

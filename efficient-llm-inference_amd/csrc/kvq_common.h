@@ -35,11 +35,9 @@ int check_launch(const char* what);
 
 struct Tunables {
   int64_t dequant_variant;       // -1 = shipped default
-  int64_t dequant_grid;          // 0 = auto
-  int64_t quant_force_two_pass;  // 0/1
-  int64_t pool_variant;
-  int64_t quant_ablate;  // benchmarks only
-  int64_t quant_direct_stores;  // 1 = skip the LDS-staged 16 B stores (tests / A-B)
+  int64_t dequant_grid;          // 0 = one chunk per workgroup
+  int64_t quant_force_two_pass;  // 1 = generic two-pass quantise for every shape (tests)
+  int64_t quant_direct_stores;   // 1 = skip the LDS-staged 16 B stores (tests / A-B)
 };
 Tunables& tunables();
 

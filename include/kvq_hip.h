@@ -53,10 +53,9 @@ extern "C" {
 #define KVQ_E_NULL (-1)      /* required pointer is NULL */
 #define KVQ_E_DIMS (-2)      /* negative / inconsistent dims or strides */
 #define KVQ_E_DTYPE (-3)     /* unknown dtype code */
-#define KVQ_E_ALIGN (-4)     /* flat entry point needs a layout it was not given */
-#define KVQ_E_TOO_MANY (-5)  /* more than KVQ_MAX_PTRS pointers in one call */
 
-#define KVQ_MAX_PTRS 256 /* pointer-list entry points chunk internally; this is the cap per call */
+/* Pointer-list entry points take any number of groups; they launch once per 128 pointers
+ * (the pointers travel by value in the kernel-argument segment). */
 
 typedef struct {
   int64_t G, B, H, T, D;
@@ -158,7 +157,8 @@ int kvq_gather_tokens(const void* in_base, const void* const* in_ptrs, const kvq
 
 /* ---- tuning knobs (benchmarks only; defaults are what ships) ----------------------------- */
 
-/* key: "dequant_variant" (0..), "dequant_grid" (blocks, 0 = auto), "quant_force_two_pass" (0/1).
+/* key: "dequant_variant" (0..15, -1 = shipped default), "dequant_grid" (workgroups, 0 = one chunk
+ * each), "quant_force_two_pass" (0/1), "quant_direct_stores" (0/1).
  * Returns 0, or KVQ_E_DIMS for an unknown key. Process-global. */
 int kvq_set_tunable(const char* key, int64_t value);
 int64_t kvq_get_tunable(const char* key);
