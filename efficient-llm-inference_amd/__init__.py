@@ -8,6 +8,7 @@ and signatures; the arithmetic runs in hand-written HIP kernels for gfx950 behin
 """
 __version__ = "0.1.0"
 
+from . import _lib  # noqa: F401
 from .core.config import BenchmarkConfig, CacheConfig, Config, QuantizationConfig  # noqa: F401
 from .cache import chunk_summarize_kv, trim_kv_sliding_window  # noqa: F401
 from .quantization import (  # noqa: F401

@@ -343,3 +343,41 @@ def test_quant_batch_strided_input(E, kind):
         ws = torch.empty(G * T, dtype=torch.float32, device="cuda")
         kernels.quant_tokens(x, store, scales, ws, kind)
         assert np.array_equal(to_numpy(store), q_ref) and np.array_equal(bits(scales), bits(s32_ref))
+
+
+def test_more_than_128_groups_chunked_launches(E):
+    """Pointer tables hold 128 groups per launch: 130 separately allocated tensors exercise the
+    second launch's base-pointer / scale-table / workspace offsets in every entry point."""
+    from efficient_llm_inference_amd import kernels
+    G, B, H, T, D = 130, 1, 2, 6, 64
+    x_np = seeded_kv((G, B, H, T, D), "f16", 51, "heavy")
+    xs = [to_torch(x_np[g]) for g in range(G)]  # separately allocated
+    for kind in ("int8", "int4"):
+        q_ref, _, s32_ref = O.quantize_tokens(x_np, kind)
+        Dq = kernels.packed_dim(kind, D)
+        for two_pass in (0, 1):
+            store = torch.zeros(G, B, H, T, Dq, dtype=kernels.QDTYPE[kind], device="cuda")
+            scales = torch.zeros(G, T, dtype=torch.float32, device="cuda")
+            ws = torch.empty(G * T, dtype=torch.float32, device="cuda")
+            E._lib.set_tunable("quant_force_two_pass", two_pass)
+            try:
+                kernels.quant_tokens(xs, store, scales, ws, kind)
+            finally:
+                E._lib.set_tunable("quant_force_two_pass", 0)
+            assert np.array_equal(to_numpy(store), q_ref) and np.array_equal(bits(scales), bits(s32_ref)), (kind, two_pass)
+        out = torch.empty(G, B, H, T, D, dtype=torch.float16, device="cuda")
+        kernels.dequant_tokens(store, scales, out, kind)
+        assert np.array_equal(bits(out), bits(O.dequantize_tokens(q_ref, s32_ref, kind, D, "f16")))
+    past = tuple((xs[2 * l], xs[2 * l + 1]) for l in range(G // 2))
+    res = E.chunk_summarize_kv(past, 2, 1)
+    orc = O.chunk_summarize_kv(x_np, 2, 1)
+    win = E.trim_kv_sliding_window(past, 4)
+    from efficient_llm_inference_amd.cache import trim_kv_strided
+    st = trim_kv_strided(past, 2, 2, 1)
+    idx = O.keep_indices_strided(T, 2, 2, 1)
+    for l in range(G // 2):
+        for j in (0, 1):
+            g = 2 * l + j
+            assert np.array_equal(bits(res[l][j]), bits(orc[g]))
+            assert np.array_equal(bits(win[l][j]), bits(x_np[g][..., T - 4:, :]))
+            assert np.array_equal(bits(st[l][j]), bits(O.gather_tokens(x_np[g], idx)))
