@@ -27,7 +27,7 @@ int check_launch(const char* what) {
 }
 
 Tunables& tunables() {
-  static Tunables t = {-1, 0, 0, 0};
+  static Tunables t = {-1, 0, 0, 0, 0};
   return t;
 }
 
@@ -46,6 +46,7 @@ int kvq_set_tunable(const char* key, int64_t value) {
   else if (!strcmp(key, "dequant_grid")) t.dequant_grid = value;
   else if (!strcmp(key, "quant_force_two_pass")) t.quant_force_two_pass = value;
   else if (!strcmp(key, "quant_direct_stores")) t.quant_direct_stores = value;
+  else if (!strcmp(key, "pool_grid")) t.pool_grid = value;
   else {
     kvq::set_error("kvq_set_tunable: unknown key '%s'", key);
     return KVQ_E_DIMS;
@@ -60,6 +61,7 @@ int64_t kvq_get_tunable(const char* key) {
   if (!strcmp(key, "dequant_grid")) return t.dequant_grid;
   if (!strcmp(key, "quant_force_two_pass")) return t.quant_force_two_pass;
   if (!strcmp(key, "quant_direct_stores")) return t.quant_direct_stores;
+  if (!strcmp(key, "pool_grid")) return t.pool_grid;
   return 0;
 }
 

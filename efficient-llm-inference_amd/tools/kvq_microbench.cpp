@@ -66,6 +66,25 @@ __global__ __launch_bounds__(256) void read16_k(const u32x4* __restrict__ in, ui
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc ^= in[i];
   if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
 }
+// read pattern of the chunk mean-pool kernel without its arithmetic: each 16-lane group streams
+// 64 rows of 256 B (one chunk = 16 KiB), a wave covers 4 chunks -> every wave load touches four
+// 256-byte segments 16 KiB apart. batch = loads in flight per lane.
+template <int BATCH>
+__global__ __launch_bounds__(256) void read_seg_k(const u32x4* __restrict__ in, uint32_t* sink, int64_t n_chunks) {
+  const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t chunk = item >> 4;
+  if (chunk >= n_chunks) return;
+  const u32x4* p = in + chunk * 1024 + (item & 15);  // 16 KiB per chunk = 1024 vectors; row = 16 vectors
+  u32x4 acc = {0, 0, 0, 0};
+  for (int i = 0; i < 64; i += BATCH) {
+    u32x4 x[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) x[u] = p[(i + u) * 16];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) acc ^= x[u];
+  }
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
+}
 __global__ void rand_fill_k(uint32_t* p, int64_t n_words, uint32_t seed) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * 256) {
     uint32_t x = (uint32_t)i * 2654435761u + seed;
@@ -184,6 +203,16 @@ int main(int argc, char** argv) {
         double ms = tm.ms_per([&] { rotate(); expand4_k<<<grid, 256>>>((const uint32_t*)q4, (u32x4*)out, n16, nt); }, iters);
         printf("calib expand4 nt=%d grid=%6d  %8.3f ms  %8.1f GB/s (0.25r+1w: the INT4 dequant mix)\n", nt, grid, ms, 2.5 * N / ms / 1e6);
       }
+    {
+      const int64_t n_chunks = N * 2 / 16384;
+      const int grid = (int)((n_chunks * 16 + 255) / 256);
+      double ms = tm.ms_per([&] { rotate(); read_seg_k<8><<<grid, 256>>>((const u32x4*)in16, (uint32_t*)ws, n_chunks); }, iters);
+      printf("calib readseg  batch=8   %8.3f ms  %8.1f GB/s (r, 4 x 256 B segments per wave load)\n", ms, 1.0 * N * 2 / ms / 1e6);
+      ms = tm.ms_per([&] { rotate(); read_seg_k<16><<<grid, 256>>>((const u32x4*)in16, (uint32_t*)ws, n_chunks); }, iters);
+      printf("calib readseg  batch=16  %8.3f ms  %8.1f GB/s (r, 4 x 256 B segments per wave load)\n", ms, 1.0 * N * 2 / ms / 1e6);
+      ms = tm.ms_per([&] { rotate(); read_seg_k<32><<<grid, 256>>>((const u32x4*)in16, (uint32_t*)ws, n_chunks); }, iters);
+      printf("calib readseg  batch=32  %8.3f ms  %8.1f GB/s (r, 4 x 256 B segments per wave load)\n", ms, 1.0 * N * 2 / ms / 1e6);
+    }
     for (int grid : {2048, 4096, 16384}) {
       double ms = tm.ms_per([&] { rotate(); read16_k<<<grid, 256>>>((const u32x4*)in16, (uint32_t*)ws, n16); }, iters);
       printf("calib read16   grid=%6d  %8.3f ms  %8.1f GB/s (r)\n", grid, ms, 1.0 * N * 2 / ms / 1e6);
@@ -266,9 +295,13 @@ int main(int argc, char** argv) {
     const int64_t Tout = kvq_chunk_summary_len(T, 64, 256);
     kvq_strides_t s_out = {B * H * Tout * D, H * Tout * D, Tout * D, D};
     const double bytes = 2.0 * G * B * H * D * (T + Tout);
-    double ms = tm.ms_per([&] { rotate(); KVQ_OK(kvq_chunk_meanpool(in16, nullptr, &s_full, out, &s_out, KVQ_F16, 64, 256, &dims, 0)); }, iters);
-    printf("chunk_meanpool T=%lld->%lld  %8.3f ms  %8.1f GB/s  frac8T=%.3f\n", (long long)T, (long long)Tout, ms,
-           bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0);
+    for (int64_t pg : {(int64_t)1024, (int64_t)2048, (int64_t)4096, (int64_t)8192, (int64_t)1000000}) {
+      KVQ_OK(kvq_set_tunable("pool_grid", pg));
+      double ms = tm.ms_per([&] { rotate(); KVQ_OK(kvq_chunk_meanpool(in16, nullptr, &s_full, out, &s_out, KVQ_F16, 64, 256, &dims, 0)); }, iters);
+      printf("chunk_meanpool T=%lld->%lld grid=%7lld  %8.3f ms  %8.1f GB/s  frac8T=%.3f\n", (long long)T, (long long)Tout,
+             (long long)pg, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0);
+    }
+    KVQ_OK(kvq_set_tunable("pool_grid", 0));
   }
   if (what == "window" || what == "all") {
     for (int64_t W : {(int64_t)256, (int64_t)8192}) {
