@@ -38,7 +38,7 @@ struct Tunables {
   int64_t dequant_grid;          // 0 = one chunk per workgroup
   int64_t quant_force_two_pass;  // 1 = generic two-pass quantise for every shape (tests)
   int64_t quant_direct_stores;   // 1 = skip the LDS-staged 16 B stores (tests / A-B)
-  int64_t pool_grid;             // total workgroups of the chunk mean-pool kernel (0 = 4096)
+  int64_t pool_grid;             // total workgroups of the chunk mean-pool kernel (0 = auto)
 };
 Tunables& tunables();
 

@@ -385,10 +385,15 @@ int kvq_chunk_meanpool(const void* in_base, const void* const* in_ptrs, const kv
                (a.os.t * esz) % 16 == 0;
     for (int64_t i = 0; i < gn && vec; ++i) vec = aligned(a.in.p[i], 16);
     if (vec) {
+      // Launch shape (measured, profiles/r01c_microbench_quant_pool_window.txt): one item per
+      // thread unless the launch is large (> 16 waves of 2048 workgroups), where a persistent
+      // 2048-workgroup grid-stride launch is ~4 % faster (config-5 slice: 5.98 vs 6.22 ms).
       int64_t want = (items_vec + kBlock - 1) / kBlock;
-      const int64_t cap = tunables().pool_grid > 0 ? tunables().pool_grid : 4096;  // persistent grid, all groups
-      const int64_t per_g = (cap + gn - 1) / gn > 8 ? (cap + gn - 1) / gn : 8;
-      if (want > per_g) want = per_g;
+      const int64_t cap = tunables().pool_grid > 0 ? tunables().pool_grid : 2048;
+      if (tunables().pool_grid > 0 || want * gn > 16 * cap) {
+        const int64_t per_g = (cap + gn - 1) / gn > 8 ? (cap + gn - 1) / gn : 8;
+        if (want > per_g) want = per_g;
+      }
       const unsigned blocks = (unsigned)want;
       switch (dtype) {
         case KVQ_F16: hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_F16>), dim3(blocks, (unsigned)gn), dim3(kBlock), 0, st, a, (uint32_t)items_vec); break;
