@@ -40,6 +40,7 @@ struct QuantArgs {
   int32_t vshift;    // log2(TT * D/8)
   uint32_t nvec;     // R * TT * D/8 vectors per full tile
   uint32_t rpc;      // sweep kernel: rows per sweep step
+  uint32_t t_begin;  // first token of this launch's first tile
   int32_t bh_contig; // rows addressable as r * stride_h on both sides
 };
 
@@ -81,8 +82,8 @@ __device__ inline uint32_t group_umax(uint32_t v, int logw) {
 
 // rint(x / s32) + BIAS for 8 elements, returned in the low mantissa bits of
 // (1.5 * 2^23 + BIAS + q): bit-exact with IEEE division at a fraction of its cost.
-// Fast path: p = x * r with r = RN(1/s32). |p - x/s32| <= 2^-23 |p| (two roundings) and the
-// correctly rounded quotient RN(x/s32) is within 2^-24 |p| of x/s32, with |p| <= QMAX (1 + 2^-22)
+// Fast path: p = x * r with r = RN(1/s32). |p - x/s32| <= 2^-23 |p| (at most two roundings) and
+// the correctly rounded quotient RN(x/s32) is within 2^-24 |p| of x/s32, with |p| <= QMAX (1 + 2^-22)
 // because |x| <= amax and s32 >= RN(amax/QMAX). So if p is farther than
 // m = 1.5 * 2^-22 * QMAX (twice the error bound) from every half-integer, then p, x/s32 and
 // RN(x/s32) all round to the same integer. d = p - rint(p) is exact, and "within m of a
@@ -104,9 +105,10 @@ __device__ inline void quotient_bits8(const V& v, float s32, float r, uint32_t (
 #pragma unroll
   for (int k = 0; k < 4; ++k) {  // two elements per v_pk_*_f32
     const f32x2 x2 = {v.get(2 * k), v.get(2 * k + 1)};
-    const f32x2 p = x2 * r2;
-    const f32x2 sum = p + magic2;  // = kMagic + rint(p), exactly
-    const f32x2 d = p - (sum - magic2);
+    // sum = RN(x*r + magic) = magic + rint(x*r): the fma rounds the EXACT product, which is
+    // within 2^-24 |p| of x/s32 (only r is rounded), inside the same margin
+    const f32x2 sum = __builtin_elementwise_fma(x2, r2, magic2);
+    const f32x2 d = __builtin_elementwise_fma(x2, r2, magic2 - sum);  // x*r - rint(x*r), one rounding
     const f32x2 dd = d * d;
     worst = fmaxf(worst, fmaxf(dd[0], dd[1]));
     qb[2 * k] = __float_as_uint(sum[0]);
@@ -142,14 +144,16 @@ __device__ inline uint32_t pack_i4(const uint32_t (&qb)[8]) {
 
 // ROWU: the tile has >= 256 vectors per row, so in round i every lane of the block works on the
 // same row (row index and its offsets are scalar) and (t, d) offsets collapse to wv * 8.
-template <int IDT, int BITS, bool ROWU, bool LDS_OUT>
+// FULL: every tile of the launch is complete (kBlock * kNVMax vectors, TT tokens inside T), so no
+// lane is ever predicated off: no validity masks, no exec juggling.
+template <int IDT, int BITS, bool ROWU, bool LDS_OUT, bool FULL>
 __global__ __launch_bounds__(kBlock) void quant_tokens_fused_k(const QuantArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t s_out[LDS_OUT ? kTileElems * BITS / 32 : 4];
   __shared__ uint32_t s_amax[kMaxTT];
   __shared__ float s_scale[kMaxTT], s_rcp[kMaxTT];
   const uint32_t tid = threadIdx.x;
   const uint32_t g = blockIdx.y;
-  const uint32_t t0 = blockIdx.x * a.TT;
+  const uint32_t t0 = a.t_begin + blockIdx.x * a.TT;
   const uint32_t DV = a.D >> 3;
   const uint32_t wmask = (1u << a.vshift) - 1u;
   // is.t == D and qs.t == Dq (or a single token per tile), so within a row the tile is one
@@ -175,12 +179,12 @@ __global__ __launch_bounds__(kBlock) void quant_tokens_fused_k(const QuantArgs a
       r = v >> a.vshift;
       wv = v & wmask;
     }
-    valid[i] = ((uint32_t)(i * kBlock) + tid < a.nvec) && (t0 + (wv >> a.dvshift) < a.T);
+    valid[i] = FULL || (((uint32_t)(i * kBlock) + tid < a.nvec) && (t0 + (wv >> a.dvshift) < a.T));
     if (valid[i]) x[i].load(in + ((int64_t)r * a.is.h + (int64_t)wv * 8) * Elem<IDT>::size);
   }
 #pragma unroll
   for (int i = 0; i < kNVMax; ++i) {
-    if ((uint32_t)(i * kBlock) < a.nvec) {  // uniform: whole waves reach the lane exchanges
+    if (FULL || (uint32_t)(i * kBlock) < a.nvec) {  // uniform: whole waves reach the lane exchanges
       const uint32_t wv = ((uint32_t)(i * kBlock) + tid) & wmask;
       uint32_t m = valid[i] ? x[i].absmax_bits() : 0u;
       m = group_umax(m, a.dvshift);  // the D/8 lanes of one (row, token)
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void quant_tokens_fused_k(const QuantArgs a
   __syncthreads();
 
   // per-token scale, its reciprocal (both IEEE divides, once per token) and the stored scale
-  if (tid < a.TT && t0 + tid < a.T) {
+  if (tid < a.TT && (FULL || t0 + tid < a.T)) {
     const float amax = Vec8<IDT>::bits_to_f32(s_amax[tid]);
     const float s32 = fmaxf(amax / QRange<BITS>::qmax, a.eps);
     s_scale[tid] = s32;
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void quant_tokens_fused_k(const QuantArgs a
   // pass 2: scale, round, pack, store
 #pragma unroll
   for (int i = 0; i < kNVMax; ++i) {
-    if (!valid[i]) continue;
+    if (!FULL && !valid[i]) continue;
     uint32_t r, wv;
     if constexpr (ROWU) {
       r = (uint32_t)(i * kBlock) >> a.vshift;
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void quant_tokens_fused_k(const QuantArgs a
     __syncthreads();
     const uint32_t row_shift = a.vshift + (BITS == 8 ? 3 : 2);  // log2(bytes per full row run)
     const uint32_t row_bytes = 1u << row_shift;
-    uint32_t nt = a.T - t0;
+    uint32_t nt = FULL ? a.TT : a.T - t0;
     if (nt > a.TT) nt = a.TT;
     const uint32_t valid_bytes = nt * (a.D * BITS / 8);  // ragged last tile: shorter runs
     const uint32_t total = a.R << row_shift;
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void quant_tokens_sweep_k(const QuantArgs a
   __shared__ float s_scale[kMaxTT], s_rcp[kMaxTT];
   const uint32_t tid = threadIdx.x;
   const uint32_t g = blockIdx.y;
-  const uint32_t t0 = blockIdx.x * a.TT;
+  const uint32_t t0 = a.t_begin + blockIdx.x * a.TT;
   const uint32_t DV = a.D >> 3;
   const uint32_t wmask = (1u << a.vshift) - 1u;
   const char* in = reinterpret_cast<const char*>(a.in.p[g]) + (int64_t)t0 * a.is.t * Elem<IDT>::size;
@@ -407,14 +411,27 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
     const int64_t dq = (int64_t)a.D * BITS / 8;
     const bool lds_out = !tunables().quant_direct_stores && dq % 16 == 0 && a.qs.g % 16 == 0 && a.qs.h % 16 == 0 &&
                          a.qs.t % 16 == 0 && aligned(a.q, 16);
-    if (a.vshift >= 8 && lds_out)
-      hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
-    else if (a.vshift >= 8)
-      hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, false>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
-    else if (lds_out)
-      hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, false, true>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
-    else
-      hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, false, false>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
+    const bool rowu = a.vshift >= 8;
+    // complete tiles go to the predicate-free FULL kernel, a ragged last tile to the general one
+    const unsigned n_full = (a.nvec == (uint32_t)(kBlock * kNVMax) && rowu && lds_out) ? a.T / a.TT : 0u;
+    if (n_full) {
+      QuantArgs f = a;
+      f.t_begin = 0;
+      hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true>), dim3(n_full, a.G), dim3(kBlock), 0, st, f);
+    }
+    const unsigned rest = tiles - n_full;
+    if (rest) {
+      QuantArgs t = a;
+      t.t_begin = n_full * a.TT;
+      if (rowu && lds_out)
+        hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, false>), dim3(rest, a.G), dim3(kBlock), 0, st, t);
+      else if (rowu)
+        hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, false, false>), dim3(rest, a.G), dim3(kBlock), 0, st, t);
+      else if (lds_out)
+        hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, false, true, false>), dim3(rest, a.G), dim3(kBlock), 0, st, t);
+      else
+        hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, false, false, false>), dim3(rest, a.G), dim3(kBlock), 0, st, t);
+    }
   } else {
     const int64_t RD = (int64_t)a.R * a.D;
     const int64_t chunk_elems = (int64_t)kBlock * 16;
@@ -482,6 +499,7 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
                (a.is.h * esz) % 16 == 0 && (a.is.t * esz) % 16 == 0 && a.qs.h % qvec == 0 &&
                a.qs.t % qvec == 0 && a.qs.g % qvec == 0 && aligned(q, qvec);
   a.rpc = 0;
+  a.t_begin = 0;
   a.bh_contig = bh_contig ? 1 : 0;
   if (fused && big) {
     // tile = R x TT tokens, kept around 256 KiB so the second sweep is served from cache
