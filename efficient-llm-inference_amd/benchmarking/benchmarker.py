@@ -36,7 +36,7 @@ from ..cache import (
     trim_kv_sliding_window,
     trim_kv_strided,
 )
-from ..core.utils import get_cpu_mem_mb, get_gpu_peak_mb, mb, reset_gpu_peak
+from ..core.memory import get_cpu_mem_mb, get_gpu_peak_mb, mb, reset_gpu_peak
 from ..quantization import QuantizedKVCache
 
 try:  # transformers is only needed to rebuild a Cache object for the model

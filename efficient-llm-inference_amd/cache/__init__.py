@@ -1,20 +1,14 @@
-"""Eviction surface (reference src/cache/__init__.py:13-21)."""
-from .implementations import (
-    PagedKVCache,
-    chunk_summarize_kv,
-    trim_kv_block_old,
-    trim_kv_budget_old,
-    trim_kv_prefix_window,
-    trim_kv_sliding_window,
-    trim_kv_strided,
-)
+"""Eviction surface: the seven names the reference exports from ``src.cache``
+(reference src/cache/__init__.py:13-21), implemented over the HIP kernels in ``implementations``."""
+from . import implementations as _impl
 
 __all__ = [
-    "PagedKVCache",
-    "trim_kv_sliding_window",
-    "chunk_summarize_kv",
-    "trim_kv_prefix_window",
-    "trim_kv_strided",
-    "trim_kv_block_old",
-    "trim_kv_budget_old",
+    "trim_kv_sliding_window",   # implementations.py:124-140 in the reference
+    "chunk_summarize_kv",       # :295-346
+    "trim_kv_prefix_window",    # :143-154
+    "trim_kv_strided",          # :157-190
+    "trim_kv_block_old",        # :193-245
+    "trim_kv_budget_old",       # :248-292
+    "PagedKVCache",             # :10-121
 ]
+globals().update({_n: getattr(_impl, _n) for _n in __all__})
