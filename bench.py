@@ -241,6 +241,25 @@ def main():
     qc.init_from_prompt_past(tuple(past))
     torch.cuda.synchronize()
     est_mb = qc.estimated_bytes() / 2**20
+
+    # side measurement, outside the timed region: the prefill quantise kernels (rows a1/a2) on the
+    # same tensors, re-quantising into the same store (identical bytes every time)
+    from efficient_llm_inference_amd import kernels as _k
+    quant_info = {}
+    for name, store, tensors in (("k", qc._k, [k for k, _ in past]), ("v", qc._v, [v for _, v in past])):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ws = store._workspace(L * T)
+        for it in range(6):
+            if it == 1:
+                ev[0].record()
+            _k.quant_tokens(tensors, store.q[:, :, :, :T], store.scales[:, :T], ws, store.kind)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms = ev[0].elapsed_time(ev[1]) / 5
+        qbytes = L * B * H * T * D * BYTES_PER_ELT[store.kind]  # 2 B read + 1 or 0.5 B written per element
+        quant_info[f"quant_{store.kind}"] = {"avg_launch_ms": round(ms, 4), "achieved": round(qbytes / (ms * 1e-3) / 1e9, 1),
+                                             "frac": round(qbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                             "algorithmic_bytes_per_launch": int(qbytes), "set": name.upper()}
     del past
     torch.cuda.empty_cache()
 
@@ -327,6 +346,7 @@ def main():
                 "frac": round(bytes_k / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                 "algorithmic_bytes_per_launch": int(bytes_k), "avg_launch_ms": round(k_ms, 4),
             },
+            "roofline_quantise": quant_info,
             "est_kv_cache_mb": round(est_mb, 3),
             "fp16_kv_cache_mb": round(2 * n_elts * 2 / 2**20, 3),
         }

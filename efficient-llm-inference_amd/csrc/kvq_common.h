@@ -39,6 +39,7 @@ struct Tunables {
   int64_t quant_force_two_pass;  // 1 = generic two-pass quantise for every shape (tests)
   int64_t quant_direct_stores;   // 1 = skip the LDS-staged 16 B stores (tests / A-B)
   int64_t pool_grid;             // total workgroups of the chunk mean-pool kernel (0 = auto)
+  int64_t nt_loads;              // non-temporal input loads in the quantise / pool kernels (default 1: +2-3 % on quantise)
 };
 Tunables& tunables();
 
@@ -142,6 +143,8 @@ template <int IDT>
 struct Vec8 {
   u32x4 w;
   __device__ inline void load(const void* p) { w = *reinterpret_cast<const u32x4*>(p); }
+  // read-once stream: non-temporal (keeps the line out of the way of the stores' write-back)
+  __device__ inline void load_nt(const void* p) { w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
   // max |x| as an order-preserving bit pattern: sign-masked halves compared as unsigned ints
   __device__ inline uint32_t absmax_bits() const {
     typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
@@ -164,6 +167,7 @@ template <>
 struct Vec8<KVQ_F32> {
   float x[8];
   __device__ inline void load(const void* p) { load8<KVQ_F32>(p, x); }
+  __device__ inline void load_nt(const void* p) { load8<KVQ_F32>(p, x); }
   __device__ inline uint32_t absmax_bits() const {
     float m = 0.0f;
 #pragma unroll

@@ -30,12 +30,12 @@ struct DequantArgs {
   uint32_t total_items;
 };
 
-template <int NW>
+template <int NW, bool NTL = false>
 __device__ inline void load_words(const uint8_t* p, uint32_t (&w)[NW]) {
   if constexpr (NW == 1) {
-    w[0] = *reinterpret_cast<const uint32_t*>(p);
+    w[0] = NTL ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p)) : *reinterpret_cast<const uint32_t*>(p);
   } else if constexpr (NW == 2) {
-    const u32x2 v = *reinterpret_cast<const u32x2*>(p);
+    const u32x2 v = NTL ? __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p)) : *reinterpret_cast<const u32x2*>(p);
     w[0] = v[0];
     w[1] = v[1];
   } else {
@@ -76,7 +76,7 @@ __device__ inline void expand8(const uint32_t* wq, float s, float (&x)[8]) {
 // sides (q.t == Dq, out.t == D), D % 8 == 0. Lane l of step u owns LE consecutive elements:
 // LE = 8 makes every store instruction of a wave one contiguous 1 KiB run.
 // Per-token scales of the chunk are staged through LDS once (CHUNK/D tokens), then broadcast.
-template <int ODT, int BITS, int LE, int UNROLL, bool NT, bool LDS_SC>
+template <int ODT, int BITS, int LE, int UNROLL, bool NT, bool LDS_SC, bool NTL = false>
 __global__ __launch_bounds__(kBlock) void dequant_tokens_fast_k(const DequantArgs a) {
   constexpr int CHUNK = kBlock * LE * UNROLL;
   constexpr int NW = LE * BITS / 32;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void dequant_tokens_fast_k(const DequantArg
     for (int u = 0; u < UNROLL; ++u) {
       const uint32_t e = e0 + (u * kBlock + tid) * LE;
       if (e < a.row_len) {
-        load_words<NW>(qrow + ((int64_t)e * BITS) / 8, w[u]);
+        load_words<NW, NTL>(qrow + ((int64_t)e * BITS) / 8, w[u]);
       } else {
 #pragma unroll
         for (int i = 0; i < NW; ++i) w[u][i] = 0;
@@ -234,16 +234,18 @@ static const Variant kVariants[] = {
     {8, 1, true, true},    // 13
     {8, 4, true, false},   // 14
     {8, 1, false, true},   // 15
+    {8, 4, true, true},    // 16: as 1 + non-temporal loads
+    {8, 2, true, true},    // 17: as 12 + non-temporal loads
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 // shipped defaults (profiles/r01_microbench.txt): contiguous 1 KiB stores per wave instruction;
 // non-temporal stores for the 80 %-write INT4 stream.
 constexpr int kDefaultVariantI4 = 1;
-constexpr int kDefaultVariantI8 = 12;
+constexpr int kDefaultVariantI8 = 17;
 
-template <int ODT, int BITS, int LE, int UNROLL, bool NT, bool LDS_SC>
+template <int ODT, int BITS, int LE, int UNROLL, bool NT, bool LDS_SC, bool NTL = false>
 static void launch_fast(const DequantArgs& a, unsigned grid, hipStream_t st) {
-  hipLaunchKernelGGL((dequant_tokens_fast_k<ODT, BITS, LE, UNROLL, NT, LDS_SC>), dim3(grid), dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL((dequant_tokens_fast_k<ODT, BITS, LE, UNROLL, NT, LDS_SC, NTL>), dim3(grid), dim3(kBlock), 0, st, a);
 }
 
 template <int ODT, int BITS>
@@ -265,6 +267,8 @@ static bool launch_fast_variant(int v, const DequantArgs& a, unsigned grid, hipS
     case 13: launch_fast<ODT, BITS, 8, 1, true, true>(a, grid, st); return true;
     case 14: launch_fast<ODT, BITS, 8, 4, true, false>(a, grid, st); return true;
     case 15: launch_fast<ODT, BITS, 8, 1, false, true>(a, grid, st); return true;
+    case 16: launch_fast<ODT, BITS, 8, 4, true, true, true>(a, grid, st); return true;
+    case 17: launch_fast<ODT, BITS, 8, 2, true, true, true>(a, grid, st); return true;
   }
   return false;
 }

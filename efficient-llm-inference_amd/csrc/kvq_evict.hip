@@ -106,6 +106,7 @@ struct PoolArgs {
   uint32_t T, Tout;
   uint32_t old_len, n_chunks, chunk;
   float chunk_f;  // (float)chunk_size: the divisor, also for the ragged last chunk
+  int32_t nt_loads;
 };
 
 // independent 16-byte loads in flight per lane (raw packed registers: 4 VGPRs each for fp16/bf16)
@@ -151,8 +152,13 @@ __global__ __launch_bounds__(kBlock) void chunk_pool_vec_k(const PoolArgs a, uin
     uint32_t i = 0;
     for (; i + NB <= n; i += NB) {
       Vec8<DT> x[NB];
+      if (a.nt_loads) {
 #pragma unroll
-      for (int u = 0; u < NB; ++u) x[u].load(p + (int64_t)(i + u) * tstride);
+        for (int u = 0; u < NB; ++u) x[u].load_nt(p + (int64_t)(i + u) * tstride);
+      } else {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) x[u].load(p + (int64_t)(i + u) * tstride);
+      }
 #pragma unroll
       for (int u = 0; u < NB; ++u)
 #pragma unroll
@@ -371,6 +377,7 @@ int kvq_chunk_meanpool(const void* in_base, const void* const* in_ptrs, const kv
   a.n_chunks = (uint32_t)n_chunks;
   a.chunk = (uint32_t)chunk_size;
   a.chunk_f = (float)chunk_size;
+  a.nt_loads = (int32_t)tunables().nt_loads;
 
   const int64_t items_vec = d->B * d->H * Tout * (d->D / 8);
   const int64_t items_gen = d->B * d->H * Tout * d->D;

@@ -41,6 +41,7 @@ struct QuantArgs {
   uint32_t nvec;     // R * TT * D/8 vectors per full tile
   uint32_t rpc;      // sweep kernel: rows per sweep step
   uint32_t t_begin;  // first token of this launch's first tile
+  int32_t nt_loads;  // non-temporal input loads
   int32_t bh_contig; // rows addressable as r * stride_h on both sides
 };
 
@@ -180,7 +181,11 @@ __global__ __launch_bounds__(kBlock) void quant_tokens_fused_k(const QuantArgs a
       wv = v & wmask;
     }
     valid[i] = FULL || (((uint32_t)(i * kBlock) + tid < a.nvec) && (t0 + (wv >> a.dvshift) < a.T));
-    if (valid[i]) x[i].load(in + ((int64_t)r * a.is.h + (int64_t)wv * 8) * Elem<IDT>::size);
+    if (valid[i]) {
+      const char* src = in + ((int64_t)r * a.is.h + (int64_t)wv * 8) * Elem<IDT>::size;
+      if (a.nt_loads) x[i].load_nt(src);
+      else x[i].load(src);
+    }
   }
 #pragma unroll
   for (int i = 0; i < kNVMax; ++i) {
@@ -500,6 +505,7 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
                a.qs.t % qvec == 0 && a.qs.g % qvec == 0 && aligned(q, qvec);
   a.rpc = 0;
   a.t_begin = 0;
+  a.nt_loads = (int32_t)tunables().nt_loads;
   a.bh_contig = bh_contig ? 1 : 0;
   if (fused && big) {
     // tile = R x TT tokens, kept around 256 KiB so the second sweep is served from cache

@@ -247,7 +247,7 @@ int main(int argc, char** argv) {
   if (what == "mixed" || what == "all") {
     hipEvent_t e0, e1, e2;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1)); HIP_OK(hipEventCreate(&e2));
-    for (int v8 : {0, 1, 8, 12}) for (int v4 : {0, 1, 12}) {
+    for (int v8 : {12, 17}) for (int v4 : {1, 16}) {
       double t8 = 0, t4 = 0;
       for (int it = 0; it < iters + 3; ++it) {
         rotate();
@@ -271,7 +271,7 @@ int main(int argc, char** argv) {
 
   auto run_quant = [&](int bits) {
     const double bytes = bits == 4 ? N * 2.5 : N * 3.0;
-    for (int two_pass = 0; two_pass < 2; ++two_pass) {
+    for (int two_pass = 0; two_pass < (what == "ntload" ? 1 : 2); ++two_pass) {
       KVQ_OK(kvq_set_tunable("quant_force_two_pass", two_pass));
       double ms = tm.ms_per(
           [&] {
@@ -287,6 +287,19 @@ int main(int argc, char** argv) {
     }
     KVQ_OK(kvq_set_tunable("quant_force_two_pass", 0));
   };
+  if (what == "ntload") {
+    for (int nt = 0; nt < 2; ++nt) {
+      KVQ_OK(kvq_set_tunable("nt_loads", nt));
+      printf("nt_loads=%d\n", nt);
+      run_quant(4);
+      run_quant(8);
+      const int64_t Tout = kvq_chunk_summary_len(T, 64, 256);
+      kvq_strides_t s_out = {B * H * Tout * D, H * Tout * D, Tout * D, D};
+      double ms = tm.ms_per([&] { rotate(); KVQ_OK(kvq_chunk_meanpool(in16, nullptr, &s_full, out, &s_out, KVQ_F16, 64, 256, &dims, 0)); }, iters);
+      printf("chunk_meanpool nt=%d  %8.3f ms  %8.1f GB/s\n", nt, ms, 2.0 * G * B * H * D * (T + Tout) / ms / 1e6);
+    }
+    KVQ_OK(kvq_set_tunable("nt_loads", 0));
+  }
   if (what == "quant4" || what == "all") run_quant(4);
   if (what == "quant8" || what == "all") run_quant(8);
 
