@@ -131,6 +131,7 @@ def run_evict(args, rank, world, dev):
     """configs[4] per-rank slice: one STEP = trim_kv_sliding_window + chunk_summarize_kv over the
     whole legacy tuple (64 tensors of [8,8,32768,128] fp16): two launches, inputs resident."""
     import efficient_llm_inference_amd as E
+    from efficient_llm_inference_amd import sharding
     L, B, H, T, D, W, chunk, keep = EVICT[args.workload]
     torch.manual_seed(42 + rank)
     past = tuple((torch.randn(B, H, T, D, device=dev, dtype=torch.float16),
@@ -156,23 +157,18 @@ def run_evict(args, rank, world, dev):
         step()
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    sharding.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(events[i])
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    sharding.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     w_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
     p_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = sharding.max_over_ranks(elapsed, dev)  # the step takes as long as the slowest rank
     if rank == 0:
         print(json.dumps({
             "metric": "KV eviction GB/s vs HBM roofline (sliding_window + chunk_summary step)",
@@ -210,7 +206,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import efficient_llm_inference_amd as E
-    from efficient_llm_inference_amd import _lib
+    from efficient_llm_inference_amd import _lib, sharding
 
     _lib.load()
     if args.workload.startswith("decode"):
@@ -287,24 +283,19 @@ def main():
         step(i)
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    sharding.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, events[i])
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    sharding.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
     k_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
     v_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = sharding.max_over_ranks(elapsed, dev)  # the step takes as long as the slowest rank
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

@@ -38,6 +38,32 @@ def shard_batch_rows(n_rows: int, rank: int = None, world_size: int = None) -> r
     return range(start, start + base + (1 if rank < extra else 0))
 
 
+def _reduce_device(device=None):
+    if device is not None:
+        return device
+    if dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def barrier() -> None:
+    """Rendezvous of all ranks (no-op in a single process). bench.py brackets its timed region
+    with barrier() + torch.cuda.synchronize() on both sides."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    """MAX of a host scalar over all ranks: the wall time of a step is the slowest rank's. One
+    8-byte ``all_reduce(MAX)`` over xGMI (RCCL) / TCP (gloo); identical result on every rank."""
+    _, ws = world()
+    if ws == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_reduce_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def aggregate_results(local: Dict[str, float], device=None) -> Dict[str, float]:
     """Combine per-rank ``benchmark_method`` dicts: token counts and cache MB are summed, elapsed
     time is the max over ranks (ranks run concurrently), tokens/sec = total tokens / max elapsed.
@@ -47,8 +73,7 @@ def aggregate_results(local: Dict[str, float], device=None) -> Dict[str, float]:
     if ws == 1:
         out["n_ranks"] = 1
         return out
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    device = _reduce_device(device)
     est = local.get("est_kv_cache_mb_avg", float("nan"))
     has_est = 0.0 if est != est else 1.0
     sums = torch.tensor([float(local.get("total_new_tokens", 0)), (est if has_est else 0.0), has_est,

@@ -106,7 +106,11 @@ def _worker(rank, world_size, port, q):
         b = KVCacheBenchmarker(model, tok, device="cpu")
         prompts = ["<8>", "<9>", "<10>", "<11>", "<12>"]
         res = sharding.benchmark_sharded(b, prompts, "full_cache", max_new_tokens=4)
-        q.put((rank, res["total_new_tokens"], res["n_prompts"], res["n_ranks"], res["elapsed_sec"], res["tokens_per_sec"]))
+        sharding.barrier()
+        slowest = sharding.max_over_ranks(1.0 + rank)  # bench.py's timing reduction
+        rows = list(sharding.shard_batch_rows(5))
+        q.put((rank, res["total_new_tokens"], res["n_prompts"], res["n_ranks"], res["elapsed_sec"], res["tokens_per_sec"],
+               slowest, rows))
     finally:
         dist.destroy_process_group()
 
@@ -123,9 +127,11 @@ def test_sharded_benchmark_world_size_2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, total, n_prompts, n_ranks, elapsed, tps in out:
+    for rank, total, n_prompts, n_ranks, elapsed, tps, slowest, rows in out:
         assert total == 20 and n_prompts == 5 and n_ranks == 2  # 5 prompts x 4 tokens, both ranks agree
         assert abs(tps - total / elapsed) < 1e-9
+        assert slowest == 2.0  # MAX over ranks of (1 + rank)
+        assert rows == ([0, 1, 2] if rank == 0 else [3, 4])
     assert out[0][4] == out[1][4]  # max-over-ranks elapsed identical on every rank
 
 
