@@ -202,8 +202,23 @@ def main():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL over xGMI for the one scalar reduction of a run; the data path itself needs no
+        # collective. If RCCL cannot come up (IPC / driver trouble) the same reduction runs over
+        # gloo so that the per-rank measurements are still reported.
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            backend = "nccl"
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)  # surfaces RCCL initialisation errors here, not inside the timed region
+            torch.cuda.synchronize()
+        except Exception as exc:  # noqa: BLE001
+            print(f"[bench] rank {rank}: RCCL unavailable ({exc!r}); using gloo for the timing reduction", file=sys.stderr)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            backend = "gloo"
 
     import efficient_llm_inference_amd as E
     from efficient_llm_inference_amd import _lib, sharding
@@ -323,7 +338,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "shape_LBHTD": [L, B, H, T, D], "mode": mode,
                        "step": "QuantizedKVCache.to_past_key_values(): 2 launches (K set, V set)",
-                       "bytes_per_step": int(step_bytes), "parallelism": f"batch-shard x{world}, no collective"},
+                       "bytes_per_step": int(step_bytes), "parallelism": f"batch-shard x{world}, no collective",
+                       "timing_reduction_backend": backend},
             "roofline": {
                 "kernel": f"dequant_tokens_fast_k<{vk}>", "what": target_name, "bound": "hbm",
                 "achieved": round(target_bytes / (target_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,

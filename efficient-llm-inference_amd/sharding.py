@@ -39,11 +39,10 @@ def shard_batch_rows(n_rows: int, rank: int = None, world_size: int = None) -> r
 
 
 def _reduce_device(device=None):
-    if device is not None:
-        return device
-    if dist.get_backend() == "nccl":
-        return torch.device("cuda", torch.cuda.current_device())
-    return torch.device("cpu")
+    """where the scalars of a reduction live: the GPU under RCCL, host memory under gloo"""
+    if dist.get_backend() != "nccl":
+        return torch.device("cpu")
+    return device if device is not None else torch.device("cuda", torch.cuda.current_device())
 
 
 def barrier() -> None:
