@@ -178,7 +178,7 @@ def run_evict(args, rank, world, dev):
             "metric": "KV eviction GB/s vs HBM roofline (sliding_window + chunk_summary step)",
             "value": round(step_bytes * world / (elapsed / args.steps) / 1e9, 1), "unit": "GB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 (fp32 accumulate)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "dtype_detail": "fp16 in/out, fp32 accumulate",
             "data": "synthetic",
             "config": {"workload": args.workload, "shape_per_rank_L2BHTD": [L, 2, B, H, T, D], "window": W,
                        "chunk_size": chunk, "keep_last": keep, "global_batch": B * world,
@@ -345,7 +345,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8->f16 (fp32 multiply)",
+            "dtype": "f32",  # arithmetic: (float)q * scale in fp32, rounded once to the fp16 output
+            "dtype_detail": "int8 / packed-int4 in, fp32 multiply, fp16 out",
             "data": "synthetic",
             "config": {"workload": args.workload, "shape_LBHTD": [L, B, H, T, D], "mode": mode,
                        "step": "QuantizedKVCache.to_past_key_values(): 2 launches (K set, V set)",
