@@ -46,6 +46,15 @@ def _prep(t: torch.Tensor) -> torch.Tensor:
     return t if (t.size(-1) == 1 or t.stride(-1) == 1) else t.contiguous()
 
 
+def _pairs(past_key_values, flat: List[torch.Tensor], out: List[torch.Tensor]) -> tuple:
+    """Re-assemble ``tuple_L[(k, v)]``; a tensor the policy left untouched is returned as the
+    caller's own object (the reference returns its inputs unchanged in that case)."""
+    orig = _flatten(past_key_values)
+    return tuple((orig[2 * l] if out[2 * l] is flat[2 * l] else out[2 * l],
+                  orig[2 * l + 1] if out[2 * l + 1] is flat[2 * l + 1] else out[2 * l + 1])
+                 for l in range(len(out) // 2))
+
+
 def trim_kv_sliding_window(past_key_values: tuple, window_size: int) -> tuple:
     """Keep only the last ``window_size`` tokens of every K and V (reference
     implementations.py:124-140)."""
@@ -62,14 +71,7 @@ def trim_kv_sliding_window(past_key_values: tuple, window_size: int) -> tuple:
             kernels.window_compact([flat[i] for i in part], buf, W)
             for j, i in enumerate(part):
                 out[i] = buf[j]
-    # pairs whose K and V were both untouched keep the caller's own objects
-    orig = _flatten(past_key_values)
-    res = []
-    for l in range(len(out) // 2):
-        k = orig[2 * l] if out[2 * l] is flat[2 * l] else out[2 * l]
-        v = orig[2 * l + 1] if out[2 * l + 1] is flat[2 * l + 1] else out[2 * l + 1]
-        res.append((k, v))
-    return tuple(res)
+    return _pairs(past_key_values, flat, out)
 
 
 def chunk_summarize_kv(past_key_values: tuple, chunk_size: int, keep_last: int) -> tuple:
@@ -90,13 +92,7 @@ def chunk_summarize_kv(past_key_values: tuple, chunk_size: int, keep_last: int) 
             kernels.chunk_meanpool([flat[i] for i in part], buf, int(chunk_size), int(keep_last))
             for j, i in enumerate(part):
                 out[i] = buf[j]
-    orig = _flatten(past_key_values)
-    res = []
-    for l in range(len(out) // 2):
-        k = orig[2 * l] if out[2 * l] is flat[2 * l] else out[2 * l]
-        v = orig[2 * l + 1] if out[2 * l + 1] is flat[2 * l + 1] else out[2 * l + 1]
-        res.append((k, v))
-    return tuple(res)
+    return _pairs(past_key_values, flat, out)
 
 
 # ----------------------------------------------------------------------------- index-select family
@@ -122,13 +118,7 @@ def _gather_policy(past_key_values: tuple, index_fn) -> tuple:
             kernels.gather_tokens([flat[i] for i in part], buf, idx_dev)
             for j, i in enumerate(part):
                 out[i] = buf[j]
-    orig = _flatten(past_key_values)
-    res = []
-    for l in range(len(out) // 2):
-        k = orig[2 * l] if out[2 * l] is flat[2 * l] else out[2 * l]
-        v = orig[2 * l + 1] if out[2 * l + 1] is flat[2 * l + 1] else out[2 * l + 1]
-        res.append((k, v))
-    return tuple(res)
+    return _pairs(past_key_values, flat, out)
 
 
 def trim_kv_prefix_window(past_key_values, prefix_len: int, window_size: int):
