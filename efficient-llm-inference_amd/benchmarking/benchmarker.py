@@ -37,7 +37,7 @@ from ..cache import (
     trim_kv_strided,
 )
 from ..core.memory import get_cpu_mem_mb, get_gpu_peak_mb, mb, reset_gpu_peak
-from ..quantization import QuantizedKVCache
+from ..quantization import QuantizedKVCache, hf_cache
 
 try:  # transformers is only needed to rebuild a Cache object for the model
     from transformers import DynamicCache
@@ -90,6 +90,10 @@ class KVCacheBenchmarker:
         self.model = model
         self.tokenizer = tokenizer
         self.device = device
+        # quantised decode: let the model append into the cache's staging buffers in place
+        # (quantization/hf_cache.py) instead of rebuilding a DynamicCache from a tuple every step.
+        # Same tokens either way; False restores the reference's loop shape literally.
+        self.inplace_decode = True
 
     # ------------------------------------------------------------------ shared loop machinery
 
@@ -186,9 +190,19 @@ class KVCacheBenchmarker:
         qcache.init_from_prompt_past(past_kv_tuple)  # 2 launches (reference: L*T Python iterations)
 
         generated = input_ids.clone()
+        staged = None
+        if self.inplace_decode and hf_cache.available():
+            staged = hf_cache.StagedQuantizedCache(qcache)
         for _ in range(max_new_tokens):
             next_token = torch.argmax(logits, dim=-1, keepdim=True)
             generated = torch.cat([generated, next_token], dim=-1)
+            if staged is not None:
+                # O(1) per step: dequantise the newest token into the staging buffers, the model
+                # appends its K/V there in place, then that slot is quantised into the store
+                out = self.model(input_ids=next_token, use_cache=True, past_key_values=staged.sync())
+                logits = out.logits[:, -1, :]
+                staged.commit()
+                continue
             past = from_legacy_tuple(qcache.to_past_key_values())  # 2 launches, no host sync
             out = self.model(input_ids=next_token, use_cache=True, past_key_values=past)
             logits = out.logits[:, -1, :]
