@@ -96,11 +96,11 @@ class StagedQuantizedCache:
             self.cache = DynamicCache()
             self.cache.layers = [_StagedLayer(self, i) for i in range(len(qc.layers))]
         else:
+            moved = self.cache.layers[0]._kbuf.data_ptr() != qc._k.stage[0].data_ptr()  # store grew
             for layer in self.cache.layers:
-                if layer._kbuf.data_ptr() != qc._k.stage[layer._index].data_ptr():
+                if moved:
                     layer._rebind()
-                layer._len = self._len
-                layer.keys, layer.values = layer._kbuf[:, :, :self._len], layer._vbuf[:, :, :self._len]
+                layer._len = self._len  # the views handed to attention are rebuilt by update()
         return self.cache
 
     def commit(self) -> None:
@@ -113,6 +113,5 @@ class StagedQuantizedCache:
         T = qc._k.lens[0]
         if new_len == T:
             return
-        L = len(qc.layers)
-        qc._k.append([qc._k.stage[i][:, :, T:new_len] for i in range(L)])
-        qc._v.append([qc._v.stage[i][:, :, T:new_len] for i in range(L)])
+        qc._k.append(qc._k.stage[:, :, :, T:new_len])  # one 5-D window: all layers, one launch
+        qc._v.append(qc._v.stage[:, :, :, T:new_len])

@@ -184,10 +184,15 @@ class _KVStore:
     def append(self, xs: Sequence[torch.Tensor], g0: int = 0) -> None:
         """Quantise ``xs`` (one [B,H,Tn,D] tensor per group g0..g0+len) and append Tn tokens to
         each of those groups: ONE launch. All of them must currently hold the same length."""
-        xs = list(xs)
-        n = len(xs)
-        self._bind(xs[0])
-        Tn = xs[0].size(2)
+        if isinstance(xs, torch.Tensor):  # one [n,B,H,Tn,D] view (e.g. a window of the staging buffer)
+            n = xs.size(0)
+            first = xs[0]
+        else:
+            xs = list(xs)
+            n = len(xs)
+            first = xs[0]
+        self._bind(first)
+        Tn = first.size(2)
         if Tn == 0:
             return
         t0 = self.lens[g0]
