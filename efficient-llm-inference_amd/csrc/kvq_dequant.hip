@@ -236,6 +236,9 @@ static const Variant kVariants[] = {
     {8, 1, false, true},   // 15
     {8, 4, true, true},    // 16: as 1 + non-temporal loads
     {8, 2, true, true},    // 17: as 12 + non-temporal loads
+    {8, 1, true, false},   // 18: one vector per thread, scales straight from global (no LDS, no barrier)
+    {8, 2, true, false},   // 19
+    {8, 1, true, false},   // 20: 18 + non-temporal loads
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 // shipped defaults (profiles/r01_microbench.txt): contiguous 1 KiB stores per wave instruction;
@@ -269,6 +272,9 @@ static bool launch_fast_variant(int v, const DequantArgs& a, unsigned grid, hipS
     case 15: launch_fast<ODT, BITS, 8, 1, false, true>(a, grid, st); return true;
     case 16: launch_fast<ODT, BITS, 8, 4, true, true, true>(a, grid, st); return true;
     case 17: launch_fast<ODT, BITS, 8, 2, true, true, true>(a, grid, st); return true;
+    case 18: launch_fast<ODT, BITS, 8, 1, true, false>(a, grid, st); return true;
+    case 19: launch_fast<ODT, BITS, 8, 2, true, false>(a, grid, st); return true;
+    case 20: launch_fast<ODT, BITS, 8, 1, true, false, true>(a, grid, st); return true;
   }
   return false;
 }

@@ -66,6 +66,25 @@ __global__ __launch_bounds__(256) void read16_k(const u32x4* __restrict__ in, ui
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc ^= in[i];
   if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
 }
+// copy recipes: U independent 16-byte loads per thread, then U stores (NT optional); one tile per block
+template <int BLOCK, int U, bool NT>
+__global__ __launch_bounds__(BLOCK) void copy16_tile_k(const u32x4* __restrict__ in, u32x4* __restrict__ out, int64_t n) {
+  const int64_t base = (int64_t)blockIdx.x * BLOCK * U + threadIdx.x;
+  u32x4 v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = base + (int64_t)u * BLOCK;
+    if (i < n) v[u] = NT ? __builtin_nontemporal_load(&in[i]) : in[i];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = base + (int64_t)u * BLOCK;
+    if (i < n) {
+      if (NT) __builtin_nontemporal_store(v[u], &out[i]);
+      else out[i] = v[u];
+    }
+  }
+}
 // read pattern of the chunk mean-pool kernel without its arithmetic: each 16-lane group streams
 // 64 rows of 256 B (one chunk = 16 KiB), a wave covers 4 chunks -> every wave load touches four
 // 256-byte segments 16 KiB apart. batch = loads in flight per lane.
@@ -190,6 +209,22 @@ int main(int argc, char** argv) {
       double ms = tm.ms_per([&] { rotate(); fill16_k<<<grid, 256>>>((u32x4*)out, n16, 7u); }, iters);
       printf("calib fill16   grid=%6d  %8.3f ms  %8.1f GB/s (w)\n", grid, ms, 1.0 * N * 2 / ms / 1e6);
     }
+    {
+      struct Ctx { decltype(rotate)* r; } ctx{&rotate};
+      auto rot = [](void* c) { (*static_cast<Ctx*>(c)->r)(); };
+#define RUN_TILE(BLOCK, U, NT)                                                                              \
+  {                                                                                                         \
+    const int64_t per = (int64_t)BLOCK * U;                                                                 \
+    const unsigned grid = (unsigned)((n16 + per - 1) / per);                                                \
+    double ms = tm.ms_per([&] { rotate(); copy16_tile_k<BLOCK, U, NT><<<grid, BLOCK>>>((const u32x4*)in16, (u32x4*)out, n16); }, iters); \
+    printf("calib copytile block=%4d U=%d nt=%d  %8.3f ms  %8.1f GB/s (r+w)\n", BLOCK, U, (int)NT, ms, 2.0 * N * 2 / ms / 1e6); \
+  }
+      (void)rot; (void)ctx;
+      RUN_TILE(256, 1, false) RUN_TILE(256, 2, false) RUN_TILE(256, 4, false) RUN_TILE(256, 8, false)
+      RUN_TILE(512, 4, false) RUN_TILE(1024, 4, false) RUN_TILE(1024, 1, false)
+      RUN_TILE(256, 4, true) RUN_TILE(256, 8, true) RUN_TILE(512, 4, true) RUN_TILE(1024, 2, true)
+#undef RUN_TILE
+    }
     for (int grid : {4096, 65536}) {
       double ms = tm.ms_per([&] { rotate(); fill16_nt_k<<<grid, 256>>>((u32x4*)out, n16, 7u); }, iters);
       printf("calib fill16nt grid=%6d  %8.3f ms  %8.1f GB/s (w)\n", grid, ms, 1.0 * N * 2 / ms / 1e6);
@@ -247,7 +282,7 @@ int main(int argc, char** argv) {
   if (what == "mixed" || what == "all") {
     hipEvent_t e0, e1, e2;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1)); HIP_OK(hipEventCreate(&e2));
-    for (int v8 : {12, 17}) for (int v4 : {1, 16}) {
+    for (int v8 : {17, 18, 19, 20}) for (int v4 : {1, 18, 19, 20}) {
       double t8 = 0, t4 = 0;
       for (int it = 0; it < iters + 3; ++it) {
         rotate();
