@@ -24,8 +24,8 @@ struct CopyArgs {
   uint32_t cps;          // chunks per segment
 };
 
-constexpr int kCopyUnroll = 4;
-constexpr int64_t kCopyChunk = (int64_t)kBlock * 16 * kCopyUnroll;  // 16 KiB per work item
+constexpr int kCopyUnroll = 1;  // one 16-byte vector per thread: the fastest copy recipe on this chip (profiles: 6.14 vs 5.8 TB/s at 4)
+constexpr int64_t kCopyChunk = (int64_t)kBlock * 16 * kCopyUnroll;  // 4 KiB per work item
 
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void copy_rows_k(const CopyArgs a) {
