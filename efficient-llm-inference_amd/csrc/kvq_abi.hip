@@ -27,7 +27,7 @@ int check_launch(const char* what) {
 }
 
 Tunables& tunables() {
-  static Tunables t = {-1, 0, 0, 0, 0, 1};
+  static Tunables t = {-1, 0, 0, 0, 0, 64, 1};
   return t;
 }
 
@@ -48,6 +48,7 @@ int kvq_set_tunable(const char* key, int64_t value) {
   else if (!strcmp(key, "quant_direct_stores")) t.quant_direct_stores = value;
   else if (!strcmp(key, "pool_grid")) t.pool_grid = value;
   else if (!strcmp(key, "nt_loads")) t.nt_loads = value;
+  else if (!strcmp(key, "quant_block")) t.quant_block = value;
   else {
     kvq::set_error("kvq_set_tunable: unknown key '%s'", key);
     return KVQ_E_DIMS;
@@ -64,6 +65,7 @@ int64_t kvq_get_tunable(const char* key) {
   if (!strcmp(key, "quant_direct_stores")) return t.quant_direct_stores;
   if (!strcmp(key, "pool_grid")) return t.pool_grid;
   if (!strcmp(key, "nt_loads")) return t.nt_loads;
+  if (!strcmp(key, "quant_block")) return t.quant_block;
   return 0;
 }
 

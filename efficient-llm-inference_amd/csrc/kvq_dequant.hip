@@ -76,9 +76,9 @@ __device__ inline void expand8(const uint32_t* wq, float s, float (&x)[8]) {
 // sides (q.t == Dq, out.t == D), D % 8 == 0. Lane l of step u owns LE consecutive elements:
 // LE = 8 makes every store instruction of a wave one contiguous 1 KiB run.
 // Per-token scales of the chunk are staged through LDS once (CHUNK/D tokens), then broadcast.
-template <int ODT, int BITS, int LE, int UNROLL, bool NT, bool LDS_SC, bool NTL = false>
-__global__ __launch_bounds__(kBlock) void dequant_tokens_fast_k(const DequantArgs a) {
-  constexpr int CHUNK = kBlock * LE * UNROLL;
+template <int ODT, int BITS, int LE, int UNROLL, bool NT, bool LDS_SC, bool NTL = false, int BLK = kBlock>
+__global__ __launch_bounds__(BLK) void dequant_tokens_fast_k(const DequantArgs a) {
+  constexpr int CHUNK = BLK * LE * UNROLL;
   constexpr int NW = LE * BITS / 32;
   constexpr int MAXTOK = CHUNK / 8 + 2;
   __shared__ float s_scale[LDS_SC ? MAXTOK : 1];
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kBlock) void dequant_tokens_fast_k(const DequantArg
     uint32_t w[UNROLL][NW];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const uint32_t e = e0 + (u * kBlock + tid) * LE;
+      const uint32_t e = e0 + (u * BLK + tid) * LE;
       if (e < a.row_len) {
         load_words<NW, NTL>(qrow + ((int64_t)e * BITS) / 8, w[u]);
       } else {
@@ -118,14 +118,14 @@ __global__ __launch_bounds__(kBlock) void dequant_tokens_fast_k(const DequantArg
     if constexpr (LDS_SC) {
       uint32_t ntok = (rem0 + CHUNK - 1) / D + 1;
       if (ntok > a.T - tok0) ntok = a.T - tok0;
-      for (uint32_t i = tid; i < ntok; i += kBlock) s_scale[i] = srow[tok0 + i];
+      for (uint32_t i = tid; i < ntok; i += BLK) s_scale[i] = srow[tok0 + i];
       __syncthreads();
     }
 
     // 3. expand, scale, round, store (16 B per lane per store)
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const uint32_t off = (u * kBlock + tid) * LE;
+      const uint32_t off = (u * BLK + tid) * LE;
       const uint32_t e = e0 + off;
       if (e < a.row_len) {
 #pragma unroll
@@ -215,6 +215,7 @@ static inline unsigned grid_for(int64_t work_blocks, int64_t cap) {
 struct Variant {
   int le, unroll;
   bool nt, lds;
+  int blk = kBlock;
 };
 // Index = tunable "dequant_variant". kDefaultVariant ships.
 static const Variant kVariants[] = {
@@ -239,16 +240,26 @@ static const Variant kVariants[] = {
     {8, 1, true, false},   // 18: one vector per thread, scales straight from global (no LDS, no barrier)
     {8, 2, true, false},   // 19
     {8, 1, true, false},   // 20: 18 + non-temporal loads
+    {8, 4, true, true, 64},   // 21: as 1, one-wave workgroups
+    {8, 8, true, true, 64},   // 22
+    {8, 2, true, true, 64},   // 23: as 17 (NT loads), one-wave workgroups
+    {8, 4, true, true, 64},   // 24: as 21 + NT loads
+    {8, 16, true, true, 64},  // 25
+    {8, 2, true, true, 64},   // 26
+    {8, 1, true, true, 64},   // 27
+    {8, 1, true, true, 64},   // 28: 27 + NT loads
+    {8, 4, true, true, 128},  // 29
+    {8, 2, true, true, 128},  // 30: NT loads
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 // shipped defaults (profiles/r01_microbench.txt): contiguous 1 KiB stores per wave instruction;
 // non-temporal stores for the 80 %-write INT4 stream.
-constexpr int kDefaultVariantI4 = 1;
-constexpr int kDefaultVariantI8 = 17;
+constexpr int kDefaultVariantI4 = 21;
+constexpr int kDefaultVariantI8 = 23;
 
-template <int ODT, int BITS, int LE, int UNROLL, bool NT, bool LDS_SC, bool NTL = false>
+template <int ODT, int BITS, int LE, int UNROLL, bool NT, bool LDS_SC, bool NTL = false, int BLK = kBlock>
 static void launch_fast(const DequantArgs& a, unsigned grid, hipStream_t st) {
-  hipLaunchKernelGGL((dequant_tokens_fast_k<ODT, BITS, LE, UNROLL, NT, LDS_SC, NTL>), dim3(grid), dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL((dequant_tokens_fast_k<ODT, BITS, LE, UNROLL, NT, LDS_SC, NTL, BLK>), dim3(grid), dim3(BLK), 0, st, a);
 }
 
 template <int ODT, int BITS>
@@ -275,6 +286,16 @@ static bool launch_fast_variant(int v, const DequantArgs& a, unsigned grid, hipS
     case 18: launch_fast<ODT, BITS, 8, 1, true, false>(a, grid, st); return true;
     case 19: launch_fast<ODT, BITS, 8, 2, true, false>(a, grid, st); return true;
     case 20: launch_fast<ODT, BITS, 8, 1, true, false, true>(a, grid, st); return true;
+    case 21: launch_fast<ODT, BITS, 8, 4, true, true, false, 64>(a, grid, st); return true;
+    case 22: launch_fast<ODT, BITS, 8, 8, true, true, false, 64>(a, grid, st); return true;
+    case 23: launch_fast<ODT, BITS, 8, 2, true, true, true, 64>(a, grid, st); return true;
+    case 24: launch_fast<ODT, BITS, 8, 4, true, true, true, 64>(a, grid, st); return true;
+    case 25: launch_fast<ODT, BITS, 8, 16, true, true, false, 64>(a, grid, st); return true;
+    case 26: launch_fast<ODT, BITS, 8, 2, true, true, false, 64>(a, grid, st); return true;
+    case 27: launch_fast<ODT, BITS, 8, 1, true, true, false, 64>(a, grid, st); return true;
+    case 28: launch_fast<ODT, BITS, 8, 1, true, true, true, 64>(a, grid, st); return true;
+    case 29: launch_fast<ODT, BITS, 8, 4, true, true, false, 128>(a, grid, st); return true;
+    case 30: launch_fast<ODT, BITS, 8, 2, true, true, true, 128>(a, grid, st); return true;
   }
   return false;
 }
@@ -314,7 +335,7 @@ static int dequant_tokens(const uint8_t* q, const kvq_strides_t* q_st, const flo
   int v = (int)tunables().dequant_variant;
   if (v < 0 || v >= kNumVariants) v = BITS == 4 ? kDefaultVariantI4 : kDefaultVariantI8;
   const Variant var = kVariants[v];
-  const int64_t chunk = (int64_t)kBlock * var.le * var.unroll;
+  const int64_t chunk = (int64_t)var.blk * var.le * var.unroll;
 
   // fast path: rows contiguous in (t,d) on both sides, 16-byte vectors everywhere, 32-bit indices
   const int64_t qvec = var.le * BITS / 8;  // bytes per lane load

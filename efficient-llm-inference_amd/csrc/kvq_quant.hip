@@ -42,6 +42,7 @@ struct QuantArgs {
   uint32_t rpc;      // sweep kernel: rows per sweep step
   uint32_t t_begin;  // first token of this launch's first tile
   int32_t nt_loads;  // non-temporal input loads
+  int32_t blk;       // workgroup size of the fused kernel (256, or 64 = one wave per tile)
   int32_t bh_contig; // rows addressable as r * stride_h on both sides
 };
 
@@ -147,9 +148,11 @@ __device__ inline uint32_t pack_i4(const uint32_t (&qb)[8]) {
 // same row (row index and its offsets are scalar) and (t, d) offsets collapse to wv * 8.
 // FULL: every tile of the launch is complete (kBlock * kNVMax vectors, TT tokens inside T), so no
 // lane is ever predicated off: no validity masks, no exec juggling.
-template <int IDT, int BITS, bool ROWU, bool LDS_OUT, bool FULL>
-__global__ __launch_bounds__(kBlock) void quant_tokens_fused_k(const QuantArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_out[LDS_OUT ? kTileElems * BITS / 32 : 4];
+// BLK: workgroup size. 64 = one wave per workgroup: the three barriers cost nothing and waves of
+// different tiles run fully decoupled (tile = 4096 elements).
+template <int IDT, int BITS, bool ROWU, bool LDS_OUT, bool FULL, int BLK = kBlock>
+__global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_out[LDS_OUT ? BLK * kNVMax * 8 * BITS / 32 : 4];
   __shared__ uint32_t s_amax[kMaxTT];
   __shared__ float s_scale[kMaxTT], s_rcp[kMaxTT];
   const uint32_t tid = threadIdx.x;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void quant_tokens_fused_k(const QuantArgs a
   uint8_t* qbase = a.q + (int64_t)g * a.qs.g + (int64_t)t0 * a.qs.t;
   constexpr int QV = BITS;  // bytes stored per 8-element vector: 8 (INT8) or 4 (INT4)
 
-  if (tid < kMaxTT) s_amax[tid] = 0u;
+  for (uint32_t i = tid; i < (uint32_t)kMaxTT; i += BLK) s_amax[i] = 0u;
   __syncthreads();
 
   // pass 1: load the tile (stays in registers), per-(row, token) abs-max -> LDS max across rows
@@ -173,14 +176,14 @@ __global__ __launch_bounds__(kBlock) void quant_tokens_fused_k(const QuantArgs a
   for (int i = 0; i < kNVMax; ++i) {
     uint32_t r, wv;
     if constexpr (ROWU) {
-      r = (uint32_t)(i * kBlock) >> a.vshift;
-      wv = ((uint32_t)(i * kBlock) & wmask) + tid;
+      r = (uint32_t)(i * BLK) >> a.vshift;
+      wv = ((uint32_t)(i * BLK) & wmask) + tid;
     } else {
-      const uint32_t v = i * kBlock + tid;
+      const uint32_t v = i * BLK + tid;
       r = v >> a.vshift;
       wv = v & wmask;
     }
-    valid[i] = FULL || (((uint32_t)(i * kBlock) + tid < a.nvec) && (t0 + (wv >> a.dvshift) < a.T));
+    valid[i] = FULL || (((uint32_t)(i * BLK) + tid < a.nvec) && (t0 + (wv >> a.dvshift) < a.T));
     if (valid[i]) {
       const char* src = in + ((int64_t)r * a.is.h + (int64_t)wv * 8) * Elem<IDT>::size;
       if (a.nt_loads) x[i].load_nt(src);
@@ -189,8 +192,8 @@ __global__ __launch_bounds__(kBlock) void quant_tokens_fused_k(const QuantArgs a
   }
 #pragma unroll
   for (int i = 0; i < kNVMax; ++i) {
-    if (FULL || (uint32_t)(i * kBlock) < a.nvec) {  // uniform: whole waves reach the lane exchanges
-      const uint32_t wv = ((uint32_t)(i * kBlock) + tid) & wmask;
+    if (FULL || (uint32_t)(i * BLK) < a.nvec) {  // uniform: whole waves reach the lane exchanges
+      const uint32_t wv = ((uint32_t)(i * BLK) + tid) & wmask;
       uint32_t m = valid[i] ? x[i].absmax_bits() : 0u;
       m = group_umax(m, a.dvshift);  // the D/8 lanes of one (row, token)
       if (valid[i] && (wv & (DV - 1u)) == 0u) atomicMax(&s_amax[wv >> a.dvshift], m);
@@ -214,10 +217,10 @@ __global__ __launch_bounds__(kBlock) void quant_tokens_fused_k(const QuantArgs a
     if (!FULL && !valid[i]) continue;
     uint32_t r, wv;
     if constexpr (ROWU) {
-      r = (uint32_t)(i * kBlock) >> a.vshift;
-      wv = ((uint32_t)(i * kBlock) & wmask) + tid;
+      r = (uint32_t)(i * BLK) >> a.vshift;
+      wv = ((uint32_t)(i * BLK) & wmask) + tid;
     } else {
-      const uint32_t v = i * kBlock + tid;
+      const uint32_t v = i * BLK + tid;
       r = v >> a.vshift;
       wv = v & wmask;
     }
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void quant_tokens_fused_k(const QuantArgs a
     if (nt > a.TT) nt = a.TT;
     const uint32_t valid_bytes = nt * (a.D * BITS / 8);  // ragged last tile: shorter runs
     const uint32_t total = a.R << row_shift;
-    for (uint32_t k = tid * 16u; k < total; k += kBlock * 16u) {
+    for (uint32_t k = tid * 16u; k < total; k += BLK * 16u) {
       const uint32_t r = k >> row_shift;
       const uint32_t off = k & (row_bytes - 1u);
       if (off < valid_bytes) {
@@ -418,6 +421,20 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
                          a.qs.t % 16 == 0 && aligned(a.q, 16);
     const bool rowu = a.vshift >= 8;
     // complete tiles go to the predicate-free FULL kernel, a ragged last tile to the general one
+    if (a.blk == 64) {  // one-wave workgroups (host guarantees ROWU + LDS_OUT eligibility for this mode)
+      const unsigned n_full64 = a.nvec == 64u * kNVMax ? a.T / a.TT : 0u;
+      if (n_full64) {
+        QuantArgs f = a;
+        f.t_begin = 0;
+        hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64>), dim3(n_full64, a.G), dim3(64), 0, st, f);
+      }
+      if (tiles - n_full64) {
+        QuantArgs t = a;
+        t.t_begin = n_full64 * a.TT;
+        hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, false, 64>), dim3(tiles - n_full64, a.G), dim3(64), 0, st, t);
+      }
+      return;
+    }
     const unsigned n_full = (a.nvec == (uint32_t)(kBlock * kNVMax) && rowu && lds_out) ? a.T / a.TT : 0u;
     if (n_full) {
       QuantArgs f = a;
@@ -505,6 +522,7 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
                a.qs.t % qvec == 0 && a.qs.g % qvec == 0 && aligned(q, qvec);
   a.rpc = 0;
   a.t_begin = 0;
+  a.blk = kBlock;
   a.nt_loads = (int32_t)tunables().nt_loads;
   a.bh_contig = bh_contig ? 1 : 0;
   if (fused && big) {
@@ -526,6 +544,21 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
     a.dvshift = dvshift;
     a.vshift = dvshift + ilog2_exact(tt);
     a.nvec = (uint32_t)(R * tt * (d->D / 8));
+    // one-wave workgroups: tile of 64 * kNVMax vectors, every row run >= 64 vectors (ROWU), 16-byte
+    // aligned row runs in the store (LDS_OUT)
+    const int64_t tile64 = 64 * kNVMax * 8;
+    const int64_t dq16 = (int64_t)d->D * BITS / 8;
+    if (tunables().quant_block == 64 && R * d->D <= tile64 && dq16 % 16 == 0 && a.qs.g % 16 == 0 &&
+        a.qs.h % 16 == 0 && a.qs.t % 16 == 0 && aligned(q, 16)) {
+      uint32_t t64 = pow2_floor((uint64_t)(tile64 / (R * d->D)));
+      if (t64 > kMaxTT) t64 = kMaxTT;
+      if ((int64_t)t64 * (d->D / 8) >= 64 && (int64_t)t64 <= d->T) {
+        a.blk = 64;
+        a.TT = t64;
+        a.vshift = dvshift + ilog2_exact(t64);
+        a.nvec = (uint32_t)(R * t64 * (d->D / 8));
+      }
+    }
   } else {
     a.TT = 1;
     a.dvshift = a.vshift = 0;

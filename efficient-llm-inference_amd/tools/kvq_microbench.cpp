@@ -282,7 +282,7 @@ int main(int argc, char** argv) {
   if (what == "mixed" || what == "all") {
     hipEvent_t e0, e1, e2;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1)); HIP_OK(hipEventCreate(&e2));
-    for (int v8 : {17, 18, 19, 20}) for (int v4 : {1, 18, 19, 20}) {
+    for (int v8 : {23, 26, 28, 30}) for (int v4 : {21, 26, 27, 29}) {
       double t8 = 0, t4 = 0;
       for (int it = 0; it < iters + 3; ++it) {
         rotate();
@@ -306,7 +306,7 @@ int main(int argc, char** argv) {
 
   auto run_quant = [&](int bits) {
     const double bytes = bits == 4 ? N * 2.5 : N * 3.0;
-    for (int two_pass = 0; two_pass < (what == "ntload" ? 1 : 2); ++two_pass) {
+    for (int two_pass = 0; two_pass < ((what == "ntload" || what == "qblock") ? 1 : 2); ++two_pass) {
       KVQ_OK(kvq_set_tunable("quant_force_two_pass", two_pass));
       double ms = tm.ms_per(
           [&] {
@@ -322,6 +322,15 @@ int main(int argc, char** argv) {
     }
     KVQ_OK(kvq_set_tunable("quant_force_two_pass", 0));
   };
+  if (what == "qblock") {
+    for (int blk : {256, 64, 256, 64}) {
+      KVQ_OK(kvq_set_tunable("quant_block", blk));
+      printf("quant_block=%d\n", blk);
+      run_quant(4);
+      run_quant(8);
+    }
+    KVQ_OK(kvq_set_tunable("quant_block", 256));
+  }
   if (what == "ntload") {
     for (int nt = 0; nt < 2; ++nt) {
       KVQ_OK(kvq_set_tunable("nt_loads", nt));

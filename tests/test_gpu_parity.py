@@ -132,7 +132,7 @@ CASES = [  # (G, B, H, T, D)
 ]
 
 
-def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3, direct_stores=False):
+def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3, direct_stores=False, block=256):
     from efficient_llm_inference_amd import _lib, kernels
     G, B, H, T, D = x_np.shape
     x = to_torch(x_np, dtype)
@@ -142,12 +142,14 @@ def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3
     ws = torch.empty(G * T + 8, dtype=torch.float32, device="cuda")
     _lib.set_tunable("quant_force_two_pass", int(force_two_pass))
     _lib.set_tunable("quant_direct_stores", int(direct_stores))
+    _lib.set_tunable("quant_block", int(block))
     try:
         src = [x[g] for g in range(G)] if as_list else x
         kernels.quant_tokens(src, store[:, :, :, 1:T + 1], scales[:, 1:T + 1], ws, kind)
     finally:
         _lib.set_tunable("quant_force_two_pass", 0)
         _lib.set_tunable("quant_direct_stores", 0)
+        _lib.set_tunable("quant_block", 256)
     torch.cuda.synchronize()
     # the window [1, T+1) was written; the guard tokens around it must be untouched
     assert int(store[:, :, :, 0].to(torch.int32).abs().sum()) == 0 and int(store[:, :, :, T + 1:].to(torch.int32).abs().sum()) == 0
@@ -161,11 +163,12 @@ def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3
 def test_oracle_quant_dequant_tokens(E, case, dtype, kind):
     from efficient_llm_inference_amd import kernels
     G, B, H, T, D = case
-    for dist, two_pass, as_list, direct in (("normal", False, False, False), ("heavy", True, True, False),
-                                            ("tiny", False, True, False), ("heavy", False, False, True)):
+    for dist, two_pass, as_list, direct, block in (("normal", False, False, False, 256), ("heavy", True, True, False, 256),
+                                                   ("tiny", False, True, False, 256), ("heavy", False, False, True, 256),
+                                                   ("heavy", False, True, False, 64)):
         x_np = seeded_kv(case, dtype, seed=zlib.crc32(repr((case, dtype, kind, dist)).encode()), dist=dist)
         q_ref, stored_ref, s32_ref = O.quantize_tokens(x_np, kind, dtype=odt(dtype))
-        store, scales = _quant_via_kernels(E, x_np, dtype, kind, two_pass, as_list, direct_stores=direct)
+        store, scales = _quant_via_kernels(E, x_np, dtype, kind, two_pass, as_list, direct_stores=direct, block=block)
         assert np.array_equal(to_numpy(store[:, :, :, 1:T + 1]), q_ref), (dist, two_pass)
         assert np.array_equal(bits(scales[:, 1:T + 1]), bits(s32_ref)), (dist, two_pass)
         for od in DTYPES:
@@ -187,7 +190,7 @@ def test_dequant_all_variants_bit_exact(E, kind, od):
     ref = O.dequantize_tokens(q_ref, s32_ref, kind, 128, od)
     q, sc = to_torch(q_ref), to_torch(s32_ref)
     try:
-        for v in range(21):
+        for v in range(31):
             for grid in (0, 7):
                 _lib.set_tunable("dequant_variant", v)
                 _lib.set_tunable("dequant_grid", grid)
