@@ -282,7 +282,9 @@ int main(int argc, char** argv) {
   if (what == "mixed" || what == "all") {
     hipEvent_t e0, e1, e2;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1)); HIP_OK(hipEventCreate(&e2));
-    for (int v8 : {23, 26, 28, 30}) for (int v4 : {21, 26, 27, 29}) {
+    // 256-thread defaults of the first half of the round (17, 1) vs one-wave workgroups (23, 21) and
+    // their smaller / larger chunk neighbours
+    for (int v8 : {17, 23, 30}) for (int v4 : {1, 21, 26, 22, 29}) {
       double t8 = 0, t4 = 0;
       for (int it = 0; it < iters + 3; ++it) {
         rotate();
