@@ -27,7 +27,7 @@ int check_launch(const char* what) {
 }
 
 Tunables& tunables() {
-  static Tunables t = {-1, 0, 0, 0, 0, 64, 1};
+  static Tunables t = {-1, 0, 0, 0, 0, 64, 64, 1};
   return t;
 }
 
@@ -49,6 +49,7 @@ int kvq_set_tunable(const char* key, int64_t value) {
   else if (!strcmp(key, "pool_grid")) t.pool_grid = value;
   else if (!strcmp(key, "nt_loads")) t.nt_loads = value;
   else if (!strcmp(key, "quant_block")) t.quant_block = value;
+  else if (!strcmp(key, "pool_block")) t.pool_block = value;
   else {
     kvq::set_error("kvq_set_tunable: unknown key '%s'", key);
     return KVQ_E_DIMS;
@@ -66,6 +67,7 @@ int64_t kvq_get_tunable(const char* key) {
   if (!strcmp(key, "pool_grid")) return t.pool_grid;
   if (!strcmp(key, "nt_loads")) return t.nt_loads;
   if (!strcmp(key, "quant_block")) return t.quant_block;
+  if (!strcmp(key, "pool_block")) return t.pool_block;
   return 0;
 }
 

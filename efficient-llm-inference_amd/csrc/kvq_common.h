@@ -38,7 +38,8 @@ struct Tunables {
   int64_t dequant_grid;          // 0 = one chunk per workgroup
   int64_t quant_force_two_pass;  // 1 = generic two-pass quantise for every shape (tests)
   int64_t quant_direct_stores;   // 1 = skip the LDS-staged 16 B stores (tests / A-B)
-  int64_t pool_grid;             // total workgroups of the chunk mean-pool kernel (0 = auto)
+  int64_t pool_grid;             // benchmarks: cap the chunk mean-pool grid (256-thread equivalents); 0 = one item per thread
+  int64_t pool_block;            // chunk mean-pool workgroup size: 64 (default, +7 %), 128 or 256
   int64_t quant_block;           // fused quantise kernel workgroup: 64 (default, one wave per tile: +8-12 %) or 256
   int64_t nt_loads;              // non-temporal input loads in the quantise / pool kernels (default 1: +2-3 % on quantise)
 };

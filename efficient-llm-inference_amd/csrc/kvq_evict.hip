@@ -124,9 +124,8 @@ __global__ __launch_bounds__(kBlock) void chunk_pool_vec_k(const PoolArgs a, uin
   const uint32_t g = blockIdx.y;
   const uint32_t DV = a.D >> 3;
   const int64_t tstride = a.is.t * Elem<DT>::size;
-  // grid-stride over items: a read-dominated stream runs ~8 % faster from a persistent grid
-  // (profiles/r01b_microbench_calibration.txt: read16 6.4 TB/s at 2048 workgroups, 5.9 at 16384)
-  for (uint32_t item = blockIdx.x * kBlock + threadIdx.x; item < items_per_g; item += gridDim.x * kBlock) {
+  // grid-stride only when a benchmark caps the grid; the shipped launch is one item per thread
+  for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < items_per_g; item += gridDim.x * blockDim.x) {
     const uint32_t dv = item % DV;
     uint32_t r = item / DV;
     const uint32_t j = r % a.Tout;
@@ -392,20 +391,20 @@ int kvq_chunk_meanpool(const void* in_base, const void* const* in_ptrs, const kv
                (a.os.t * esz) % 16 == 0;
     for (int64_t i = 0; i < gn && vec; ++i) vec = aligned(a.in.p[i], 16);
     if (vec) {
-      // Launch shape (measured, profiles/r01c_microbench_quant_pool_window.txt): one item per
-      // thread unless the launch is large (> 16 waves of 2048 workgroups), where a persistent
-      // 2048-workgroup grid-stride launch is ~4 % faster (config-5 slice: 5.98 vs 6.22 ms).
-      int64_t want = (items_vec + kBlock - 1) / kBlock;
-      const int64_t cap = tunables().pool_grid > 0 ? tunables().pool_grid : 2048;
-      if (tunables().pool_grid > 0 || want * gn > 16 * cap) {
+      // Launch shape (measured on a config-5-shaped launch, 64-thread workgroups): one item per
+      // thread 6.04 TB/s, persistent grids of 2048 / 4096 / 16384 workgroups 5.85 / 5.94 / 6.00.
+      const int64_t blk = tunables().pool_block == 256 || tunables().pool_block == 128 ? tunables().pool_block : 64;
+      int64_t want = (items_vec + blk - 1) / blk;
+      if (tunables().pool_grid > 0) {  // benchmarks only: persistent grid-stride launch
+        const int64_t cap = tunables().pool_grid * (kBlock / blk);
         const int64_t per_g = (cap + gn - 1) / gn > 8 ? (cap + gn - 1) / gn : 8;
         if (want > per_g) want = per_g;
       }
       const unsigned blocks = (unsigned)want;
       switch (dtype) {
-        case KVQ_F16: hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_F16>), dim3(blocks, (unsigned)gn), dim3(kBlock), 0, st, a, (uint32_t)items_vec); break;
-        case KVQ_BF16: hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_BF16>), dim3(blocks, (unsigned)gn), dim3(kBlock), 0, st, a, (uint32_t)items_vec); break;
-        case KVQ_F32: hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_F32>), dim3(blocks, (unsigned)gn), dim3(kBlock), 0, st, a, (uint32_t)items_vec); break;
+        case KVQ_F16: hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_F16>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec); break;
+        case KVQ_BF16: hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_BF16>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec); break;
+        case KVQ_F32: hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_F32>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec); break;
       }
     } else {
       int64_t blocks = (items_gen + kBlock - 1) / kBlock;

@@ -324,6 +324,17 @@ int main(int argc, char** argv) {
     }
     KVQ_OK(kvq_set_tunable("quant_force_two_pass", 0));
   };
+  if (what == "pblock") {
+    const int64_t Tout = kvq_chunk_summary_len(T, 64, 256);
+    kvq_strides_t s_out = {B * H * Tout * D, H * Tout * D, Tout * D, D};
+    for (int rep = 0; rep < 2; ++rep)
+      for (int blk : {256, 128, 64}) {
+        KVQ_OK(kvq_set_tunable("pool_block", blk));
+        double ms = tm.ms_per([&] { rotate(); KVQ_OK(kvq_chunk_meanpool(in16, nullptr, &s_full, out, &s_out, KVQ_F16, 64, 256, &dims, 0)); }, iters);
+        printf("chunk_meanpool block=%3d  %8.3f ms  %8.1f GB/s\n", blk, ms, 2.0 * G * B * H * D * (T + Tout) / ms / 1e6);
+      }
+    KVQ_OK(kvq_set_tunable("pool_block", 256));
+  }
   if (what == "qblock") {
     for (int blk : {256, 64, 256, 64}) {
       KVQ_OK(kvq_set_tunable("quant_block", blk));
