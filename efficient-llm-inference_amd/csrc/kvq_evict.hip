@@ -24,7 +24,8 @@ struct CopyArgs {
   uint32_t cps;          // chunks per segment
 };
 
-constexpr int kCopyUnroll = 1;  // one 16-byte vector per thread: the fastest copy recipe on this chip (profiles: 6.14 vs 5.8 TB/s at 4)
+constexpr int kCopyUnroll = 1;  // one 16-byte vector per thread + non-temporal load/store: the fastest copy recipe
+                                // on this chip (profiles/r01e_microbench_calibration.txt: 6.58 TB/s; 5.9 at 4 vectors)
 constexpr int64_t kCopyChunk = (int64_t)kBlock * 16 * kCopyUnroll;  // 4 KiB per work item
 
 template <bool VEC>
@@ -45,12 +46,12 @@ __global__ __launch_bounds__(kBlock) void copy_rows_k(const CopyArgs a) {
 #pragma unroll
     for (int u = 0; u < kCopyUnroll; ++u) {
       const int64_t o = c0 + ((int64_t)u * kBlock + threadIdx.x) * 16;
-      if (o < a.seg_bytes) v[u] = *reinterpret_cast<const u32x4*>(src + o);
+      if (o < a.seg_bytes) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + o));
     }
 #pragma unroll
     for (int u = 0; u < kCopyUnroll; ++u) {
       const int64_t o = c0 + ((int64_t)u * kBlock + threadIdx.x) * 16;
-      if (o < a.seg_bytes) *reinterpret_cast<u32x4*>(dst + o) = v[u];
+      if (o < a.seg_bytes) __builtin_nontemporal_store(v[u], reinterpret_cast<u32x4*>(dst + o));
     }
   } else {  // 2-byte granularity (elem_size is 2 or 4)
     int64_t c1 = c0 + kCopyChunk;
@@ -90,8 +91,10 @@ __global__ __launch_bounds__(kBlock) void gather_tokens_k(const GatherArgs a, ui
                       t * a.isb.t + (int64_t)v * kUnit;
     char* dst = a.out + (int64_t)g * a.osb.g + (int64_t)b * a.osb.b + (int64_t)h * a.osb.h + (int64_t)j * a.osb.t +
                 (int64_t)v * kUnit;
-    if constexpr (VEC) *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
-    else *reinterpret_cast<uint16_t*>(dst) = *reinterpret_cast<const uint16_t*>(src);
+    if constexpr (VEC)
+      __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src)), reinterpret_cast<u32x4*>(dst));
+    else
+      *reinterpret_cast<uint16_t*>(dst) = *reinterpret_cast<const uint16_t*>(src);
   }
 }
 

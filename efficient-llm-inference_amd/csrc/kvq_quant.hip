@@ -259,7 +259,8 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
       const uint32_t off = k & (row_bytes - 1u);
       if (off < valid_bytes) {
         const u32x4 w = *reinterpret_cast<const u32x4*>(&s_out[k >> 2]);
-        *reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off) = w;
+        if (a.nt_loads) __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off));
+        else *reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off) = w;
       }
     }
   }

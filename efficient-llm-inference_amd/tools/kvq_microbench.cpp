@@ -220,6 +220,8 @@ int main(int argc, char** argv) {
     printf("calib copytile block=%4d U=%d nt=%d  %8.3f ms  %8.1f GB/s (r+w)\n", BLOCK, U, (int)NT, ms, 2.0 * N * 2 / ms / 1e6); \
   }
       (void)rot; (void)ctx;
+      RUN_TILE(64, 1, false) RUN_TILE(64, 2, false) RUN_TILE(64, 4, false) RUN_TILE(128, 1, false) RUN_TILE(128, 2, false)
+      RUN_TILE(64, 4, true) RUN_TILE(128, 2, true) RUN_TILE(256, 1, true)
       RUN_TILE(256, 1, false) RUN_TILE(256, 2, false) RUN_TILE(256, 4, false) RUN_TILE(256, 8, false)
       RUN_TILE(512, 4, false) RUN_TILE(1024, 4, false) RUN_TILE(1024, 1, false)
       RUN_TILE(256, 4, true) RUN_TILE(256, 8, true) RUN_TILE(512, 4, true) RUN_TILE(1024, 2, true)
