@@ -27,7 +27,7 @@ int check_launch(const char* what) {
 }
 
 Tunables& tunables() {
-  static Tunables t = {-1, 0, 0, 0, 0, 64, 64, 1};
+  static Tunables t = {-1, 0, 0, 0, 0, 64, 64, 0, 1};
   return t;
 }
 
@@ -50,6 +50,7 @@ int kvq_set_tunable(const char* key, int64_t value) {
   else if (!strcmp(key, "nt_loads")) t.nt_loads = value;
   else if (!strcmp(key, "quant_block")) t.quant_block = value;
   else if (!strcmp(key, "pool_block")) t.pool_block = value;
+  else if (!strcmp(key, "quant_no_regmax")) t.quant_no_regmax = value;
   else {
     kvq::set_error("kvq_set_tunable: unknown key '%s'", key);
     return KVQ_E_DIMS;
@@ -68,6 +69,7 @@ int64_t kvq_get_tunable(const char* key) {
   if (!strcmp(key, "nt_loads")) return t.nt_loads;
   if (!strcmp(key, "quant_block")) return t.quant_block;
   if (!strcmp(key, "pool_block")) return t.pool_block;
+  if (!strcmp(key, "quant_no_regmax")) return t.quant_no_regmax;
   return 0;
 }
 

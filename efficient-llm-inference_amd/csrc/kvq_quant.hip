@@ -150,7 +150,10 @@ __device__ inline uint32_t pack_i4(const uint32_t (&qb)[8]) {
 // lane is ever predicated off: no validity masks, no exec juggling.
 // BLK: workgroup size. 64 = one wave per workgroup: the three barriers cost nothing and waves of
 // different tiles run fully decoupled (tile = 4096 elements).
-template <int IDT, int BITS, bool ROWU, bool LDS_OUT, bool FULL, int BLK = kBlock>
+// REGMAX (one-wave tiles whose row run is exactly 64 vectors): round i of the tile IS row i and a
+// lane keeps the same (token, d-vector) in every round, so the abs-max across rows is a register
+// max, the scale is computed per lane, and the kernel needs no LDS, atomics or barriers for it.
+template <int IDT, int BITS, bool ROWU, bool LDS_OUT, bool FULL, int BLK = kBlock, bool REGMAX = false>
 __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t s_out[LDS_OUT ? BLK * kNVMax * 8 * BITS / 32 : 4];
   __shared__ uint32_t s_amax[kMaxTT];
@@ -166,8 +169,10 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
   uint8_t* qbase = a.q + (int64_t)g * a.qs.g + (int64_t)t0 * a.qs.t;
   constexpr int QV = BITS;  // bytes stored per 8-element vector: 8 (INT8) or 4 (INT4)
 
-  for (uint32_t i = tid; i < (uint32_t)kMaxTT; i += BLK) s_amax[i] = 0u;
-  __syncthreads();
+  if constexpr (!REGMAX) {
+    for (uint32_t i = tid; i < (uint32_t)kMaxTT; i += BLK) s_amax[i] = 0u;
+    __syncthreads();
+  }
 
   // pass 1: load the tile (stays in registers), per-(row, token) abs-max -> LDS max across rows
   Vec8<IDT> x[kNVMax];
@@ -190,26 +195,37 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
       else x[i].load(src);
     }
   }
+  float reg_s32 = 0.0f, reg_rcp = 0.0f;
+  if constexpr (REGMAX) {
+    uint32_t m = 0u;
 #pragma unroll
-  for (int i = 0; i < kNVMax; ++i) {
-    if (FULL || (uint32_t)(i * BLK) < a.nvec) {  // uniform: whole waves reach the lane exchanges
-      const uint32_t wv = ((uint32_t)(i * BLK) + tid) & wmask;
-      uint32_t m = valid[i] ? x[i].absmax_bits() : 0u;
-      m = group_umax(m, a.dvshift);  // the D/8 lanes of one (row, token)
-      if (valid[i] && (wv & (DV - 1u)) == 0u) atomicMax(&s_amax[wv >> a.dvshift], m);
+    for (int i = 0; i < kNVMax; ++i) m = max(m, x[i].absmax_bits());  // across the tile's rows
+    m = group_umax(m, a.dvshift);                                       // across the D/8 lanes of the token
+    reg_s32 = fmaxf(Vec8<IDT>::bits_to_f32(m) / QRange<BITS>::qmax, a.eps);
+    reg_rcp = 1.0f / reg_s32;
+    if ((tid & (DV - 1u)) == 0u) a.scales[(int64_t)g * a.ssg + t0 + (tid >> a.dvshift)] = Elem<IDT>::round_trip(reg_s32);
+  } else {
+#pragma unroll
+    for (int i = 0; i < kNVMax; ++i) {
+      if (FULL || (uint32_t)(i * BLK) < a.nvec) {  // uniform: whole waves reach the lane exchanges
+        const uint32_t wv = ((uint32_t)(i * BLK) + tid) & wmask;
+        uint32_t m = valid[i] ? x[i].absmax_bits() : 0u;
+        m = group_umax(m, a.dvshift);  // the D/8 lanes of one (row, token)
+        if (valid[i] && (wv & (DV - 1u)) == 0u) atomicMax(&s_amax[wv >> a.dvshift], m);
+      }
     }
-  }
-  __syncthreads();
+    __syncthreads();
 
-  // per-token scale, its reciprocal (both IEEE divides, once per token) and the stored scale
-  if (tid < a.TT && (FULL || t0 + tid < a.T)) {
-    const float amax = Vec8<IDT>::bits_to_f32(s_amax[tid]);
-    const float s32 = fmaxf(amax / QRange<BITS>::qmax, a.eps);
-    s_scale[tid] = s32;
-    s_rcp[tid] = 1.0f / s32;
-    a.scales[(int64_t)g * a.ssg + t0 + tid] = Elem<IDT>::round_trip(s32);
+    // per-token scale, its reciprocal (both IEEE divides, once per token) and the stored scale
+    if (tid < a.TT && (FULL || t0 + tid < a.T)) {
+      const float amax = Vec8<IDT>::bits_to_f32(s_amax[tid]);
+      const float s32 = fmaxf(amax / QRange<BITS>::qmax, a.eps);
+      s_scale[tid] = s32;
+      s_rcp[tid] = 1.0f / s32;
+      a.scales[(int64_t)g * a.ssg + t0 + tid] = Elem<IDT>::round_trip(s32);
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
   // pass 2: scale, round, pack, store
 #pragma unroll
@@ -226,7 +242,8 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
     }
     const uint32_t tl = wv >> a.dvshift;
     uint32_t qb[8];
-    quotient_bits8<BITS>(x[i], s_scale[tl], s_rcp[tl], qb);
+    if constexpr (REGMAX) quotient_bits8<BITS>(x[i], reg_s32, reg_rcp, qb);
+    else quotient_bits8<BITS>(x[i], s_scale[tl], s_rcp[tl], qb);
     if constexpr (LDS_OUT) {
       // stage the packed bytes in LDS in output order (row-major, wv * QV within the row run)
       const uint32_t widx = ((r << a.vshift) + wv) * (QV / 4);
@@ -427,7 +444,10 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
       if (n_full64) {
         QuantArgs f = a;
         f.t_begin = 0;
-        hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64>), dim3(n_full64, a.G), dim3(64), 0, st, f);
+        if (a.vshift == 6 && !tunables().quant_no_regmax)  // row run == one wave: register abs-max
+          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, true>), dim3(n_full64, a.G), dim3(64), 0, st, f);
+        else
+          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64>), dim3(n_full64, a.G), dim3(64), 0, st, f);
       }
       if (tiles - n_full64) {
         QuantArgs t = a;
