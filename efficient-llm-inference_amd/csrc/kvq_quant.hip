@@ -88,8 +88,8 @@ __device__ inline uint32_t group_umax(uint32_t v, int logw) {
 // the correctly rounded quotient RN(x/s32) is within 2^-24 |p| of x/s32, with |p| <= QMAX (1 + 2^-22)
 // because |x| <= amax and s32 >= RN(amax/QMAX). So if p is farther than
 // m = 1.5 * 2^-22 * QMAX (twice the error bound) from every half-integer, then p, x/s32 and
-// RN(x/s32) all round to the same integer. d = p - rint(p) is exact, and "within m of a
-// half-integer" is d*d >= (0.5 - m)^2. Otherwise (INT8: ~1 element in 11,000; INT4: ~1 in
+// RN(x/s32) all round to the same integer; "within m of a half-integer" is |d| >= 0.5 - m with
+// d = p - rint(p). Otherwise (INT8: ~1 element in 11,000; INT4: ~1 in
 // 200,000) the 8-element vector is redone with the IEEE divide.
 // Rounding: adding 1.5 * 2^23 (even) rounds p to the nearest integer, ties to even — the same
 // integer as rint(p) — and leaves it in two's complement in the low mantissa bits.
@@ -100,7 +100,7 @@ __device__ inline void quotient_bits8(const V& v, float s32, float r, uint32_t (
   constexpr float kBias = BITS == 8 ? 0.0f : 8.0f;
   constexpr float kMagic = 12582912.0f + kBias;  // 1.5 * 2^23 + BIAS
   constexpr float kM = 1.5f * QRange<BITS>::qmax * 0x1p-22f;
-  constexpr float kThr = (0.5f - kM) * (0.5f - kM);
+  constexpr float kThr = 0.5f - kM;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   const f32x2 r2 = {r, r}, magic2 = {kMagic, kMagic};
   float worst = 0.0f;
@@ -111,8 +111,7 @@ __device__ inline void quotient_bits8(const V& v, float s32, float r, uint32_t (
     // within 2^-24 |p| of x/s32 (only r is rounded), inside the same margin
     const f32x2 sum = __builtin_elementwise_fma(x2, r2, magic2);
     const f32x2 d = __builtin_elementwise_fma(x2, r2, magic2 - sum);  // x*r - rint(x*r), one rounding
-    const f32x2 dd = d * d;
-    worst = fmaxf(worst, fmaxf(dd[0], dd[1]));
+    worst = fmaxf(worst, fmaxf(fabsf(d[0]), fabsf(d[1])));              // one v_max3_f32 with |.| modifiers
     qb[2 * k] = __float_as_uint(sum[0]);
     qb[2 * k + 1] = __float_as_uint(sum[1]);
   }
