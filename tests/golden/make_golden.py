@@ -158,6 +158,28 @@ def gen_cache():
     print("g5_cache:", len(out), "arrays")
 
 
+def gen_cache_bf16():
+    """bf16 KV (what Llama-family models produce) with fp16 compute_dtype (what the reference's
+    decode loop asks for on a GPU, benchmarker.py:452): scales are stored rounded to bf16."""
+    out = {}
+    for cname, (L, B, H, T, D) in {"llamaish": (2, 1, 8, 6, 128), "odd": (2, 2, 3, 4, 5)}.items():
+        kv = make_input((L, 2, B, H, T + 1, D), "bf16", "heavy", 2500 + L + D)
+        out[f"{cname}.kv"] = to_np(kv)
+        for mode in ("int8", "int4", "mixed"):
+            qc = QuantizedKVCache(n_layers=L, mode=mode, device="cpu", compute_dtype=torch.float16)
+            qc.init_from_prompt_past(tuple((kv[l, 0, :, :, :T], kv[l, 1, :, :, :T]) for l in range(L)))
+            qc.append_from_past(tuple((kv[l, 0], kv[l, 1]) for l in range(L)))
+            past = qc.to_past_key_values()
+            key = f"{cname}.{mode}"
+            out[key + ".deq"] = to_np(torch.stack([torch.stack([k, v]) for k, v in past]))
+            out[key + ".bytes"] = np.array([qc.estimated_bytes()], dtype=np.int64)
+            ks = torch.stack([torch.stack(layer.k_scales) for layer in qc.layers])
+            vs = torch.stack([torch.stack(layer.v_scales) for layer in qc.layers])
+            out[key + ".scales"] = to_np(torch.stack([ks, vs], dim=1))
+    np.savez_compressed(os.path.join(OUT, "g5b_cache_bf16.npz"), **out)
+    print("g5b_cache_bf16:", len(out), "arrays")
+
+
 def gen_evict():
     out = {}
     case = 0
@@ -231,5 +253,6 @@ if __name__ == "__main__":
     gen_slices()
     gen_kat()
     gen_cache()
+    gen_cache_bf16()
     gen_evict()
     gen_sparse()

@@ -384,3 +384,22 @@ def test_more_than_128_groups_chunked_launches(E):
             assert np.array_equal(bits(res[l][j]), bits(orc[g]))
             assert np.array_equal(bits(win[l][j]), bits(x_np[g][..., T - 4:, :]))
             assert np.array_equal(bits(st[l][j]), bits(O.gather_tokens(x_np[g], idx)))
+
+
+@pytest.mark.parametrize("cname", ["llamaish", "odd"])
+@pytest.mark.parametrize("mode", ["int8", "int4", "mixed"])
+def test_golden_cache_bf16_kv_fp16_compute(E, cname, mode):
+    """bf16 KV tensors (Llama-family) through the container with fp16 compute_dtype."""
+    from tests.conftest import load_golden
+    g = load_golden("g5b_cache_bf16.npz")
+    kv = to_torch(g[f"{cname}.kv"], "bf16")
+    L, _, B, H, T1, D = kv.shape
+    qc = E.QuantizedKVCache(n_layers=L, mode=mode, device="cuda", compute_dtype=torch.float16)
+    qc.init_from_prompt_past(tuple((kv[l, 0, :, :, :T1 - 1], kv[l, 1, :, :, :T1 - 1]) for l in range(L)))
+    qc.append_from_past(tuple((kv[l, 0], kv[l, 1]) for l in range(L)))
+    past = qc.to_past_key_values()
+    deq = torch.stack([torch.stack([k, v]) for k, v in past])
+    assert deq.dtype == torch.float16 and np.array_equal(bits(deq), bits(g[f"{cname}.{mode}.deq"]))
+    sc = torch.stack([torch.stack([torch.stack(l.k_scales), torch.stack(l.v_scales)]) for l in qc.layers])
+    assert sc.dtype == torch.bfloat16 and np.array_equal(bits(sc), bits(g[f"{cname}.{mode}.scales"]))
+    assert qc.estimated_bytes() == int(g[f"{cname}.{mode}.bytes"][0])

@@ -145,3 +145,20 @@ def test_chunk_trajectory(g6):
         lens.append(T)
         T += 1
     assert lens == g6["chunk.trajectory"].tolist() == [764, 264, 257, 257]
+
+
+@pytest.mark.parametrize("cname", ["llamaish", "odd"])
+@pytest.mark.parametrize("mode", ["int8", "int4", "mixed"])
+def test_cache_bf16_kv_fp16_compute(cname, mode):
+    """bf16 KV, fp16 dequantised output (Llama-family dtype with the reference's GPU compute dtype)."""
+    from tests.conftest import load_golden
+    g = load_golden("g5b_cache_bf16.npz")
+    kv = g[f"{cname}.kv"]  # uint16 bf16 bits [L,2,B,H,T,D]
+    L, _, B, H, T, D = kv.shape
+    kinds = {"int8": ("int8", "int8"), "int4": ("int4", "int4"), "mixed": ("int8", "int4")}[mode]
+    for kvi, kind in enumerate(kinds):
+        q, stored, s32 = O.quantize_tokens(kv[:, kvi], kind, dtype="bf16")
+        assert np.array_equal(stored, g[f"{cname}.{mode}.scales"][:, kvi])
+        deq = O.dequantize_tokens(q, s32, kind, D, "f16")
+        assert np.array_equal(deq.view(np.uint8), g[f"{cname}.{mode}.deq"][:, kvi].view(np.uint8))
+    assert O.estimated_bytes(mode, L, B, H, T, D, 2) == int(g[f"{cname}.{mode}.bytes"][0])
