@@ -204,8 +204,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(1, n_dev)  # ranks > GPUs (a rehearsal on a 1-GPU box) share the card
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     backend = None
     if world > 1:
         # RCCL over xGMI for the one scalar reduction of a run; the data path itself needs no
