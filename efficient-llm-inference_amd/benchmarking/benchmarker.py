@@ -191,7 +191,9 @@ class KVCacheBenchmarker:
 
         generated = input_ids.clone()
         staged = None
-        if self.inplace_decode and hf_cache.available():
+        # in place only when the model's KV dtype is the cache's compute dtype (fp16 on the GPU):
+        # the staging buffers are then both what the model reads and what gets quantised
+        if self.inplace_decode and hf_cache.available() and past_kv_tuple[0][0].dtype == compute_dtype:
             staged = hf_cache.StagedQuantizedCache(qcache)
         for _ in range(max_new_tokens):
             next_token = torch.argmax(logits, dim=-1, keepdim=True)
