@@ -104,6 +104,14 @@ class KVCacheBenchmarker:
             enc = self.tokenizer(prompt, return_tensors="pt")
         return enc.input_ids.to(self.device)
 
+    def _compute_dtype(self, past_kv_tuple) -> torch.dtype:
+        """fp16 on "cuda", fp32 otherwise — by the device STRING, like the reference
+        (benchmarker.py:452, :515). One deviation: a bf16 model keeps bf16, because the reference's
+        fp16 choice makes HF's attention fail there (query bf16 vs cached keys fp16/fp32)."""
+        if self.device != "cuda":
+            return torch.float32
+        return torch.bfloat16 if past_kv_tuple[0][0].dtype == torch.bfloat16 else torch.float16
+
     def _finish(self, generated: torch.Tensor, input_ids: torch.Tensor) -> Tuple[str, int]:
         n_new = generated.shape[-1] - input_ids.shape[-1]
         return self.tokenizer.decode(generated[0], skip_special_tokens=True), n_new
@@ -183,7 +191,7 @@ class KVCacheBenchmarker:
         logits = out.logits[:, -1, :]
         past_kv_tuple = to_legacy_tuple(out.past_key_values)
 
-        compute_dtype = torch.float16 if self.device == "cuda" else torch.float32
+        compute_dtype = self._compute_dtype(past_kv_tuple)
         qcache = QuantizedKVCache(n_layers=len(past_kv_tuple), mode=mode, device=self.device,
                                   compute_dtype=compute_dtype)
         qcache.reserve(input_ids.shape[-1] + max_new_tokens)  # decode never reallocates
@@ -284,7 +292,7 @@ class KVCacheBenchmarker:
         out = self.model(input_ids=input_ids, use_cache=True)
         logits = out.logits[:, -1, :]
         past_kv_tuple = to_legacy_tuple(out.past_key_values)
-        dtype = torch.float16 if self.device == "cuda" else torch.float32
+        dtype = self._compute_dtype(past_kv_tuple)
         paged = [PagedKVCache(block_size=block_size, device=self.device, dtype=dtype) for _ in past_kv_tuple]
         for layer_cache, (k, v) in zip(paged, past_kv_tuple):
             layer_cache.extend(k, v)  # == T single-token appends (reference :524-526)
