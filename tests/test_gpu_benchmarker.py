@@ -143,3 +143,19 @@ def test_staged_cache_grows_without_reserve(rig):
         assert len(qc.layers[0]) == 49 and cache.layers[0].get_seq_length() == 49
         for i, layer in enumerate(cache.layers):
             assert torch.equal(layer.keys, k_full[i]) and layer.keys.shape[-2] == 49
+
+
+def test_bf16_model_decodes_with_bf16_compute():
+    """Llama-family dtype: a bf16 model keeps bf16 as the cache's compute dtype (the reference's
+    fp16-by-device-string choice would fail inside HF attention); both decode paths agree."""
+    from efficient_llm_inference_amd import KVCacheBenchmarker
+    from efficient_llm_inference_amd.benchmarking.offline import load_model
+    model, tok = load_model("gpt2-tiny", "cuda", torch.bfloat16)
+    b = KVCacheBenchmarker(model, tok, device="cuda")
+    b.inplace_decode = False
+    a1 = b.generate_with_quantized_kv("<33>", 8, "mixed")
+    b.inplace_decode = True
+    a2 = b.generate_with_quantized_kv("<33>", 8, "mixed")
+    assert a1 == a2 and a1[1] == 8
+    res = b.benchmark_method(["<40>"], "paged_attention", max_new_tokens=4, block_size=8)
+    assert res["total_new_tokens"] == 4
