@@ -76,6 +76,8 @@ __device__ inline void expand8(const uint32_t* wq, float s, float (&x)[8]) {
 // sides (q.t == Dq, out.t == D), D % 8 == 0. Lane l of step u owns LE consecutive elements:
 // LE = 8 makes every store instruction of a wave one contiguous 1 KiB run.
 // Per-token scales of the chunk are staged through LDS once (CHUNK/D tokens), then broadcast.
+// BLK = 64 (shipped): one wave per workgroup, 2048-element chunk = 4 KiB of output — the
+// granularity at which plain copies are fastest on this chip; the LDS barrier is then free.
 template <int ODT, int BITS, int LE, int UNROLL, bool NT, bool LDS_SC, bool NTL = false, int BLK = kBlock>
 __global__ __launch_bounds__(BLK) void dequant_tokens_fast_k(const DequantArgs a) {
   constexpr int CHUNK = BLK * LE * UNROLL;

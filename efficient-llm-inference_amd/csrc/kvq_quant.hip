@@ -12,9 +12,15 @@
 // Roofline: HBM stream, single pass: 2 B in + 1 B (INT8) or 0.5 B (INT4) out per fp16 element.
 // Fused kernel: a workgroup owns a tile of TT tokens x all B*H rows of one group. Rows are T*D
 // apart in memory, so each row contributes one contiguous TT*D run (coalesced 16 B/lane
-// loads). The tile stays in registers between the abs-max pass and the quantise pass;
-// abs-max: per-lane -> wave64 shuffle over the D/8 lanes of a (row, token) -> LDS atomic max
-// across rows (per-token scales live in LDS).
+// loads). The tile stays PACKED in registers between the abs-max pass and the quantise pass.
+//   abs-max   packed u16 max of sign-masked halves -> DPP over the D/8 lanes of a (row, token) ->
+//             register max across rows (one-wave tiles, REGMAX) or LDS ds_max_u32 (larger tiles)
+//   quotient  x * RN(1/s32) with a distance-to-half-integer guard and an IEEE-divide fallback:
+//             bit-exact rint(x / s32) at a third of the cost of dividing every element
+//   stores    staged through LDS in output order, 16 B/lane, non-temporal
+// Shipped launch shape: ONE WAVE per workgroup (64 threads, 4096-element tile): no barrier costs
+// anything and waves of different tiles run decoupled. Larger B*H*D -> quant_tokens_sweep_k;
+// odd / unaligned shapes -> the generic two-pass pair.
 #include "kvq_common.h"
 
 namespace kvq {
