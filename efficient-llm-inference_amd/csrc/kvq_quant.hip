@@ -444,20 +444,30 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
                          a.qs.t % 16 == 0 && aligned(a.q, 16);
     const bool rowu = a.vshift >= 8;
     // complete tiles go to the predicate-free FULL kernel, a ragged last tile to the general one
-    if (a.blk == 64) {  // one-wave workgroups (host guarantees ROWU + LDS_OUT eligibility for this mode)
-      const unsigned n_full64 = a.nvec == 64u * kNVMax ? a.T / a.TT : 0u;
-      if (n_full64) {
+    if (a.blk == 64 || a.blk == 128) {  // small workgroups (host guarantees ROWU + LDS_OUT eligibility)
+      const unsigned n_small = a.nvec == (uint32_t)(a.blk * kNVMax) ? a.T / a.TT : 0u;
+      const bool regmax = (1 << a.vshift) == a.blk && !tunables().quant_no_regmax;  // one round == one row
+      if (n_small) {
         QuantArgs f = a;
         f.t_begin = 0;
-        if (a.vshift == 6 && !tunables().quant_no_regmax)  // row run == one wave: register abs-max
-          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, true>), dim3(n_full64, a.G), dim3(64), 0, st, f);
+        const dim3 grid(n_small, a.G);
+        if (a.blk == 64 && regmax)
+          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, true>), grid, dim3(64), 0, st, f);
+        else if (a.blk == 64)
+          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64>), grid, dim3(64), 0, st, f);
+        else if (regmax)
+          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 128, true>), grid, dim3(128), 0, st, f);
         else
-          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64>), dim3(n_full64, a.G), dim3(64), 0, st, f);
+          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 128>), grid, dim3(128), 0, st, f);
       }
-      if (tiles - n_full64) {
+      if (tiles - n_small) {
         QuantArgs t = a;
-        t.t_begin = n_full64 * a.TT;
-        hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, false, 64>), dim3(tiles - n_full64, a.G), dim3(64), 0, st, t);
+        t.t_begin = n_small * a.TT;
+        const dim3 grid(tiles - n_small, a.G);
+        if (a.blk == 64)
+          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, false, 64>), grid, dim3(64), 0, st, t);
+        else
+          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, false, 128>), grid, dim3(128), 0, st, t);
       }
       return;
     }
@@ -572,14 +582,15 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
     a.nvec = (uint32_t)(R * tt * (d->D / 8));
     // one-wave workgroups: tile of 64 * kNVMax vectors, every row run >= 64 vectors (ROWU), 16-byte
     // aligned row runs in the store (LDS_OUT)
-    const int64_t tile64 = 64 * kNVMax * 8;
+    const int64_t sblk = tunables().quant_block == 128 ? 128 : 64;
+    const int64_t tile64 = sblk * kNVMax * 8;
     const int64_t dq16 = (int64_t)d->D * BITS / 8;
-    if (tunables().quant_block == 64 && R * d->D <= tile64 && dq16 % 16 == 0 && a.qs.g % 16 == 0 &&
-        a.qs.h % 16 == 0 && a.qs.t % 16 == 0 && aligned(q, 16)) {
+    if ((tunables().quant_block == 64 || tunables().quant_block == 128) && R * d->D <= tile64 && dq16 % 16 == 0 &&
+        a.qs.g % 16 == 0 && a.qs.h % 16 == 0 && a.qs.t % 16 == 0 && aligned(q, 16)) {
       uint32_t t64 = pow2_floor((uint64_t)(tile64 / (R * d->D)));
       if (t64 > kMaxTT) t64 = kMaxTT;
-      if ((int64_t)t64 * (d->D / 8) >= 64 && (int64_t)t64 <= d->T) {
-        a.blk = 64;
+      if ((int64_t)t64 * (d->D / 8) >= sblk && (int64_t)t64 <= d->T) {
+        a.blk = (int32_t)sblk;
         a.TT = t64;
         a.vshift = dvshift + ilog2_exact(t64);
         a.nvec = (uint32_t)(R * t64 * (d->D / 8));

@@ -348,7 +348,7 @@ int main(int argc, char** argv) {
     KVQ_OK(kvq_set_tunable("quant_no_regmax", 0));
   }
   if (what == "qblock") {
-    for (int blk : {256, 64, 256, 64}) {
+    for (int blk : {256, 128, 64, 128, 64}) {
       KVQ_OK(kvq_set_tunable("quant_block", blk));
       printf("quant_block=%d\n", blk);
       run_quant(4);

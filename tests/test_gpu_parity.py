@@ -165,7 +165,7 @@ def test_oracle_quant_dequant_tokens(E, case, dtype, kind):
     G, B, H, T, D = case
     for dist, two_pass, as_list, direct, block in (("normal", False, False, False, 256), ("heavy", True, True, False, 256),
                                                    ("tiny", False, True, False, 256), ("heavy", False, False, True, 256),
-                                                   ("heavy", False, True, False, 64)):
+                                                   ("heavy", False, True, False, 64), ("normal", False, False, False, 128)):
         x_np = seeded_kv(case, dtype, seed=zlib.crc32(repr((case, dtype, kind, dist)).encode()), dist=dist)
         q_ref, stored_ref, s32_ref = O.quantize_tokens(x_np, kind, dtype=odt(dtype))
         store, scales = _quant_via_kernels(E, x_np, dtype, kind, two_pass, as_list, direct_stores=direct, block=block)
