@@ -41,6 +41,7 @@ struct Tunables {
   int64_t pool_grid;             // benchmarks: cap the chunk mean-pool grid (256-thread equivalents); 0 = one item per thread
   int64_t pool_block;            // chunk mean-pool workgroup size: 64 (default, +7 %), 128 or 256
   int64_t quant_block;           // fused quantise kernel workgroup: 64 (default, one wave per tile), 128 or 256 (measured: 241 / 261 / 270 us)
+  int64_t quant_nv;              // 4 = 2048-element one-wave tiles (A-B), else 8
   int64_t quant_no_regmax;       // 1 = keep the LDS abs-max in one-wave tiles (A-B)
   int64_t nt_loads;              // non-temporal input loads in the quantise / pool kernels (default 1: +2-3 % on quantise)
 };

@@ -49,6 +49,7 @@ struct QuantArgs {
   uint32_t t_begin;  // first token of this launch's first tile
   int32_t nt_loads;  // non-temporal input loads
   int32_t blk;       // workgroup size of the fused kernel (256, or 64 = one wave per tile)
+  int32_t nv;        // vectors per lane per tile (8, or 4 for the small one-wave tile)
   int32_t bh_contig; // rows addressable as r * stride_h on both sides
 };
 
@@ -155,12 +156,14 @@ __device__ inline uint32_t pack_i4(const uint32_t (&qb)[8]) {
 // lane is ever predicated off: no validity masks, no exec juggling.
 // BLK: workgroup size. 64 = one wave per workgroup: the three barriers cost nothing and waves of
 // different tiles run fully decoupled (tile = 4096 elements).
-// REGMAX (one-wave tiles whose row run is exactly 64 vectors): round i of the tile IS row i and a
-// lane keeps the same (token, d-vector) in every round, so the abs-max across rows is a register
-// max, the scale is computed per lane, and the kernel needs no LDS, atomics or barriers for it.
-template <int IDT, int BITS, bool ROWU, bool LDS_OUT, bool FULL, int BLK = kBlock, bool REGMAX = false>
+// REGMAX (one-wave tiles whose row run is at most 64 vectors): a lane keeps the same
+// (token, d-vector) in every round and only the row changes, so the abs-max across rows is a
+// register max (plus one lane exchange per halving of the row run below 64 vectors), the scale is
+// computed per lane, and the kernel needs no LDS, atomics or barriers for it.
+// NV: 16-byte vectors per lane per tile (tile = BLK * NV * 8 elements).
+template <int IDT, int BITS, bool ROWU, bool LDS_OUT, bool FULL, int BLK = kBlock, bool REGMAX = false, int NV = kNVMax>
 __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_out[LDS_OUT ? BLK * kNVMax * 8 * BITS / 32 : 4];
+  __shared__ __attribute__((aligned(16))) uint32_t s_out[LDS_OUT ? BLK * NV * 8 * BITS / 32 : 4];
   __shared__ uint32_t s_amax[kMaxTT];
   __shared__ float s_scale[kMaxTT], s_rcp[kMaxTT];
   const uint32_t tid = threadIdx.x;
@@ -180,10 +183,10 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
   }
 
   // pass 1: load the tile (stays in registers), per-(row, token) abs-max -> LDS max across rows
-  Vec8<IDT> x[kNVMax];
-  bool valid[kNVMax];
+  Vec8<IDT> x[NV];
+  bool valid[NV];
 #pragma unroll
-  for (int i = 0; i < kNVMax; ++i) {
+  for (int i = 0; i < NV; ++i) {
     uint32_t r, wv;
     if constexpr (ROWU) {
       r = (uint32_t)(i * BLK) >> a.vshift;
@@ -204,14 +207,16 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
   if constexpr (REGMAX) {
     uint32_t m = 0u;
 #pragma unroll
-    for (int i = 0; i < kNVMax; ++i) m = max(m, x[i].absmax_bits());  // across the tile's rows
+    for (int i = 0; i < NV; ++i) m = max(m, x[i].absmax_bits());  // across the tile's rows
     m = group_umax(m, a.dvshift);                                       // across the D/8 lanes of the token
+    for (int sh = a.vshift; sh < 6; ++sh) m = max(m, (uint32_t)__shfl_xor((int)m, 1 << sh));  // row run < one wave
     reg_s32 = fmaxf(Vec8<IDT>::bits_to_f32(m) / QRange<BITS>::qmax, a.eps);
     reg_rcp = 1.0f / reg_s32;
-    if ((tid & (DV - 1u)) == 0u) a.scales[(int64_t)g * a.ssg + t0 + (tid >> a.dvshift)] = Elem<IDT>::round_trip(reg_s32);
+    if ((tid & (DV - 1u)) == 0u && (tid >> a.vshift) == 0u)
+      a.scales[(int64_t)g * a.ssg + t0 + ((tid & wmask) >> a.dvshift)] = Elem<IDT>::round_trip(reg_s32);
   } else {
 #pragma unroll
-    for (int i = 0; i < kNVMax; ++i) {
+    for (int i = 0; i < NV; ++i) {
       if (FULL || (uint32_t)(i * BLK) < a.nvec) {  // uniform: whole waves reach the lane exchanges
         const uint32_t wv = ((uint32_t)(i * BLK) + tid) & wmask;
         uint32_t m = valid[i] ? x[i].absmax_bits() : 0u;
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
 
   // pass 2: scale, round, pack, store
 #pragma unroll
-  for (int i = 0; i < kNVMax; ++i) {
+  for (int i = 0; i < NV; ++i) {
     if (!FULL && !valid[i]) continue;
     uint32_t r, wv;
     if constexpr (ROWU) {
@@ -444,6 +449,20 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
                          a.qs.t % 16 == 0 && aligned(a.q, 16);
     const bool rowu = a.vshift >= 8;
     // complete tiles go to the predicate-free FULL kernel, a ragged last tile to the general one
+    if (a.blk == 64 && a.nv == 4) {  // smallest tile: 2048 elements per wave, row runs <= one wave
+      const unsigned n_small = a.nvec == 64u * 4u ? a.T / a.TT : 0u;
+      if (n_small) {
+        QuantArgs f = a;
+        f.t_begin = 0;
+        hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, false, true, true, 64, true, 4>), dim3(n_small, a.G), dim3(64), 0, st, f);
+      }
+      if (tiles - n_small) {
+        QuantArgs t = a;
+        t.t_begin = n_small * a.TT;
+        hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, false, true, false, 64, false, 4>), dim3(tiles - n_small, a.G), dim3(64), 0, st, t);
+      }
+      return;
+    }
     if (a.blk == 64 || a.blk == 128) {  // small workgroups (host guarantees ROWU + LDS_OUT eligibility)
       const unsigned n_small = a.nvec == (uint32_t)(a.blk * kNVMax) ? a.T / a.TT : 0u;
       const bool regmax = (1 << a.vshift) == a.blk && !tunables().quant_no_regmax;  // one round == one row
@@ -559,6 +578,7 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
   a.rpc = 0;
   a.t_begin = 0;
   a.blk = kBlock;
+  a.nv = kNVMax;
   a.nt_loads = (int32_t)tunables().nt_loads;
   a.bh_contig = bh_contig ? 1 : 0;
   if (fused && big) {
@@ -583,14 +603,18 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
     // one-wave workgroups: tile of 64 * kNVMax vectors, every row run >= 64 vectors (ROWU), 16-byte
     // aligned row runs in the store (LDS_OUT)
     const int64_t sblk = tunables().quant_block == 128 ? 128 : 64;
-    const int64_t tile64 = sblk * kNVMax * 8;
+    const int64_t snv = (sblk == 64 && tunables().quant_nv == 4) ? 4 : kNVMax;
+    const int64_t tile64 = sblk * snv * 8;
     const int64_t dq16 = (int64_t)d->D * BITS / 8;
     if ((tunables().quant_block == 64 || tunables().quant_block == 128) && R * d->D <= tile64 && dq16 % 16 == 0 &&
         a.qs.g % 16 == 0 && a.qs.h % 16 == 0 && a.qs.t % 16 == 0 && aligned(q, 16)) {
       uint32_t t64 = pow2_floor((uint64_t)(tile64 / (R * d->D)));
       if (t64 > kMaxTT) t64 = kMaxTT;
-      if ((int64_t)t64 * (d->D / 8) >= sblk && (int64_t)t64 <= d->T) {
+      const bool row_ok = snv == 4 ? (int64_t)t64 * (d->D / 8) <= 64  // register abs-max handles short row runs
+                                   : (int64_t)t64 * (d->D / 8) >= sblk;
+      if (row_ok && (int64_t)t64 <= d->T) {
         a.blk = (int32_t)sblk;
+        a.nv = (int32_t)snv;
         a.TT = t64;
         a.vshift = dvshift + ilog2_exact(t64);
         a.nvec = (uint32_t)(R * t64 * (d->D / 8));

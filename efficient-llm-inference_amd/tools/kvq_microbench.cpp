@@ -310,7 +310,7 @@ int main(int argc, char** argv) {
 
   auto run_quant = [&](int bits) {
     const double bytes = bits == 4 ? N * 2.5 : N * 3.0;
-    for (int two_pass = 0; two_pass < ((what == "ntload" || what == "qblock" || what == "regmax") ? 1 : 2); ++two_pass) {
+    for (int two_pass = 0; two_pass < ((what == "ntload" || what == "qblock" || what == "regmax" || what == "qnv") ? 1 : 2); ++two_pass) {
       KVQ_OK(kvq_set_tunable("quant_force_two_pass", two_pass));
       double ms = tm.ms_per(
           [&] {
@@ -336,6 +336,16 @@ int main(int argc, char** argv) {
         printf("chunk_meanpool block=%3d  %8.3f ms  %8.1f GB/s\n", blk, ms, 2.0 * G * B * H * D * (T + Tout) / ms / 1e6);
       }
     KVQ_OK(kvq_set_tunable("pool_block", 256));
+  }
+  if (what == "qnv") {
+    for (int rep = 0; rep < 2; ++rep)
+      for (int nv : {8, 4}) {
+        KVQ_OK(kvq_set_tunable("quant_nv", nv));
+        printf("quant_nv=%d\n", nv);
+        run_quant(4);
+        run_quant(8);
+      }
+    KVQ_OK(kvq_set_tunable("quant_nv", 8));
   }
   if (what == "regmax") {
     for (int rep = 0; rep < 2; ++rep)

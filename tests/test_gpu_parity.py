@@ -132,7 +132,7 @@ CASES = [  # (G, B, H, T, D)
 ]
 
 
-def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3, direct_stores=False, block=256):
+def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3, direct_stores=False, block=256, nv=8):
     from efficient_llm_inference_amd import _lib, kernels
     G, B, H, T, D = x_np.shape
     x = to_torch(x_np, dtype)
@@ -143,13 +143,15 @@ def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3
     _lib.set_tunable("quant_force_two_pass", int(force_two_pass))
     _lib.set_tunable("quant_direct_stores", int(direct_stores))
     _lib.set_tunable("quant_block", int(block))
+    _lib.set_tunable("quant_nv", int(nv))
     try:
         src = [x[g] for g in range(G)] if as_list else x
         kernels.quant_tokens(src, store[:, :, :, 1:T + 1], scales[:, 1:T + 1], ws, kind)
     finally:
         _lib.set_tunable("quant_force_two_pass", 0)
         _lib.set_tunable("quant_direct_stores", 0)
-        _lib.set_tunable("quant_block", 256)
+        _lib.set_tunable("quant_block", 64)
+        _lib.set_tunable("quant_nv", 8)
     torch.cuda.synchronize()
     # the window [1, T+1) was written; the guard tokens around it must be untouched
     assert int(store[:, :, :, 0].to(torch.int32).abs().sum()) == 0 and int(store[:, :, :, T + 1:].to(torch.int32).abs().sum()) == 0
@@ -163,12 +165,13 @@ def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3
 def test_oracle_quant_dequant_tokens(E, case, dtype, kind):
     from efficient_llm_inference_amd import kernels
     G, B, H, T, D = case
-    for dist, two_pass, as_list, direct, block in (("normal", False, False, False, 256), ("heavy", True, True, False, 256),
-                                                   ("tiny", False, True, False, 256), ("heavy", False, False, True, 256),
-                                                   ("heavy", False, True, False, 64), ("normal", False, False, False, 128)):
+    for dist, two_pass, as_list, direct, block, nv in (
+            ("normal", False, False, False, 256, 8), ("heavy", True, True, False, 256, 8), ("tiny", False, True, False, 256, 8),
+            ("heavy", False, False, True, 256, 8), ("heavy", False, True, False, 64, 8), ("normal", False, False, False, 128, 8),
+            ("heavy", False, False, False, 64, 4)):
         x_np = seeded_kv(case, dtype, seed=zlib.crc32(repr((case, dtype, kind, dist)).encode()), dist=dist)
         q_ref, stored_ref, s32_ref = O.quantize_tokens(x_np, kind, dtype=odt(dtype))
-        store, scales = _quant_via_kernels(E, x_np, dtype, kind, two_pass, as_list, direct_stores=direct, block=block)
+        store, scales = _quant_via_kernels(E, x_np, dtype, kind, two_pass, as_list, direct_stores=direct, block=block, nv=nv)
         assert np.array_equal(to_numpy(store[:, :, :, 1:T + 1]), q_ref), (dist, two_pass)
         assert np.array_equal(bits(scales[:, 1:T + 1]), bits(s32_ref)), (dist, two_pass)
         for od in DTYPES:
