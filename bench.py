@@ -81,6 +81,18 @@ def cpu_baseline(L, B, H, T, D, sample_layers):
     C.dequantize_tokens(q, sc, "int4", D, "f16")
     dt = time.perf_counter() - t0
     n = n_layers * B * H * T * D
+    # the reference's literal call structure (per-slice op chains + T-way cat) on a small sample
+    import torch as _t
+    from oracle import literal_loop as LL
+    Ts = min(T, 2048)
+    qs = [_t.from_numpy(q[0, :, :, t:t + 1, :].copy()) for t in range(Ts)]
+    ss = [_t.tensor(float(sc[0, t]), dtype=_t.float16) for t in range(Ts)]
+    _t.set_num_threads(os.cpu_count() or 1)
+    LL.dequantize_slices(qs[:64], ss[:64], "int4", D, _t.float16)
+    t1 = time.perf_counter()
+    LL.dequantize_slices(qs, ss, "int4", D, _t.float16)
+    dl = time.perf_counter() - t1
+    n_lit = B * H * Ts * D
     return {
         "value": round(n * BYTES_PER_ELT["int4"] / dt / 1e9, 4),
         "unit": "GB/s",
@@ -89,6 +101,10 @@ def cpu_baseline(L, B, H, T, D, sample_layers):
         "sample": f"INT4->fp16 dequantise of {n_layers}/{L} layers of the V set "
                   f"[{n_layers},{B},{H},{T},{D}] ({n} elements, {dt:.2f} s), oracle/kvq_oracle.c scalar",
         "host_cores_available": os.cpu_count(),
+        "literal_loop": {"value": round(n_lit * BYTES_PER_ELT["int4"] / dl / 1e9, 5), "unit": "GB/s",
+                         "sample": f"per-slice dequantise + {Ts}-way cat of one layer's V [{B},{H},{Ts},{D}] with torch-CPU ops "
+                                   f"({dl:.2f} s), the reference's own call structure (oracle/literal_loop.py)",
+                         "torch_threads": _t.get_num_threads()},
     }
 
 

@@ -57,3 +57,16 @@ def test_c_oracle_vs_reference_goldens(g5, cname, dtype):
 def test_c_chunk_summary_equals_numpy_oracle(g6, dtype, T, chunk, keep):
     x = g6[f"chunk.{dtype}.T{T}.c{chunk}.k{keep}.x"]
     assert np.array_equal(C.chunk_summarize(x, chunk, keep).view(np.uint8), O.chunk_summarize_kv(x, chunk, keep).view(np.uint8))
+
+
+@pytest.mark.parametrize("kind", ["int8", "int4"])
+def test_literal_loop_equals_numpy_oracle(kind):
+    """The per-slice torch-CPU restatement (bench.py's 'literal' CPU leg) agrees with the oracle."""
+    import torch
+    from oracle import literal_loop as LL
+    x = seeded_kv((1, 2, 3, 9, 16), "f16", 5, "heavy")
+    q_ref, _, s32 = O.quantize_tokens(x, kind)
+    qs, scales = LL.quantize_slices(torch.from_numpy(x[0]), kind)
+    assert np.array_equal(torch.cat(qs, dim=2).numpy(), q_ref[0])
+    out = LL.dequantize_slices(qs, scales, kind, 16, torch.float16)
+    assert np.array_equal(out.numpy().view(np.uint8), O.dequantize_tokens(q_ref, s32, kind, 16, "f16")[0].view(np.uint8))
