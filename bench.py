@@ -63,7 +63,7 @@ def parse():
                     help="independent quantised caches visited round-robin by consecutive steps, so that no "
                          "step re-reads lines the 256 MiB Infinity Cache may still hold (1 = the decode loop's "
                          "behaviour: the same cache every step; its 256 MiB INT4 store then stays cache-resident)")
-    ap.add_argument("--cpu-sample-layers", type=int, default=16)
+    ap.add_argument("--cpu-sample-layers", type=int, default=32)
     return ap.parse_args()
 
 
@@ -77,9 +77,11 @@ def cpu_baseline(L, B, H, T, D, sample_layers):
     q = rng.integers(0, 256, size=(n_layers, B, H, T, D // 2), dtype=np.uint8)
     sc = (rng.random((n_layers, T), dtype=np.float32) * 0.02 + 0.001).astype(np.float32)
     C.dequantize_tokens(q[:1], sc[:1], "int4", D, "f16")  # warm (page in, load lib)
-    t0 = time.perf_counter()
-    C.dequantize_tokens(q, sc, "int4", D, "f16")
-    dt = time.perf_counter() - t0
+    dt = float("inf")
+    for _ in range(3):  # best of three passes over the sample (~10 s of CPU work at the default)
+        t0 = time.perf_counter()
+        C.dequantize_tokens(q, sc, "int4", D, "f16")
+        dt = min(dt, time.perf_counter() - t0)
     n = n_layers * B * H * T * D
     # the reference's literal call structure (per-slice op chains + T-way cat) on a small sample
     import torch as _t
@@ -99,7 +101,7 @@ def cpu_baseline(L, B, H, T, D, sample_layers):
         "cores": 1,
         "kind": "port",
         "sample": f"INT4->fp16 dequantise of {n_layers}/{L} layers of the V set "
-                  f"[{n_layers},{B},{H},{T},{D}] ({n} elements, {dt:.2f} s), oracle/kvq_oracle.c scalar",
+                  f"[{n_layers},{B},{H},{T},{D}] ({n} elements, best of 3 passes: {dt:.2f} s), oracle/kvq_oracle.c scalar",
         "host_cores_available": os.cpu_count(),
         "literal_loop": {"value": round(n_lit * BYTES_PER_ELT["int4"] / dl / 1e9, 5), "unit": "GB/s",
                          "sample": f"per-slice dequantise + {Ts}-way cat of one layer's V [{B},{H},{Ts},{D}] with torch-CPU ops "
