@@ -46,6 +46,8 @@ struct QuantArgs {
   int32_t vshift;    // log2(TT * D/8)
   uint32_t nvec;     // R * TT * D/8 vectors per full tile
   uint32_t rpc;      // sweep kernel: rows per sweep step
+  uint32_t dv;       // sweep kernel, D/8 not a power of two (or > 64): D/8
+  uint32_t vpr;      // sweep kernel, same case: TT * D/8 vectors per row run
   uint32_t t_begin;  // first token of this launch's first tile
   int32_t nt_loads;  // non-temporal input loads
   int32_t blk;       // workgroup size of the fused kernel (256, or 64 = one wave per tile)
@@ -298,7 +300,9 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
 // TT tokens x all R rows of one group, but sweeps the rows twice in steps of `rpc` rows — once for
 // the per-token abs-max (LDS), once to quantise. The second sweep re-reads what the workgroup has
 // just read (tile sized to stay cache-resident), no global atomics, no workspace.
-template <int IDT, int BITS>
+// POW2 = false: D/8 is not a power of two (D = 80, 96, 160, 192 ...) or exceeds one wave: index
+// decomposition by 32-bit division and one LDS atomic per lane instead of the DPP group max.
+template <int IDT, int BITS, bool POW2>
 __global__ __launch_bounds__(kBlock) void quant_tokens_sweep_k(const QuantArgs a) {
   __shared__ uint32_t s_amax[kMaxTT];
   __shared__ float s_scale[kMaxTT], s_rcp[kMaxTT];
@@ -306,10 +310,22 @@ __global__ __launch_bounds__(kBlock) void quant_tokens_sweep_k(const QuantArgs a
   const uint32_t g = blockIdx.y;
   const uint32_t t0 = a.t_begin + blockIdx.x * a.TT;
   const uint32_t DV = a.D >> 3;
-  const uint32_t wmask = (1u << a.vshift) - 1u;
+  const uint32_t wmask = POW2 ? (1u << a.vshift) - 1u : 0u;
   const char* in = reinterpret_cast<const char*>(a.in.p[g]) + (int64_t)t0 * a.is.t * Elem<IDT>::size;
   uint8_t* qbase = a.q + (int64_t)g * a.qs.g + (int64_t)t0 * a.qs.t;
   constexpr int QV = BITS;
+  // vector index in a sweep step -> (row in step, vector in the row's TT-token run, token in tile)
+  auto split = [&](uint32_t v, uint32_t& rl, uint32_t& wv, uint32_t& tl) {
+    if constexpr (POW2) {
+      rl = v >> a.vshift;
+      wv = v & wmask;
+      tl = wv >> a.dvshift;
+    } else {
+      rl = v / a.vpr;
+      wv = v - rl * a.vpr;
+      tl = wv / a.dv;
+    }
+  };
   auto in_row = [&](uint32_t r) -> int64_t {
     return a.bh_contig ? (int64_t)r * a.is.h : (int64_t)(r / a.H) * a.is.b + (int64_t)(r % a.H) * a.is.h;
   };
@@ -322,21 +338,26 @@ __global__ __launch_bounds__(kBlock) void quant_tokens_sweep_k(const QuantArgs a
 
   for (uint32_t r0 = 0; r0 < a.R; r0 += a.rpc) {  // sweep 1: abs-max
     const uint32_t rows = a.R - r0 < a.rpc ? a.R - r0 : a.rpc;
-    const uint32_t nv = rows << a.vshift;
+    const uint32_t nv = POW2 ? rows << a.vshift : rows * a.vpr;
 #pragma unroll
     for (int i = 0; i < kNVMax; ++i) {
       if ((uint32_t)(i * kBlock) < nv) {  // uniform
         const uint32_t v = i * kBlock + tid;
-        const uint32_t wv = v & wmask;
-        const bool ok = v < nv && t0 + (wv >> a.dvshift) < a.T;
+        uint32_t rl, wv, tl;
+        split(v, rl, wv, tl);
+        const bool ok = v < nv && t0 + tl < a.T;
         uint32_t m = 0u;
         if (ok) {
           Vec8<IDT> x;
-          x.load(in + (in_row(r0 + (v >> a.vshift)) + (int64_t)wv * 8) * Elem<IDT>::size);
+          x.load(in + (in_row(r0 + rl) + (int64_t)wv * 8) * Elem<IDT>::size);
           m = x.absmax_bits();
         }
-        m = group_umax(m, a.dvshift);
-        if (ok && (wv & (DV - 1u)) == 0u) atomicMax(&s_amax[wv >> a.dvshift], m);
+        if constexpr (POW2) {
+          m = group_umax(m, a.dvshift);
+          if (ok && (wv & (DV - 1u)) == 0u) atomicMax(&s_amax[tl], m);
+        } else {
+          if (ok) atomicMax(&s_amax[tl], m);
+        }
       }
     }
   }
@@ -352,14 +373,14 @@ __global__ __launch_bounds__(kBlock) void quant_tokens_sweep_k(const QuantArgs a
 
   for (uint32_t r0 = 0; r0 < a.R; r0 += a.rpc) {  // sweep 2: quantise
     const uint32_t rows = a.R - r0 < a.rpc ? a.R - r0 : a.rpc;
-    const uint32_t nv = rows << a.vshift;
+    const uint32_t nv = POW2 ? rows << a.vshift : rows * a.vpr;
 #pragma unroll
     for (int i = 0; i < kNVMax; ++i) {
       const uint32_t v = i * kBlock + tid;
-      const uint32_t wv = v & wmask;
-      const uint32_t tl = wv >> a.dvshift;
+      uint32_t rl, wv, tl;
+      split(v, rl, wv, tl);
       if (v < nv && t0 + tl < a.T) {
-        const uint32_t r = r0 + (v >> a.vshift);
+        const uint32_t r = r0 + rl;
         Vec8<IDT> x;
         x.load(in + (in_row(r) + (int64_t)wv * 8) * Elem<IDT>::size);
         uint32_t qb[8];
@@ -440,7 +461,10 @@ template <int IDT, int BITS>
 static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
   if (fused && a.rpc) {  // swept tile: B*H*D larger than the register tile
     const unsigned tiles = (a.T + a.TT - 1) / a.TT;
-    hipLaunchKernelGGL((quant_tokens_sweep_k<IDT, BITS>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
+    if (a.vpr)
+      hipLaunchKernelGGL((quant_tokens_sweep_k<IDT, BITS, false>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
+    else
+      hipLaunchKernelGGL((quant_tokens_sweep_k<IDT, BITS, true>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
   } else if (fused) {
     const unsigned tiles = (a.T + a.TT - 1) / a.TT;
     // LDS-staged 16 B stores need 16-byte aligned row runs in the store
@@ -569,19 +593,35 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
   const int dvshift = d->D % 8 == 0 ? ilog2_exact(d->D / 8) : -1;
   const int64_t qvec = BITS == 8 ? 8 : 4;  // bytes stored per 8-element vector
   const bool bh_contig = d->B == 1 || (a.is.b == d->H * a.is.h && a.qs.b == d->H * a.qs.h);
-  const bool big = R * d->D > kTileElems;  // swept-tile kernel instead of the register tile
-  bool fused = !tunables().quant_force_two_pass && dvshift >= 0 && d->D / 8 <= kWave && d->D <= kTileElems &&
+  // D/8 not a power of two, or wider than one wave: swept tile with division-based indexing
+  const bool anydv = d->D % 8 == 0 && (dvshift < 0 || d->D / 8 > kWave);
+  const bool big = anydv || R * d->D > kTileElems;  // swept-tile kernel instead of the register tile
+  bool fused = !tunables().quant_force_two_pass && d->D % 8 == 0 && d->D <= kTileElems &&
                (d->T == 1 || (a.is.t == d->D && a.qs.t == Dq)) && (big || bh_contig) &&
                (a.is.b * esz) % 16 == 0 && a.qs.b % qvec == 0 &&
                (a.is.h * esz) % 16 == 0 && (a.is.t * esz) % 16 == 0 && a.qs.h % qvec == 0 &&
                a.qs.t % qvec == 0 && a.qs.g % qvec == 0 && aligned(q, qvec);
   a.rpc = 0;
+  a.dv = a.vpr = 0;
   a.t_begin = 0;
   a.blk = kBlock;
   a.nv = kNVMax;
   a.nt_loads = (int32_t)tunables().nt_loads;
   a.bh_contig = bh_contig ? 1 : 0;
-  if (fused && big) {
+  if (fused && anydv) {
+    const int64_t dv = d->D / 8;
+    int64_t tt = (256 * 1024) / (R * d->D * esz);
+    if (tt < 1) tt = 1;
+    if (tt > kMaxTT) tt = kMaxTT;
+    if (tt * dv > kBlock * kNVMax) tt = (kBlock * kNVMax) / dv;  // >= 1: D <= kTileElems
+    if (tt > d->T) tt = d->T;
+    a.TT = (uint32_t)tt;
+    a.dvshift = a.vshift = 0;
+    a.nvec = 0;
+    a.dv = (uint32_t)dv;
+    a.vpr = (uint32_t)(tt * dv);
+    a.rpc = (uint32_t)((kBlock * kNVMax) / a.vpr);
+  } else if (fused && big) {
     // tile = R x TT tokens, kept around 256 KiB so the second sweep is served from cache
     uint64_t tt = pow2_floor((uint64_t)((256 * 1024) / (R * d->D * esz) > 0 ? (256 * 1024) / (R * d->D * esz) : 1));
     if (tt > (uint64_t)kMaxTT) tt = kMaxTT;
@@ -658,6 +698,7 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
       b.dvshift = b.vshift = 0;
       b.nvec = 0;
       b.rpc = 0;
+      b.dv = b.vpr = 0;
     }
     switch (in_dtype) {
       case KVQ_F16: launch_quant<KVQ_F16, BITS>(b, fused_here, st); break;

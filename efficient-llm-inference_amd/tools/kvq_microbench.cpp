@@ -153,6 +153,7 @@ int main(int argc, char** argv) {
   if (getenv("KVQ_T")) T = atoll(getenv("KVQ_T"));
   if (getenv("KVQ_B")) B = atoll(getenv("KVQ_B"));
   if (getenv("KVQ_H")) H = atoll(getenv("KVQ_H"));
+  if (getenv("KVQ_D")) D = atoll(getenv("KVQ_D"));  // multiple of 8
   hipDeviceProp_t prop;
   HIP_OK(hipGetDeviceProperties(&prop, 0));
   printf("# device %s CUs=%d  shape G=%lld B=%lld H=%lld T=%lld D=%lld iters=%d\n", prop.gcnArchName,

@@ -128,7 +128,11 @@ CASES = [  # (G, B, H, T, D)
     (1, 64, 8, 3, 128),    # R*D = 65536 > register tile: swept-tile kernel
     (2, 40, 8, 21, 64),    # R*D = 20480: swept tile, several tokens per tile, ragged last tile
     (2, 2, 3, 7, 5),       # odd D: generic kernels
-    (1, 1, 2, 4, 24),      # D % 8 == 0 but D/8 not a power of two: generic quantise
+    (1, 1, 2, 4, 24),      # D % 8 == 0 but D/8 not a power of two: division-indexed swept tile
+    (3, 1, 8, 131, 96),    # D/8 = 12 (phi / falcon-style heads), ragged last tile
+    (2, 2, 5, 70, 80),     # D/8 = 10, batch > 1, R*D*TT spans several sweep steps
+    (1, 40, 8, 9, 160),    # D/8 = 20, R*D = 51200: many sweep steps per tile
+    (2, 1, 3, 6, 1024),    # D/8 = 128 > one wave: division-indexed swept tile
 ]
 
 
