@@ -43,6 +43,7 @@ struct Tunables {
   int64_t quant_block;           // fused quantise kernel workgroup: 64 (default, one wave per tile), 128 or 256 (measured: 241 / 261 / 270 us)
   int64_t quant_nv;              // 4 = 2048-element one-wave tiles (A-B), else 8
   int64_t quant_no_regmax;       // 1 = keep the LDS abs-max in one-wave tiles (A-B)
+  int64_t quant_lds_pad;         // A-B: bytes of unused dynamic LDS on the one-wave quantise launch (caps waves per CU)
   int64_t nt_loads;              // non-temporal input loads in the quantise / pool kernels (default 1: +2-3 % on quantise)
 };
 Tunables& tunables();

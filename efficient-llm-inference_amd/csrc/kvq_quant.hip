@@ -104,8 +104,20 @@ __device__ inline uint32_t group_umax(uint32_t v, int logw) {
 // integer as rint(p) — and leaves it in two's complement in the low mantissa bits.
 // No clamp is needed for finite inputs: the quotient is bounded by QMAX (1 + 2^-23), which
 // rounds to QMAX (the reference's clamp never fires either).
+// KVQ_QUANT_CALIB (calibration builds only, `make calib`; results are NOT exact): 1 = fast path
+// without the guard / exact redo, 2 = no arithmetic at all (raw input bits are packed) — they bound
+// what the guard and the whole quotient cost on top of the tile's memory traffic. 3 = 2 without the
+// stores, 4 = 2 without the loads (f16 / bf16 inputs only): the tile pattern's read-only and write-only rates.
+#ifndef KVQ_QUANT_CALIB
+#define KVQ_QUANT_CALIB 0
+#endif
 template <int BITS, class V>
 __device__ inline void quotient_bits8(const V& v, float s32, float r, uint32_t (&qb)[8]) {
+#if KVQ_QUANT_CALIB >= 2
+#pragma unroll
+  for (int j = 0; j < 8; ++j) qb[j] = __float_as_uint(v.get(j)) >> 16;
+  return;
+#endif
   constexpr float kBias = BITS == 8 ? 0.0f : 8.0f;
   constexpr float kMagic = 12582912.0f + kBias;  // 1.5 * 2^23 + BIAS
   constexpr float kM = 1.5f * QRange<BITS>::qmax * 0x1p-22f;
@@ -119,8 +131,10 @@ __device__ inline void quotient_bits8(const V& v, float s32, float r, uint32_t (
     // sum = RN(x*r + magic) = magic + rint(x*r): the fma rounds the EXACT product, which is
     // within 2^-24 |p| of x/s32 (only r is rounded), inside the same margin
     const f32x2 sum = __builtin_elementwise_fma(x2, r2, magic2);
+#if KVQ_QUANT_CALIB == 0
     const f32x2 d = __builtin_elementwise_fma(x2, r2, magic2 - sum);  // x*r - rint(x*r), one rounding
     worst = fmaxf(worst, fmaxf(fabsf(d[0]), fabsf(d[1])));              // one v_max3_f32 with |.| modifiers
+#endif
     qb[2 * k] = __float_as_uint(sum[0]);
     qb[2 * k + 1] = __float_as_uint(sum[1]);
   }
@@ -163,7 +177,7 @@ __device__ inline uint32_t pack_i4(const uint32_t (&qb)[8]) {
 // register max (plus one lane exchange per halving of the row run below 64 vectors), the scale is
 // computed per lane, and the kernel needs no LDS, atomics or barriers for it.
 // NV: 16-byte vectors per lane per tile (tile = BLK * NV * 8 elements).
-template <int IDT, int BITS, bool ROWU, bool LDS_OUT, bool FULL, int BLK = kBlock, bool REGMAX = false, int NV = kNVMax>
+template <int IDT, int BITS, bool ROWU, bool LDS_OUT, bool FULL, int BLK = kBlock, int REGMAX = 0, int NV = kNVMax>
 __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t s_out[LDS_OUT ? BLK * NV * 8 * BITS / 32 : 4];
   __shared__ uint32_t s_amax[kMaxTT];
@@ -179,7 +193,7 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
   uint8_t* qbase = a.q + (int64_t)g * a.qs.g + (int64_t)t0 * a.qs.t;
   constexpr int QV = BITS;  // bytes stored per 8-element vector: 8 (INT8) or 4 (INT4)
 
-  if constexpr (!REGMAX) {
+  if constexpr (REGMAX == 0) {
     for (uint32_t i = tid; i < (uint32_t)kMaxTT; i += BLK) s_amax[i] = 0u;
     __syncthreads();
   }
@@ -201,21 +215,36 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
     valid[i] = FULL || (((uint32_t)(i * BLK) + tid < a.nvec) && (t0 + (wv >> a.dvshift) < a.T));
     if (valid[i]) {
       const char* src = in + ((int64_t)r * a.is.h + (int64_t)wv * 8) * Elem<IDT>::size;
+#if KVQ_QUANT_CALIB == 4  // write-only pattern: no loads (the branch on eps is never taken)
+      if (a.eps < 0.0f) x[i].load(src);
+      else if constexpr (IDT != KVQ_F32) x[i].w = u32x4{tid, (uint32_t)i, r, wv};
+#else
       if (a.nt_loads) x[i].load_nt(src);
       else x[i].load(src);
+#endif
     }
   }
-  float reg_s32 = 0.0f, reg_rcp = 0.0f;
-  if constexpr (REGMAX) {
-    uint32_t m = 0u;
+  // REGMAX = number of lane identities: 1 = the row run is one round wide (or narrower), 2 = two
+  // rounds wide (rounds alternate between the run's two halves)
+  constexpr int RM = REGMAX > 0 ? REGMAX : 1;
+  float reg_s32[RM], reg_rcp[RM];
+  if constexpr (REGMAX > 0) {
+    uint32_t m[RM];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) m = max(m, x[i].absmax_bits());  // across the tile's rows
-    m = group_umax(m, a.dvshift);                                       // across the D/8 lanes of the token
-    for (int sh = a.vshift; sh < 6; ++sh) m = max(m, (uint32_t)__shfl_xor((int)m, 1 << sh));  // row run < one wave
-    reg_s32 = fmaxf(Vec8<IDT>::bits_to_f32(m) / QRange<BITS>::qmax, a.eps);
-    reg_rcp = 1.0f / reg_s32;
-    if ((tid & (DV - 1u)) == 0u && (tid >> a.vshift) == 0u)
-      a.scales[(int64_t)g * a.ssg + t0 + ((tid & wmask) >> a.dvshift)] = Elem<IDT>::round_trip(reg_s32);
+    for (int p = 0; p < RM; ++p) m[p] = 0u;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) m[i % RM] = max(m[i % RM], x[i].absmax_bits());  // across the tile's rows
+#pragma unroll
+    for (int p = 0; p < RM; ++p) {
+      uint32_t mp = group_umax(m[p], a.dvshift);  // across the D/8 lanes of the token
+      if constexpr (RM == 1)
+        for (int sh = a.vshift; sh < 6; ++sh) mp = max(mp, (uint32_t)__shfl_xor((int)mp, 1 << sh));  // row run < one wave
+      reg_s32[p] = fmaxf(Vec8<IDT>::bits_to_f32(mp) / QRange<BITS>::qmax, a.eps);
+      reg_rcp[p] = 1.0f / reg_s32[p];
+      const uint32_t wv = (uint32_t)(p * BLK) + tid;  // this lane's vector in the row run, rounds i % RM == p
+      if ((tid & (DV - 1u)) == 0u && (RM > 1 || (tid >> a.vshift) == 0u))
+        a.scales[(int64_t)g * a.ssg + t0 + ((wv & wmask) >> a.dvshift)] = Elem<IDT>::round_trip(reg_s32[p]);
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -254,7 +283,7 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
     }
     const uint32_t tl = wv >> a.dvshift;
     uint32_t qb[8];
-    if constexpr (REGMAX) quotient_bits8<BITS>(x[i], reg_s32, reg_rcp, qb);
+    if constexpr (REGMAX > 0) quotient_bits8<BITS>(x[i], reg_s32[i % RM], reg_rcp[i % RM], qb);
     else quotient_bits8<BITS>(x[i], s_scale[tl], s_rcp[tl], qb);
     if constexpr (LDS_OUT) {
       // stage the packed bytes in LDS in output order (row-major, wv * QV within the row run)
@@ -286,7 +315,11 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
     for (uint32_t k = tid * 16u; k < total; k += BLK * 16u) {
       const uint32_t r = k >> row_shift;
       const uint32_t off = k & (row_bytes - 1u);
+#if KVQ_QUANT_CALIB == 3  // read-only pattern: the stores stay in the code but never execute
+      if (off < valid_bytes && a.eps < 0.0f) {
+#else
       if (off < valid_bytes) {
+#endif
         const u32x4 w = *reinterpret_cast<const u32x4*>(&s_out[k >> 2]);
         if (a.nt_loads) __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off));
         else *reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off) = w;
@@ -487,6 +520,24 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
       }
       return;
     }
+    if (a.blk == 64 && a.nv == 16) {  // 8192-element one-wave tile: twice the row run (512 B INT4 store pieces)
+      const unsigned n_small = a.nvec == 64u * 16u ? a.T / a.TT : 0u;
+      const bool regmax2 = (1 << a.vshift) == 128 && !tunables().quant_no_regmax;
+      if (n_small) {
+        QuantArgs f = a;
+        f.t_begin = 0;
+        if (regmax2)
+          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, 2, 16>), dim3(n_small, a.G), dim3(64), 0, st, f);
+        else
+          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, 0, 16>), dim3(n_small, a.G), dim3(64), 0, st, f);
+      }
+      if (tiles - n_small) {
+        QuantArgs t = a;
+        t.t_begin = n_small * a.TT;
+        hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, false, 64, 0, 16>), dim3(tiles - n_small, a.G), dim3(64), 0, st, t);
+      }
+      return;
+    }
     if (a.blk == 64 || a.blk == 128) {  // small workgroups (host guarantees ROWU + LDS_OUT eligibility)
       const unsigned n_small = a.nvec == (uint32_t)(a.blk * kNVMax) ? a.T / a.TT : 0u;
       const bool regmax = (1 << a.vshift) == a.blk && !tunables().quant_no_regmax;  // one round == one row
@@ -494,8 +545,9 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
         QuantArgs f = a;
         f.t_begin = 0;
         const dim3 grid(n_small, a.G);
-        if (a.blk == 64 && regmax)
-          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, true>), grid, dim3(64), 0, st, f);
+        if (a.blk == 64 && regmax)  // quant_lds_pad: occupancy A-B only (dynamic LDS the kernel never touches)
+          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, true>), grid, dim3(64),
+                             (size_t)tunables().quant_lds_pad, st, f);
         else if (a.blk == 64)
           hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64>), grid, dim3(64), 0, st, f);
         else if (regmax)
@@ -643,7 +695,7 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
     // one-wave workgroups: tile of 64 * kNVMax vectors, every row run >= 64 vectors (ROWU), 16-byte
     // aligned row runs in the store (LDS_OUT)
     const int64_t sblk = tunables().quant_block == 128 ? 128 : 64;
-    const int64_t snv = (sblk == 64 && tunables().quant_nv == 4) ? 4 : kNVMax;
+    const int64_t snv = (sblk == 64 && tunables().quant_nv == 4) ? 4 : (sblk == 64 && tunables().quant_nv == 16) ? 16 : kNVMax;
     const int64_t tile64 = sblk * snv * 8;
     const int64_t dq16 = (int64_t)d->D * BITS / 8;
     if ((tunables().quant_block == 64 || tunables().quant_block == 128) && R * d->D <= tile64 && dq16 % 16 == 0 &&

@@ -311,7 +311,7 @@ int main(int argc, char** argv) {
 
   auto run_quant = [&](int bits) {
     const double bytes = bits == 4 ? N * 2.5 : N * 3.0;
-    for (int two_pass = 0; two_pass < ((what == "ntload" || what == "qblock" || what == "regmax" || what == "qnv") ? 1 : 2); ++two_pass) {
+    for (int two_pass = 0; two_pass < ((what == "ntload" || what == "qblock" || what == "regmax" || what == "qnv" || what == "qocc") ? 1 : 2); ++two_pass) {
       KVQ_OK(kvq_set_tunable("quant_force_two_pass", two_pass));
       double ms = tm.ms_per(
           [&] {
@@ -340,13 +340,23 @@ int main(int argc, char** argv) {
   }
   if (what == "qnv") {
     for (int rep = 0; rep < 2; ++rep)
-      for (int nv : {8, 4}) {
+      for (int nv : {8, 16, 4}) {
         KVQ_OK(kvq_set_tunable("quant_nv", nv));
         printf("quant_nv=%d\n", nv);
         run_quant(4);
         run_quant(8);
       }
     KVQ_OK(kvq_set_tunable("quant_nv", 8));
+  }
+  if (what == "qocc") {  // waves per CU of the one-wave quantise kernel, capped through unused dynamic LDS
+    for (int rep = 0; rep < 2; ++rep)
+      for (int pad : {0, 6144, 16384, 36864, 77824}) {
+        KVQ_OK(kvq_set_tunable("quant_lds_pad", pad));
+        printf("quant_lds_pad=%d\n", pad);
+        run_quant(4);
+        run_quant(8);
+      }
+    KVQ_OK(kvq_set_tunable("quant_lds_pad", 0));
   }
   if (what == "regmax") {
     for (int rep = 0; rep < 2; ++rep)

@@ -158,7 +158,7 @@ int kvq_gather_tokens(const void* in_base, const void* const* in_ptrs, const kvq
 /* ---- tuning knobs (benchmarks only; defaults are what ships) ----------------------------- */
 
 /* key: "dequant_variant" (0..30, -1 = shipped default), "dequant_grid" (workgroups, 0 = one chunk
- * each), "quant_force_two_pass" (0/1), "quant_direct_stores" (0/1), "pool_grid" (workgroup cap, 0 = none), "nt_loads" (0/1), "quant_block" (64|128|256), "quant_nv" (8|4), "quant_no_regmax" (0/1), "pool_block" (64|128|256).
+ * each), "quant_force_two_pass" (0/1), "quant_direct_stores" (0/1), "pool_grid" (workgroup cap, 0 = none), "nt_loads" (0/1), "quant_block" (64|128|256), "quant_nv" (8|4|16), "quant_lds_pad" (bytes of unused dynamic LDS, occupancy A-B), "quant_no_regmax" (0/1), "pool_block" (64|128|256).
  * Returns 0, or KVQ_E_DIMS for an unknown key. Process-global. */
 int kvq_set_tunable(const char* key, int64_t value);
 int64_t kvq_get_tunable(const char* key);

@@ -172,7 +172,7 @@ def test_oracle_quant_dequant_tokens(E, case, dtype, kind):
     for dist, two_pass, as_list, direct, block, nv in (
             ("normal", False, False, False, 256, 8), ("heavy", True, True, False, 256, 8), ("tiny", False, True, False, 256, 8),
             ("heavy", False, False, True, 256, 8), ("heavy", False, True, False, 64, 8), ("normal", False, False, False, 128, 8),
-            ("heavy", False, False, False, 64, 4)):
+            ("heavy", False, False, False, 64, 4), ("normal", False, True, False, 64, 16)):
         x_np = seeded_kv(case, dtype, seed=zlib.crc32(repr((case, dtype, kind, dist)).encode()), dist=dist)
         q_ref, stored_ref, s32_ref = O.quantize_tokens(x_np, kind, dtype=odt(dtype))
         store, scales = _quant_via_kernels(E, x_np, dtype, kind, two_pass, as_list, direct_stores=direct, block=block, nv=nv)
