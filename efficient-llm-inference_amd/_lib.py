@@ -36,6 +36,8 @@ EXPORTS = (
     "kvq_chunk_meanpool",
     "kvq_chunk_summary_len",
     "kvq_gather_tokens",
+    "kvq_decode_attn_workspace",
+    "kvq_decode_attn",
     "kvq_set_tunable",
     "kvq_get_tunable",
 )
@@ -47,6 +49,10 @@ class KvqDims(Structure):
 
 class KvqStrides(Structure):
     _fields_ = [("g", c_int64), ("b", c_int64), ("h", c_int64), ("t", c_int64)]
+
+
+class KvqAttnDims(Structure):
+    _fields_ = [("B", c_int64), ("Hq", c_int64), ("Hkv", c_int64), ("T", c_int64), ("D", c_int64)]
 
 
 class KvqError(RuntimeError):
@@ -90,6 +96,12 @@ def _declare(lib):
     lib.kvq_chunk_meanpool.argtypes = [P, POINTER(c_void_p), ST, P, ST, c_int, c_int64, c_int64, DM, P]
     lib.kvq_gather_tokens.restype = c_int
     lib.kvq_gather_tokens.argtypes = [P, POINTER(c_void_p), ST, P, ST, c_int, P, c_int64, DM, P]
+    AD = POINTER(KvqAttnDims)
+    lib.kvq_decode_attn_workspace.restype = c_int64
+    lib.kvq_decode_attn_workspace.argtypes = [AD]
+    lib.kvq_decode_attn.restype = c_int
+    lib.kvq_decode_attn.argtypes = [P, c_int64, c_int64, P, ST, P, c_int, P, ST, P, c_int, P, c_int64, c_int64,
+                                    P, c_int64, c_int64, P, c_int64, c_int64, c_int, c_float, P, c_int64, AD, P]
     lib.kvq_chunk_summary_len.restype = c_int64
     lib.kvq_chunk_summary_len.argtypes = [c_int64, c_int64, c_int64]
     lib.kvq_set_tunable.restype = c_int
@@ -163,7 +175,7 @@ def get_tunable(key: str) -> int:
 
 
 __all__ = [
-    "KvqDims", "KvqStrides", "KvqError", "load", "check", "current_stream", "require_gpu",
+    "KvqDims", "KvqStrides", "KvqAttnDims", "KvqError", "load", "check", "current_stream", "require_gpu",
     "strides4", "dims5", "ptr_array", "dtype_code", "set_tunable", "get_tunable", "byref",
     "c_void_p", "LIB_PATH", "EXPORTS", "KVQ_F16", "KVQ_BF16", "KVQ_F32",
 ]

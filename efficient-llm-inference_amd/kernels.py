@@ -222,3 +222,71 @@ def gather_tokens(x: TensorOrList, out: torch.Tensor, idx: torch.Tensor) -> None
                                        dt.itemsize, c_void_p(idx.data_ptr()), n, byref(dims5(G, B, H, T, D)),
                                        _lib.current_stream(dev))
     check(rc, "gather_tokens")
+
+
+def decode_attn_workspace(B: int, Hq: int, Hkv: int, T: int, D: int) -> int:
+    """fp32 elements of scratch :func:`decode_attn` needs for these dims (include/kvq_hip.h)."""
+    n = int(_lib.load().kvq_decode_attn_workspace(byref(_lib.KvqAttnDims(B, Hq, Hkv, T, D))))
+    if n < 0:
+        raise _lib.KvqError(f"kvq: bad decode-attention dims B={B} Hq={Hq} Hkv={Hkv} T={T} D={D}")
+    return n
+
+
+def decode_attn(q: torch.Tensor, k_store: torch.Tensor, k_scales: torch.Tensor, k_kind: str,
+                v_store: torch.Tensor, v_scales: torch.Tensor, v_kind: str, T: int, out: torch.Tensor,
+                workspace: torch.Tensor, sm_scale: float, k_new: torch.Tensor | None = None,
+                v_new: torch.Tensor | None = None) -> None:
+    """One decode step of ONE layer straight from the quantised store (kvq_decode_attn).
+
+    q / out ``[B, Hq, D]``, k_new / v_new ``[B, Hkv, D]`` (fp16 or bf16, last dim contiguous, any
+    batch / head strides); k_store / v_store ``[B, Hkv, Tcap, Dq]`` views of one layer of the store
+    (int8, or uint8 packed INT4); k_scales / v_scales ``[>= T]`` fp32 rows of the scale table. The
+    first ``T`` stored tokens are attended, plus the exact new token when given. Replaces
+    ``to_past_key_values`` + the model's attention over the dequantised past
+    (reference src/quantization/ops.py:345-355, src/benchmarking/benchmarker.py:470-471).
+    """
+    for name, t in (("q", q), ("out", out), ("k_store", k_store), ("v_store", v_store), ("k_scales", k_scales),
+                    ("v_scales", v_scales), ("workspace", workspace)):
+        require_gpu(t, name)
+    if q.dim() != 3 or out.shape != q.shape or out.dtype != q.dtype:
+        raise _lib.KvqError(f"kvq: decode_attn q / out must be matching [B,Hq,D] tensors, got {tuple(q.shape)} / {tuple(out.shape)}")
+    if q.dtype not in (torch.float16, torch.bfloat16):
+        raise _lib.KvqError(f"kvq: decode_attn computes from fp16 / bf16 queries, got {q.dtype}")
+    B, Hq, D = q.shape
+    if k_store.dim() != 4 or v_store.dim() != 4 or k_store.shape[:2] != v_store.shape[:2] or k_store.size(0) != B:
+        raise _lib.KvqError("kvq: decode_attn stores must be [B,Hkv,Tcap,Dq] views of one layer")
+    Hkv = k_store.size(1)
+    if k_store.dtype != QDTYPE[k_kind] or v_store.dtype != QDTYPE[v_kind]:
+        raise _lib.KvqError("kvq: decode_attn store dtype does not match its kind")
+    if k_store.size(3) != packed_dim(k_kind, D) or v_store.size(3) != packed_dim(v_kind, D):
+        raise _lib.KvqError("kvq: decode_attn store last dim does not match head_dim")
+    T = int(T)
+    if T < 0 or T > k_store.size(2) or T > v_store.size(2) or k_scales.numel() < T or v_scales.numel() < T:
+        raise _lib.KvqError(f"kvq: decode_attn T={T} exceeds the store / scale table")
+    for name, t in (("q", q), ("out", out), ("k_store", k_store), ("v_store", v_store)):
+        if t.stride(-1) != 1:
+            raise _lib.KvqError(f"kvq: decode_attn {name} last dim must be contiguous")
+    if k_scales.dtype != torch.float32 or v_scales.dtype != torch.float32 or workspace.dtype != torch.float32:
+        raise _lib.KvqError("kvq: decode_attn scales / workspace must be float32")
+    if (T > 0 and (k_scales.stride(-1) != 1 or v_scales.stride(-1) != 1)) or not workspace.is_contiguous():
+        raise _lib.KvqError("kvq: decode_attn scales / workspace must be contiguous")
+    if (k_new is None) != (v_new is None):
+        raise _lib.KvqError("kvq: decode_attn k_new and v_new go together")
+    kn = vn = (None, 0, 0)
+    if k_new is not None:
+        for name, t in (("k_new", k_new), ("v_new", v_new)):
+            require_gpu(t, name)
+            if t.shape != (B, Hkv, D) or t.dtype != q.dtype or t.stride(-1) != 1:
+                raise _lib.KvqError(f"kvq: decode_attn {name} must be [B,Hkv,D] of the query dtype")
+        kn = (c_void_p(k_new.data_ptr()), k_new.stride(0), k_new.stride(1))
+        vn = (c_void_p(v_new.data_ptr()), v_new.stride(0), v_new.stride(1))
+    kst = KvqStrides(0, k_store.stride(0), k_store.stride(1), k_store.stride(2))  # 1-byte elements: bytes
+    vst = KvqStrides(0, v_store.stride(0), v_store.stride(1), v_store.stride(2))
+    dims = _lib.KvqAttnDims(B, Hq, Hkv, T, D)
+    check(_lib.load().kvq_decode_attn(
+        c_void_p(q.data_ptr()), q.stride(0), q.stride(1),
+        c_void_p(k_store.data_ptr()), byref(kst), c_void_p(k_scales.data_ptr()), KIND_BITS[k_kind],
+        c_void_p(v_store.data_ptr()), byref(vst), c_void_p(v_scales.data_ptr()), KIND_BITS[v_kind],
+        kn[0], kn[1], kn[2], vn[0], vn[1], vn[2],
+        c_void_p(out.data_ptr()), out.stride(0), out.stride(1), dtype_code(q.dtype), float(sm_scale),
+        c_void_p(workspace.data_ptr()), workspace.numel(), byref(dims), _lib.current_stream(q.device)), "decode_attn")

@@ -155,6 +155,38 @@ int kvq_gather_tokens(const void* in_base, const void* const* in_ptrs, const kvq
                       void* out, const kvq_strides_t* out_st, int elem_size, const int32_t* idx,
                       int64_t n_idx, const kvq_dims_t* dims, void* stream);
 
+/* ---- decode attention over the quantised store -------------------------- */
+
+typedef struct {
+  int64_t B, Hq, Hkv, T, D; /* T = stored (quantised) tokens attended; Hq % Hkv == 0, Hq/Hkv <= 8 */
+} kvq_attn_dims_t;
+
+/* Workspace floats kvq_decode_attn needs for these dims (-1 on bad dims). */
+int64_t kvq_decode_attn_workspace(const kvq_attn_dims_t* dims);
+
+/* One decode step of one layer without materialising the fp16 cache. Replaces, for a single
+ * query token, QuantizedKVCache.to_past_key_values (src/quantization/ops.py:345-355: dequantise
+ * every stored token) + the model's attention over [dequantised past, new token]
+ * (src/benchmarking/benchmarker.py:470-471):
+ *   s[t]   = sm_scale * k_scales[t] * sum_d q[d] * k_int[t,d]            t < T
+ *   s_new  = sm_scale * sum_d q[d] * k_new[d]                             (if k_new)
+ *   p      = softmax over {s[0..T), s_new}
+ *   out[d] = sum_t p[t] * v_scales[t] * v_int[t,d] + p_new * v_new[d]
+ * q / k_new / v_new / out: [B, H, D] of `dtype` (KVQ_F16 | KVQ_BF16) with element strides
+ * (stride_b, stride_h), D contiguous; q heads Hq, k_new / v_new heads Hkv; query head h uses kv
+ * head h / (Hq/Hkv). k_store / v_store: one layer's [B, Hkv, Tcap, Dq] rows (int8, or packed INT4
+ * with the even element in the high nibble), byte strides k_st / v_st (g unused); *_scales[t] the
+ * per-token scale table of that layer. k_bits / v_bits: 8 or 4. D in {32, 64, 128, 256}.
+ * fp32 accumulation; the reference's intermediate fp16 rounding of the dequantised values is
+ * skipped, so results agree within fp16 tolerance, not bit-exactly. */
+int kvq_decode_attn(const void* q, int64_t q_stride_b, int64_t q_stride_h,
+                    const uint8_t* k_store, const kvq_strides_t* k_st, const float* k_scales, int k_bits,
+                    const uint8_t* v_store, const kvq_strides_t* v_st, const float* v_scales, int v_bits,
+                    const void* k_new, int64_t kn_stride_b, int64_t kn_stride_h,
+                    const void* v_new, int64_t vn_stride_b, int64_t vn_stride_h,
+                    void* out, int64_t out_stride_b, int64_t out_stride_h, int dtype, float sm_scale,
+                    float* workspace, int64_t workspace_floats, const kvq_attn_dims_t* dims, void* stream);
+
 /* ---- tuning knobs (benchmarks only; defaults are what ships) ----------------------------- */
 
 /* key: "dequant_variant" (0..30, -1 = shipped default), "dequant_grid" (workgroups, 0 = one chunk

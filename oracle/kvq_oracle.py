@@ -333,3 +333,39 @@ def gather_tokens(x: np.ndarray, idx) -> np.ndarray:
     if idx is None:
         return x
     return x[..., np.asarray(idx, dtype=np.int64), :]
+
+
+# ----------------------------------------------------------------------------------------------
+# N1 (second form): one decode step of attention over the quantised cache
+
+
+def decode_attention(q, k_q, k_scales_f32, k_kind, v_q, v_scales_f32, v_kind, D, sm_scale,
+                     k_new=None, v_new=None, kv_dtype: str = "f16") -> np.ndarray:
+    """What the reference computes for ONE layer and ONE new query token, in float64.
+
+    ``QuantizedKVCache.to_past_key_values`` (ops.py:345-355) dequantises every stored token to the
+    compute dtype (``get_kv`` :213-269); the model then cats the new token's exact k/v and runs
+    ``softmax(q K^T * sm_scale) V`` (HF attention under benchmarker.py:470-471).
+
+    q [B,Hq,D]; k_q / v_q [B,Hkv,T,Dq] (int8 or packed uint8); *_scales_f32 [T]; k_new / v_new
+    [B,Hkv,D] or None. Grouped-query: query head h reads kv head h // (Hq // Hkv).
+    Returns float64 [B,Hq,D] (callers compare at the compute dtype's tolerance).
+    """
+    q = np.asarray(q, dtype=np.float64)
+    B, Hq, _ = q.shape
+    kd = dequantize_tokens(k_q[None], np.asarray(k_scales_f32, F32)[None], k_kind, D, kv_dtype)[0]
+    vd = dequantize_tokens(v_q[None], np.asarray(v_scales_f32, F32)[None], v_kind, D, kv_dtype)[0]
+    kd = (bf16_bits_to_f32(kd) if kv_dtype == "bf16" else kd).astype(np.float64)
+    vd = (bf16_bits_to_f32(vd) if kv_dtype == "bf16" else vd).astype(np.float64)
+    if k_new is not None:
+        kd = np.concatenate([kd, np.asarray(k_new, np.float64)[:, :, None, :]], axis=2)
+        vd = np.concatenate([vd, np.asarray(v_new, np.float64)[:, :, None, :]], axis=2)
+    Hkv = kd.shape[1]
+    rep = Hq // Hkv
+    out = np.empty((B, Hq, D), np.float64)
+    for b in range(B):
+        for h in range(Hq):
+            s = kd[b, h // rep] @ q[b, h] * float(sm_scale)  # [T(+1)]
+            p = np.exp(s - s.max())
+            out[b, h] = (p / p.sum()) @ vd[b, h // rep]
+    return out

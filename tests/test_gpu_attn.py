@@ -1,0 +1,142 @@
+"""Scope row N1 (second form) on the MI355X: one decode step of attention straight from the
+INT8 / packed-INT4 store (kvq_decode_attn) vs the oracle's float64 restatement of the reference
+pipeline (dequantise everything -> cat the new token -> softmax(q K^T) V).
+
+Floating point, so a tolerance instead of bit equality: the kernel accumulates exact
+integer x fp16 products in fp32 and skips the reference's rounding of the dequantised values to the
+compute dtype (<= 2^-11 relative per element for fp16, 2^-8 for bf16), and the output is rounded to
+the compute dtype once. TOL below = 2 output ulps + that slack.
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kvq_oracle as O
+from tests.util import TD, to_numpy, to_torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f16": 2e-3, "bf16": 1.6e-2}
+
+
+@pytest.fixture(scope="module")
+def K():
+    assert torch.cuda.is_available()
+    from efficient_llm_inference_amd import _lib, kernels
+    _lib.load()
+    return kernels
+
+
+def _as_f32(a, dtype):
+    return O.bf16_bits_to_f32(a) if dtype == "bf16" else a.astype(np.float32)
+
+
+def _rand(shape, dtype, rng, scale=1.0):
+    x = (rng.standard_normal(shape) * scale).astype(np.float32)
+    return O.f32_to_bf16_bits(x) if dtype == "bf16" else x.astype(np.float16)
+
+
+def _run_case(K, B, Hq, Hkv, T, D, k_kind, v_kind, dtype, with_new, tcap_pad=3, q_scale=1.0, strided_q=False):
+    rng = np.random.default_rng(zlib.crc32(repr((B, Hq, Hkv, T, D, k_kind, v_kind, dtype, with_new)).encode()))
+    kv_np = [_rand((1, B, Hkv, T, D), dtype, rng), _rand((1, B, Hkv, T, D), dtype, rng)]
+    # outlier channel in K, as real keys have
+    if T:
+        k32 = _as_f32(kv_np[0], dtype)
+        k32[..., 3] *= 6.0
+        kv_np[0] = O.f32_to_bf16_bits(k32) if dtype == "bf16" else k32.astype(np.float16)
+    odt = "bf16" if dtype == "bf16" else None
+    kq, _, ks = O.quantize_tokens(kv_np[0], k_kind, dtype=odt)
+    vq, _, vs = O.quantize_tokens(kv_np[1], v_kind, dtype=odt)
+    q_np = _rand((B, Hq, D), dtype, rng, q_scale)
+    kn_np = _rand((B, Hkv, D), dtype, rng) if with_new else None
+    vn_np = _rand((B, Hkv, D), dtype, rng) if with_new else None
+    sm = 1.0 / np.sqrt(D)
+    ref = O.decode_attention(_as_f32(q_np, dtype), kq[0], ks[0], k_kind, vq[0], vs[0], v_kind, D, sm,
+                             None if kn_np is None else _as_f32(kn_np, dtype),
+                             None if vn_np is None else _as_f32(vn_np, dtype), kv_dtype=dtype)
+
+    Tcap = T + tcap_pad
+    k_store = torch.zeros(B, Hkv, Tcap, kq.shape[-1], dtype=K.QDTYPE[k_kind], device="cuda")
+    v_store = torch.zeros(B, Hkv, Tcap, vq.shape[-1], dtype=K.QDTYPE[v_kind], device="cuda")
+    k_sc = torch.full((Tcap,), float("nan"), device="cuda")
+    v_sc = torch.full((Tcap,), float("nan"), device="cuda")
+    if T:
+        k_store[:, :, :T] = to_torch(kq[0])
+        v_store[:, :, :T] = to_torch(vq[0])
+        k_sc[:T] = to_torch(ks[0])
+        v_sc[:T] = to_torch(vs[0])
+    # guard tokens past T hold garbage that must never be read into the result
+    k_store[:, :, T:] = 77 if k_kind == "int8" else 0x7F
+    v_store[:, :, T:] = 77 if v_kind == "int8" else 0x7F
+    if strided_q:  # the layout HF's fused qkv projection hands over: [B, 1, 3E] split into q | k | v
+        qkv = torch.zeros(B, 3 * Hq * D, dtype=TD[dtype], device="cuda")
+        qkv[:, :Hq * D] = to_torch(q_np, dtype).reshape(B, Hq * D)
+        q = qkv[:, :Hq * D].view(B, Hq, D)
+    else:
+        q = to_torch(q_np, dtype)
+    kn = None if kn_np is None else to_torch(kn_np, dtype)
+    vn = None if vn_np is None else to_torch(vn_np, dtype)
+    out = torch.full((B, Hq, D), float("nan"), dtype=TD[dtype], device="cuda")
+    ws = torch.empty(max(1, K.decode_attn_workspace(B, Hq, Hkv, T, D)), dtype=torch.float32, device="cuda")
+    K.decode_attn(q, k_store, k_sc, k_kind, v_store, v_sc, v_kind, T, out, ws, sm, kn, vn)
+    torch.cuda.synchronize()
+    got = _as_f32(to_numpy(out), dtype).astype(np.float64)
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref)
+    bound = TOL[dtype] * (np.abs(ref) + np.abs(ref).max())
+    assert (err <= bound).all(), (float(err.max()), float(np.abs(ref).max()))
+    return float(err.max())
+
+
+CASES = [  # B, Hq, Hkv, T, D
+    (1, 12, 12, 300, 64),    # gpt2: one query head per kv head
+    (1, 16, 16, 1024, 64),   # gpt2-medium at n_positions
+    (1, 32, 8, 1000, 128),   # Llama-3-8B grouping (4 query heads per kv head), ragged split
+    (2, 8, 4, 257, 128),     # batch 2, 2 query heads per kv head
+    (1, 8, 1, 640, 128),     # multi-query: 8 query heads on one kv head
+    (1, 6, 2, 130, 32),      # 3 per kv head (padded to 4), smallest head_dim
+    (1, 4, 4, 200, 256),     # widest head_dim
+    (3, 4, 2, 1, 64),        # a single stored token
+    (1, 32, 8, 5000, 128),   # several splits of different fill
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("kinds", [("int8", "int8"), ("int8", "int4"), ("int4", "int4"), ("int4", "int8")])
+def test_decode_attn_matches_oracle(K, case, kinds):
+    for dtype, with_new in (("f16", True), ("f16", False), ("bf16", True)):
+        _run_case(K, *case, kinds[0], kinds[1], dtype, with_new)
+
+
+def test_decode_attn_only_new_token(K):
+    # empty store: the softmax has the new token alone, out == v_new
+    _run_case(K, 2, 8, 4, 0, 64, "int8", "int4", "f16", True)
+
+
+def test_decode_attn_strided_query_and_large_logits(K):
+    _run_case(K, 1, 12, 12, 700, 64, "int8", "int4", "f16", True, strided_q=True)
+    # peaked softmax: logits of a few tens
+    _run_case(K, 1, 8, 8, 900, 128, "int8", "int8", "f16", True, q_scale=8.0)
+
+
+def test_decode_attn_rejects_bad_arguments(K):
+    from efficient_llm_inference_amd._lib import KvqError
+    q = torch.zeros(1, 4, 48, dtype=torch.float16, device="cuda")
+    ks = torch.zeros(1, 4, 8, 48, dtype=torch.int8, device="cuda")
+    sc = torch.ones(8, device="cuda")
+    ws = torch.empty(4096, device="cuda")
+    with pytest.raises(KvqError):  # head_dim 48 is not supported by the fused kernel
+        K.decode_attn(q, ks, sc, "int8", ks, sc, "int8", 8, torch.empty_like(q), ws, 1.0)
+    q = torch.zeros(1, 4, 64, dtype=torch.float32, device="cuda")
+    ks = torch.zeros(1, 4, 8, 64, dtype=torch.int8, device="cuda")
+    with pytest.raises(KvqError):  # fp32 queries are not supported
+        K.decode_attn(q, ks, sc, "int8", ks, sc, "int8", 8, torch.empty_like(q), ws, 1.0)
+    q = torch.zeros(1, 4, 64, dtype=torch.float16, device="cuda")
+    with pytest.raises(KvqError):  # T beyond the store
+        K.decode_attn(q, ks, sc, "int8", ks, sc, "int8", 9, torch.empty_like(q), ws, 1.0)
+    with pytest.raises(KvqError):  # CPU tensors never reach the kernel
+        K.decode_attn(q.cpu(), ks, sc, "int8", ks, sc, "int8", 8, torch.empty_like(q), ws, 1.0)
+    with pytest.raises(KvqError):  # workspace too small
+        K.decode_attn(q, ks, sc, "int8", ks, sc, "int8", 8, torch.empty_like(q), ws[:4], 1.0)
