@@ -46,6 +46,12 @@ DECODE_DEFAULT = ("gpt2", "quant_int8", 512, 512)  # arch, method, prompt tokens
 # BASELINE.json configs[4]: Llama-3-8B sliding_window + chunk_summary, seq 32K, batch 64 sharded
 # over 8 GPUs = 8 batch rows per GPU: per-rank KV [L=32, 2, B=8, H=8, T=32768, D=128] fp16 = 32 GiB
 EVICT = {"llama3_8b_evict_seq32k": (32, 8, 8, 32768, 128, 256, 64, 256)}  # L,B,H,T,D,window,chunk,keep_last
+# scope row N1 (second form): one decode step's attention over the quantised store, all layers
+ATTN = {  # name: (L, B, Hq, Hkv, T, D, mode)
+    "llama3_8b_decode_attn_seq16k": (32, 1, 32, 8, 16384, 128, "mixed"),
+    "llama3_8b_decode_attn_seq16k_b8": (32, 8, 32, 8, 16384, 128, "mixed"),
+    "gpt2_decode_attn_seq1k": (12, 1, 12, 12, 1024, 64, "int8"),
+}
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 BYTES_PER_ELT = {"int8": 3.0, "int4": 2.5}  # q read + fp16 write
 
@@ -57,13 +63,16 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="llama3_8b_mixed_seq16k",
                     help="one of %s, or decode:<arch>:<method>[:<prompt_tokens>:<new_tokens>] "
-                         "(e.g. decode:gpt2:quant_int8:512:512; steps = prompts per rank)" % sorted(WORKLOADS))
+                         "(e.g. decode:gpt2:quant_int8:512:512; steps = prompts per rank)" % sorted(list(WORKLOADS) + list(ATTN) + list(EVICT)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rotate-caches", type=int, default=2,
                     help="independent quantised caches visited round-robin by consecutive steps, so that no "
                          "step re-reads lines the 256 MiB Infinity Cache may still hold (1 = the decode loop's "
                          "behaviour: the same cache every step; its 256 MiB INT4 store then stays cache-resident)")
     ap.add_argument("--cpu-sample-layers", type=int, default=32)
+    ap.add_argument("--fused-attention", action="store_true",
+                    help="decode:* workloads with quant_* methods: attend straight over the quantised store "
+                         "(kvq_decode_attn) instead of the staged fp16 copy")
     return ap.parse_args()
 
 
@@ -123,6 +132,7 @@ def run_decode(args, rank, world, dev):
     n_new = int(parts[4]) if len(parts) > 4 else DECODE_DEFAULT[3]
     model, tok = load_model(arch, "cuda", torch.float16)
     bm = E.KVCacheBenchmarker(model, tok, device="cuda")
+    bm.fused_attention = bool(args.fused_attention)
     prompts = [f"<{n_prompt}>"] * (args.steps * world)
     for _ in range(args.warmup):
         bm.benchmark_method([f"<{min(n_prompt, 64)}>"], method=method, max_new_tokens=8)
@@ -138,7 +148,8 @@ def run_decode(args, rank, world, dev):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(res["elapsed_sec"] / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16 model, u8/u4 KV", "data": "synthetic",
-            "config": {"workload": args.workload, "arch": arch, "method": method, "prompt_tokens": n_prompt,
+            "config": {"workload": args.workload, "arch": arch, "method": method, "fused_attention": bool(args.fused_attention),
+                       "prompt_tokens": n_prompt,
                        "new_tokens": n_new, "weights": "random-init (offline)", "layers": cfg.n_layer,
                        "heads": cfg.n_head, "head_dim": cfg.n_embd // cfg.n_head,
                        "parallelism": f"prompt-shard x{world}, one all_reduce of counters"},
@@ -212,6 +223,89 @@ def run_evict(args, rank, world, dev):
         }), flush=True)
 
 
+def run_attn(args, rank, world, dev):
+    """One STEP = the attention of one decode step over the quantised store of every layer
+    (kvq_decode_attn per layer: split-T partial kernel + merge), new token's exact K/V included.
+    Side measurement: the same step as the staged path runs it (torch SDPA over the fp16 copy)."""
+    import efficient_llm_inference_amd as E
+    from efficient_llm_inference_amd import kernels as K
+    from efficient_llm_inference_amd import sharding
+    L, B, Hq, Hkv, T, D, mode = ATTN[args.workload]
+    kk, vk = {"int8": ("int8", "int8"), "int4": ("int4", "int4"), "mixed": ("int8", "int4")}[mode]
+    torch.manual_seed(42 + rank)
+    qc = E.QuantizedKVCache(n_layers=L, mode=mode, device="cuda", compute_dtype=torch.float16)
+    qc.reserve(T)
+    for g0 in range(0, L, 4):  # quantise 4 layers at a time: bounded fp16 scratch
+        n = min(4, L - g0)
+        qc._k.append([torch.randn(B, Hkv, T, D, device=dev, dtype=torch.float16) for _ in range(n)], g0=g0)
+        qc._v.append([torch.randn(B, Hkv, T, D, device=dev, dtype=torch.float16) for _ in range(n)], g0=g0)
+    q = torch.randn(L, B, Hq, D, device=dev, dtype=torch.float16)
+    kn = torch.randn(L, B, Hkv, D, device=dev, dtype=torch.float16)
+    vn = torch.randn(L, B, Hkv, D, device=dev, dtype=torch.float16)
+    out = torch.empty(L, B, Hq, D, device=dev, dtype=torch.float16)
+    ws = torch.empty(K.decode_attn_workspace(B, Hq, Hkv, T, D), device=dev, dtype=torch.float32)
+    sm = D ** -0.5
+    layer_bytes = B * Hkv * T * (K.packed_dim(kk, D) + K.packed_dim(vk, D)) + 8 * T  # rows + two fp32 scales per token
+    step_bytes = L * layer_bytes
+
+    def step():
+        for i in range(L):
+            K.decode_attn(q[i], qc._k.q[i], qc._k.scales[i], kk, qc._v.q[i], qc._v.scales[i], vk, T, out[i], ws, sm,
+                          kn[i], vn[i])
+
+    for _ in range(args.warmup):
+        step()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for _ in range(args.steps):
+        step()
+    ev[1].record()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    layer_ms = ev[0].elapsed_time(ev[1]) / (args.steps * L)
+    elapsed = sharding.max_over_ranks(elapsed, dev)
+
+    # the staged path's attention on the same shapes: SDPA over an fp16 copy of ONE layer
+    kf = torch.randn(B, Hkv, T + 1, D, device=dev, dtype=torch.float16)
+    vf = torch.randn(B, Hkv, T + 1, D, device=dev, dtype=torch.float16)
+    q4 = q[0].unsqueeze(2)
+    sd = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for it in range(12):
+        if it == 2:
+            sd[0].record()
+        torch.nn.functional.scaled_dot_product_attention(q4, kf, vf, scale=sm, enable_gqa=Hq != Hkv)
+    sd[1].record()
+    torch.cuda.synchronize()
+    sdpa_ms = sd[0].elapsed_time(sd[1]) / 10
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"decode attention over the quantised KV store, GB/s vs HBM roofline ({kk.upper()} K + {vk.upper()} V)",
+            "value": round(step_bytes * world / (elapsed / args.steps) / 1e9, 1), "unit": "GB/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "dtype_detail": "int8 / packed-int4 store, fp16 query, fp32 accumulate, fp16 out", "data": "synthetic",
+            "config": {"workload": args.workload, "shape_L_B_Hq_Hkv_T_D": [L, B, Hq, Hkv, T, D], "mode": mode,
+                       "step": "one decode step: kvq_decode_attn per layer (2 launches each), host launch gaps included",
+                       "bytes_per_step": int(step_bytes), "parallelism": f"batch-shard x{world}, no collective"},
+            "roofline": {"kernel": "decode_attn_partial_k + decode_attn_merge_k (per layer call)", "bound": "hbm",
+                         "achieved": round(layer_bytes / (layer_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(layer_bytes / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(layer_bytes), "avg_launch_ms": round(layer_ms, 5),
+                         "timer": "HIP events around the timed region / (steps * layers)"},
+            "staged_path_sdpa": {"what": "torch SDPA over an fp16 copy of one layer's KV (what the staged decode runs)",
+                                 "avg_ms": round(sdpa_ms, 5), "fp16_bytes": int(4 * B * Hkv * (T + 1) * D),
+                                 "speedup_of_fused": round(sdpa_ms / layer_ms, 3)},
+            "est_kv_cache_mb": round(qc.estimated_bytes() / 2**20, 3),
+            "fp16_kv_cache_mb": round(L * 4 * B * Hkv * T * D / 2**20, 3),
+        }), flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -250,6 +344,12 @@ def main():
     _lib.load()
     if args.workload.startswith("decode"):
         run_decode(args, rank, world, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if args.workload in ATTN:
+        run_attn(args, rank, world, dev)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()

@@ -37,7 +37,7 @@ from ..cache import (
     trim_kv_strided,
 )
 from ..core.memory import get_cpu_mem_mb, get_gpu_peak_mb, mb, reset_gpu_peak
-from ..quantization import QuantizedKVCache, hf_cache
+from ..quantization import QuantizedKVCache, fused_attention, hf_cache
 
 try:  # transformers is only needed to rebuild a Cache object for the model
     from transformers import DynamicCache
@@ -94,6 +94,9 @@ class KVCacheBenchmarker:
         # (quantization/hf_cache.py) instead of rebuilding a DynamicCache from a tuple every step.
         # Same tokens either way; False restores the reference's loop shape literally.
         self.inplace_decode = True
+        # opt-in: attend straight over the INT8 / INT4 store (quantization/fused_attention.py): no
+        # fp16 copy of the cache exists, the model's attention function is kvq_decode_attn
+        self.fused_attention = False
 
     # ------------------------------------------------------------------ shared loop machinery
 
@@ -187,6 +190,8 @@ class KVCacheBenchmarker:
         """Decode with the KV cache stored quantised (int8 / int4 / mixed); returns
         ``(text, n_new, estimated cache MB)`` (reference benchmarker.py:422-491)."""
         input_ids = self._encode(prompt, truncate=False)
+        if self.fused_attention:
+            return self._generate_fused(input_ids, max_new_tokens, mode)
         out = self.model(input_ids=input_ids, use_cache=True)
         logits = out.logits[:, -1, :]
         past_kv_tuple = to_legacy_tuple(out.past_key_values)
@@ -220,6 +225,26 @@ class KVCacheBenchmarker:
 
         text, n_new = self._finish(generated, input_ids)
         return text, n_new, mb(qcache.estimated_bytes())
+
+    def _generate_fused(self, input_ids: torch.Tensor, max_new_tokens: int, mode: str) -> Tuple[str, int, float]:
+        """quant_* decode with the model attending over the quantised store itself: the prompt forward
+        quantises its K/V layer by layer, every later forward runs kvq_decode_attn per layer."""
+        cfg = self.model.config
+        n_layers = getattr(cfg, "num_hidden_layers", None) or cfg.n_layer
+        dtype = next(self.model.parameters()).dtype
+        fc = fused_attention.FusedQuantizedCache(n_layers, mode=mode, device=self.device, compute_dtype=dtype,
+                                                 reserve=input_ids.shape[-1] + max_new_tokens)
+        generated = input_ids.clone()
+        with fused_attention.fused_attention(self.model, fc) as cache:
+            out = self.model(input_ids=input_ids, use_cache=True, past_key_values=cache)
+            logits = out.logits[:, -1, :]
+            for _ in range(max_new_tokens):
+                next_token = torch.argmax(logits, dim=-1, keepdim=True)
+                generated = torch.cat([generated, next_token], dim=-1)
+                out = self.model(input_ids=next_token, use_cache=True, past_key_values=cache)
+                logits = out.logits[:, -1, :]
+        text, n_new = self._finish(generated, input_ids)
+        return text, n_new, mb(fc.estimated_bytes())
 
     @torch.no_grad()
     def generate_with_chunked_cache(self, prompt: str, max_new_tokens: int = 32, chunk_size: int = 64,

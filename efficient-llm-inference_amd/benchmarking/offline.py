@@ -16,6 +16,7 @@ ARCH = {  # architectural constants of the named models (nothing is downloaded)
     "gpt2": dict(n_layer=12, n_head=12, n_embd=768, n_positions=1024, vocab_size=50257),
     "gpt2-medium": dict(n_layer=24, n_head=16, n_embd=1024, n_positions=1024, vocab_size=50257),
     "gpt2-tiny": dict(n_layer=2, n_head=4, n_embd=64, n_positions=256, vocab_size=260),
+    "gpt2-mini": dict(n_layer=3, n_head=4, n_embd=256, n_positions=512, vocab_size=260),  # head_dim 64
 }
 
 

@@ -42,7 +42,8 @@ struct AttnArgs {
   int64_t vn_sb, vn_sh;
   void* out;
   int64_t o_sb, o_sh;
-  float* ws;
+  float* ws;        // [B*Hq*nsplit][2] (m, l), then at acc_off [B*Hq*nsplit][D]
+  int64_t acc_off;  // floats
   float sm_scale;
   uint32_t B, Hq, Hkv, T, D, TS, nsplit, nq;
   int32_t lpt_shift;  // log2(D / 16): lanes per token
@@ -183,21 +184,50 @@ __device__ inline float wave_fsum(float v) {
   return v;
 }
 
+// Workgroup timeline (one round trip to HBM on the critical path when TS == TL * kAttnUnroll):
+// issue the first K tile, the first V tile, the scales and the query at once; scores while V is
+// still in flight; softmax in LDS; weighted V sum; token lanes -> one row per wave -> workspace.
 template <int KBITS, int VBITS, int NQ>
 __global__ __launch_bounds__(kAttnBlock) void decode_attn_partial_k(const AttnArgs a) {
-  __shared__ float s_p[NQ][kAttnMaxTS];        // scores, then p[t] * sv[t]
+  __shared__ float s_p[NQ][kAttnMaxTS];  // raw scores, then p[t] * sv[t]
+  __shared__ float s_ks[kAttnMaxTS];     // sk[t] * sm_scale
+  __shared__ float s_vs[kAttnMaxTS];     // sv[t]
   __shared__ float s_acc[kAttnBlock / kWave][NQ][256];
-  __shared__ float s_w[NQ];                    // sum_t p[t] * sv[t]  (bias fold)
+  __shared__ float s_w[NQ];              // sum_t p[t] * sv[t]  (bias fold)
   const uint32_t tid = threadIdx.x;
   const uint32_t split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
   const uint32_t t0 = split * a.TS;
   const uint32_t nt = a.T - t0 < a.TS ? a.T - t0 : a.TS;
   const uint32_t lpt = 1u << a.lpt_shift;
-  const uint32_t ld = tid & (lpt - 1u);        // which 16-element slice of D
-  const uint32_t tl = tid >> a.lpt_shift;      // token lane
+  const uint32_t ld = tid & (lpt - 1u);    // which 16-element slice of D
+  const uint32_t tl = tid >> a.lpt_shift;  // token lane
   const uint32_t TL = kAttnBlock >> a.lpt_shift;
+  const uint32_t step = TL * kAttnUnroll;  // tokens per loop iteration
 
-  // ---- phase A: scores ------------------------------------------------------------------
+  const uint8_t* kb = a.k + (int64_t)b * a.k_sb + (int64_t)hk * a.k_sh + (int64_t)t0 * a.k_st +
+                      (int64_t)ld * Raw16<KBITS>::kBytes;
+  const uint8_t* vb = a.v + (int64_t)b * a.v_sb + (int64_t)hk * a.v_sh + (int64_t)t0 * a.v_st +
+                      (int64_t)ld * Raw16<VBITS>::kBytes;
+  Raw16<KBITS> kraw[kAttnUnroll];
+  Raw16<VBITS> vraw[kAttnUnroll];
+#pragma unroll
+  for (int u = 0; u < kAttnUnroll; ++u) {
+    const uint32_t i = u * TL + tl;
+    if (i < nt) kraw[u].load(kb + (int64_t)i * a.k_st);
+    else kraw[u].zero();
+  }
+#pragma unroll
+  for (int u = 0; u < kAttnUnroll; ++u) {
+    const uint32_t i = u * TL + tl;
+    if (i < nt) vraw[u].load(vb + (int64_t)i * a.v_st);
+    else vraw[u].zero();
+  }
+  for (uint32_t i = tid; i < nt; i += kAttnBlock) {
+    s_ks[i] = a.k_scale[t0 + i] * a.sm_scale;
+    s_vs[i] = a.v_scale[t0 + i];
+  }
+
+  // ---- phase A: raw scores q . k_int ------------------------------------------------------
   {
     f16x2 qv[NQ][8];
 #pragma unroll
@@ -211,30 +241,34 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_partial_k(const AttnAr
         for (int j = 0; j < 8; ++j) qv[h][j] = f16x2{(f16)0.0f, (f16)0.0f};
       }
     }
-    const uint8_t* kb = a.k + (int64_t)b * a.k_sb + (int64_t)hk * a.k_sh + (int64_t)t0 * a.k_st +
-                        (int64_t)ld * Raw16<KBITS>::kBytes;
-    for (uint32_t base = 0; base < nt; base += TL * kAttnUnroll) {  // uniform trip count
-      Raw16<KBITS> raw[kAttnUnroll];
+    for (uint32_t base = 0; base < nt; base += step) {  // uniform trip count
+      const bool more = base + step < nt;
+      Raw16<KBITS> nxt[kAttnUnroll];
+      if (more) {  // next tile in flight while this one is reduced
 #pragma unroll
-      for (int u = 0; u < kAttnUnroll; ++u) {
-        const uint32_t i = base + u * TL + tl;
-        if (i < nt) raw[u].load(kb + (int64_t)i * a.k_st);
-        else raw[u].zero();
+        for (int u = 0; u < kAttnUnroll; ++u) {
+          const uint32_t i = base + step + u * TL + tl;
+          if (i < nt) nxt[u].load(kb + (int64_t)i * a.k_st);
+          else nxt[u].zero();
+        }
       }
 #pragma unroll
       for (int u = 0; u < kAttnUnroll; ++u) {
         const uint32_t i = base + u * TL + tl;
         f16x2 kp[8];
-        raw[u].to_h2(kp);
-        const float sc = i < nt ? a.k_scale[t0 + i] * a.sm_scale : 0.0f;
+        kraw[u].to_h2(kp);
 #pragma unroll
         for (int h = 0; h < NQ; ++h) {
           float s = 0.0f;
 #pragma unroll
           for (int j = 0; j < 8; ++j) s = __builtin_amdgcn_fdot2(kp[j], qv[h][j], s, false);
           s = group_fadd(s, a.lpt_shift);
-          if (ld == 0u && i < nt) s_p[h][i] = s * sc;
+          if (ld == 0u && i < nt) s_p[h][i] = s;
         }
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < kAttnUnroll; ++u) kraw[u] = nxt[u];
       }
     }
   }
@@ -245,12 +279,16 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_partial_k(const AttnAr
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     for (uint32_t h = wave; h < a.nq; h += kAttnBlock / kWave) {
       float m = -INFINITY;
-      for (uint32_t i = lane; i < nt; i += kWave) m = fmaxf(m, s_p[h][i]);
+      for (uint32_t i = lane; i < nt; i += kWave) {
+        const float sc = s_p[h][i] * s_ks[i];
+        s_p[h][i] = sc;
+        m = fmaxf(m, sc);
+      }
       m = wave_fmax(m);
       float l = 0.0f, wsum = 0.0f;
       for (uint32_t i = lane; i < nt; i += kWave) {
         const float p = __expf(s_p[h][i] - m);
-        const float pv = p * a.v_scale[t0 + i];
+        const float pv = p * s_vs[i];
         l += p;
         wsum += pv;
         s_p[h][i] = pv;
@@ -259,7 +297,7 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_partial_k(const AttnAr
       wsum = wave_fsum(wsum);
       if (lane == 0u) {
         s_w[h] = wsum;
-        float* o = a.ws + (((int64_t)b * a.Hq + hk * a.nq + h) * a.nsplit + split) * (a.D + 2);
+        float* o = a.ws + (((int64_t)b * a.Hq + hk * a.nq + h) * a.nsplit + split) * 2;
         o[0] = m;
         o[1] = l;
       }
@@ -273,42 +311,59 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_partial_k(const AttnAr
   for (int h = 0; h < NQ; ++h)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[h][j] = 0.0f;
-  {
-    const uint8_t* vb = a.v + (int64_t)b * a.v_sb + (int64_t)hk * a.v_sh + (int64_t)t0 * a.v_st +
-                        (int64_t)ld * Raw16<VBITS>::kBytes;
-    for (uint32_t base = 0; base < nt; base += TL * kAttnUnroll) {
-      Raw16<VBITS> raw[kAttnUnroll];
+  for (uint32_t base = 0; base < nt; base += step) {
+    const bool more = base + step < nt;
+    Raw16<VBITS> nxt[kAttnUnroll];
+    if (more) {
 #pragma unroll
       for (int u = 0; u < kAttnUnroll; ++u) {
-        const uint32_t i = base + u * TL + tl;
-        if (i < nt) raw[u].load(vb + (int64_t)i * a.v_st);
-        else raw[u].zero();
+        const uint32_t i = base + step + u * TL + tl;
+        if (i < nt) nxt[u].load(vb + (int64_t)i * a.v_st);
+        else nxt[u].zero();
       }
+    }
 #pragma unroll
-      for (int u = 0; u < kAttnUnroll; ++u) {
-        const uint32_t i = base + u * TL + tl;
-        if (i < nt) {
-          float uf[16];
-          raw[u].to_f32_biased(uf);
+    for (int u = 0; u < kAttnUnroll; ++u) {
+      const uint32_t i = base + u * TL + tl;
+      if (i < nt) {
+        float uf[16];
+        vraw[u].to_f32_biased(uf);
 #pragma unroll
-          for (int h = 0; h < NQ; ++h) {
-            const float p = s_p[h][i];
+        for (int h = 0; h < NQ; ++h) {
+          const float p = s_p[h][i];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[h][j] = fmaf(uf[j], p, acc[h][j]);
-          }
+          for (int j = 0; j < 16; ++j) acc[h][j] = fmaf(uf[j], p, acc[h][j]);
         }
       }
     }
-  }
-  // token lanes of one wave -> lane tl == 0 of the wave, then the 4 waves through LDS
+    if (more) {
 #pragma unroll
-  for (int h = 0; h < NQ; ++h)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      float v = acc[h][j];
-      for (uint32_t s = lpt; s < (uint32_t)kWave; s <<= 1) v += __shfl_xor(v, (int)s);
-      acc[h][j] = v;
+      for (int u = 0; u < kAttnUnroll; ++u) vraw[u] = nxt[u];
     }
+  }
+  // token lanes of one wave -> every lane holds the wave's sum, then the 4 waves through LDS.
+  // Inside a 16-lane row: DPP rotations (one VALU op each); across rows: two lane exchanges per
+  // value, issued back to back (the uniform branches stay OUTSIDE the value loops so that they pipeline).
+#define KVQ_ROW_ROR(N)                                                                                     \
+  _Pragma("unroll") for (int h = 0; h < NQ; ++h) _Pragma("unroll") for (int j = 0; j < 16; ++j)           \
+      acc[h][j] += __uint_as_float(dpp_u32_attn<0x120 + N>(__float_as_uint(acc[h][j])));
+  if (lpt <= 8u) { KVQ_ROW_ROR(8) }
+  if (lpt <= 4u) { KVQ_ROW_ROR(4) }
+  if (lpt <= 2u) { KVQ_ROW_ROR(2) }
+  if (lpt <= 1u) { KVQ_ROW_ROR(1) }
+#undef KVQ_ROW_ROR
+#pragma unroll
+  for (int h = 0; h < NQ; ++h) {
+    float t[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t[j] = __shfl_xor(acc[h][j], 16);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[h][j] += t[j];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t[j] = __shfl_xor(acc[h][j], 32);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[h][j] += t[j];
+  }
   {
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     if (lane < lpt) {
@@ -323,70 +378,392 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_partial_k(const AttnAr
     const uint32_t h = idx / a.D, d = idx - h * a.D;
     const float v = s_acc[0][h][d] + s_acc[1][h][d] + s_acc[2][h][d] + s_acc[3][h][d] -
                     Raw16<VBITS>::kBias * s_w[h];
-    a.ws[(((int64_t)b * a.Hq + hk * a.nq + h) * a.nsplit + split) * (a.D + 2) + 2 + d] = v;
+    a.ws[a.acc_off + (((int64_t)b * a.Hq + hk * a.nq + h) * a.nsplit + split) * a.D + d] = v;
   }
 }
 
-// One workgroup per (query head, batch row): merge the splits and the exact new token.
+// ---------------------------------------------------------------------------- MFMA variant
+// Grouped-query heads (3..16 query heads per kv head, head_dim 128): the per-element VALU cost of
+// the kernel above grows with the group size (one dot2 / fma per element and head) and it ends up
+// VALU-bound (llama 4:1 grouping: 2.1 TB/s at batch 8). Here both products run on the matrix
+// cores as 16x16x32 f16 MFMAs with the heads padded to 16 columns; the VALU only converts
+// int8 / nibbles to f16 (exactly) and transposes V bytes in registers.
+//   ONE WAVE per workgroup, TC tokens, no barriers between phases.
+//   S = K Q^T : A = K tile (row = token x, k = 8 of the lane group's d), B = Q^T (col = head x),
+//               C: lane (x, g) holds head x, tokens 16 i + 4 g + r  (i = tile, r = 0..3)
+//   O = P V   : A = P, taken from the lane's OWN score registers of tiles 2s, 2s+1 (the k order
+//               of a 32-token step is defined as tokens 32 s + 4 g + j, 32 s + 16 + 4 g + (j-4), so
+//               no lane movement); B = V with col x <-> d = 8 x + n for MFMA n = 0..7, so the lane
+//               reads 8 contiguous bytes (4 for INT4) of 8 token rows and transposes them 8x8 in
+//               registers; C: lane (x, g) holds heads 4 g + r of d = 8 x + n.
+// P is scaled by sv[t] / max sv before the f16 pack (range), the output by max sv afterwards.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline f16x8 pack_h8(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  u32x4 w = {a, b, c, d};
+  f16x8 h;
+  __builtin_memcpy(&h, &w, 16);
+  return h;
+}
+// bytes (u0..u3) of x, each meaning value u - BIAS -> two f16 pairs, exact
+template <int BIAS>
+__device__ inline void bytes_to_h4(uint32_t x, uint32_t& lo, uint32_t& hi) {
+  const f16x2 bias = {(f16)(1024.0f + BIAS), (f16)(1024.0f + BIAS)};
+  lo = h2_bits(bits_h2(__builtin_amdgcn_perm(0x64646464u, x, 0x04010400u)) - bias);
+  hi = h2_bits(bits_h2(__builtin_amdgcn_perm(0x64646464u, x, 0x04030402u)) - bias);
+}
+// 4x4 byte transpose: rows a0..a3 -> columns c0..c3 (c_n = byte n of every row)
+__device__ inline void transpose4x4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t (&c)[4]) {
+  const uint32_t t0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u);
+  const uint32_t t1 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
+  const uint32_t t2 = __builtin_amdgcn_perm(a3, a2, 0x05010400u);
+  const uint32_t t3 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+  c[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+  c[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+  c[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+  c[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+}
+
+template <int KBITS, int VBITS, int TC>
+__global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnArgs a) {
+  constexpr int NT = TC / 16;  // 16-token score tiles
+  constexpr int NS = TC / 32;  // 32-token P V steps
+  __shared__ __attribute__((aligned(16))) float s_ks[TC];
+  __shared__ __attribute__((aligned(16))) float s_vs[TC];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t x = lane & 15u, g = lane >> 4;
+  const uint32_t split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  const uint32_t t0 = split * TC;
+  const uint32_t nt = a.T - t0 < (uint32_t)TC ? a.T - t0 : (uint32_t)TC;
+
+  for (uint32_t i = lane; i < (uint32_t)TC; i += kWave) {
+    s_ks[i] = i < nt ? a.k_scale[t0 + i] * a.sm_scale : 0.0f;
+    s_vs[i] = i < nt ? a.v_scale[t0 + i] : 0.0f;
+  }
+
+  // ---- Q^T operands: head x, the 8 d's of this lane group per k-step (zeros for padded heads) ----
+  f16x8 qb[4];
+  {
+    uint32_t w[16];
+    if (x < a.nq) {
+      const char* qp = reinterpret_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)(hk * a.nq + x) * a.q_sh) * 2;
+      if constexpr (KBITS == 8) {  // k-step s: d = 64 (s >> 1) + 16 g + 8 (s & 1) + j
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const u32x4 lo = *reinterpret_cast<const u32x4*>(qp + (64 * c + 16 * g) * 2);
+          const u32x4 hi = *reinterpret_cast<const u32x4*>(qp + (64 * c + 16 * g + 8) * 2);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            w[8 * c + j] = lo[j];
+            w[8 * c + 4 + j] = hi[j];
+          }
+        }
+      } else {  // k-step s: d = 32 g + 8 s + (0,2,4,6,1,3,5,7)[j]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(qp + (32 * g + 8 * c) * 2);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[4 * c + j] = v[j];
+        }
+      }
+      if (a.dtype == KVQ_BF16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const f16x2 h = {(f16)__uint_as_float(w[j] << 16), (f16)__uint_as_float(w[j] & 0xFFFF0000u)};
+          w[j] = h2_bits(h);
+        }
+      }
+      if constexpr (KBITS == 4) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t w0 = w[4 * c], w1 = w[4 * c + 1], w2 = w[4 * c + 2], w3 = w[4 * c + 3];
+          w[4 * c + 0] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);  // (q0, q2)
+          w[4 * c + 1] = __builtin_amdgcn_perm(w3, w2, 0x05040100u);  // (q4, q6)
+          w[4 * c + 2] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);  // (q1, q3)
+          w[4 * c + 3] = __builtin_amdgcn_perm(w3, w2, 0x07060302u);  // (q5, q7)
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) w[j] = 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qb[c] = pack_h8(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
+  }
+
+  // ---- S = K Q^T: tile i, token row x -----------------------------------------------------------
+  f32x4 sc[NT];
+  {
+    const uint8_t* kb = a.k + (int64_t)b * a.k_sb + (int64_t)hk * a.k_sh + (int64_t)t0 * a.k_st;
+    constexpr int NL = KBITS == 8 ? 2 : 1;  // 16-byte loads per token row and lane
+    u32x4 raw[NT][NL];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const uint32_t tok = 16 * i + x;
+#pragma unroll
+      for (int c = 0; c < NL; ++c) {
+        if (tok < nt)
+          raw[i][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (int64_t)tok * a.k_st + 64 * c + 16 * g));
+        else
+          raw[i][c] = KBITS == 8 ? u32x4{0u, 0u, 0u, 0u} : u32x4{0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      f32x4 c4 = {0.0f, 0.0f, 0.0f, 0.0f};
+      if constexpr (KBITS == 8) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          uint32_t h[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bytes_to_h4<128>(raw[i][c][j] ^ 0x80808080u, h[2 * j], h[2 * j + 1]);
+          c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack_h8(h[0], h[1], h[2], h[3]), qb[2 * c], c4, 0, 0, 0);
+          c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack_h8(h[4], h[5], h[6], h[7]), qb[2 * c + 1], c4, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // one 4-byte word = 8 elements = one k-step
+          uint32_t h[4];
+          bytes_to_h4<8>((raw[i][0][j] >> 4) & 0x0F0F0F0Fu, h[0], h[1]);  // (e0,e2) (e4,e6)
+          bytes_to_h4<8>(raw[i][0][j] & 0x0F0F0F0Fu, h[2], h[3]);         // (e1,e3) (e5,e7)
+          c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack_h8(h[0], h[1], h[2], h[3]), qb[j], c4, 0, 0, 0);
+        }
+      }
+      sc[i] = c4;
+    }
+  }
+  __syncthreads();  // one wave: publishes s_ks / s_vs
+
+  // ---- softmax over this split for head x; P scaled by sv / max sv --------------------------------
+  float m = -INFINITY, svmax = 0.0f;
+  f32x4 sv[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const f32x4 ks = *reinterpret_cast<const f32x4*>(&s_ks[16 * i + 4 * g]);
+    sv[i] = *reinterpret_cast<const f32x4*>(&s_vs[16 * i + 4 * g]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = (uint32_t)(16 * i + 4 * g + r) < nt;
+      sc[i][r] = ok ? sc[i][r] * ks[r] : -INFINITY;
+      m = fmaxf(m, sc[i][r]);
+      svmax = fmaxf(svmax, sv[i][r]);
+    }
+  }
+  m = fmaxf(m, __shfl_xor(m, 16));
+  m = fmaxf(m, __shfl_xor(m, 32));
+  svmax = fmaxf(svmax, __shfl_xor(svmax, 16));
+  svmax = fmaxf(svmax, __shfl_xor(svmax, 32));
+  const float svn = svmax > 0.0f ? 1.0f / svmax : 0.0f;
+  float l = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = __expf(sc[i][r] - m);  // tokens past nt: exp(-inf) = 0
+      l += p;
+      sc[i][r] = p * (sv[i][r] * svn);
+    }
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+
+  // ---- O = P V --------------------------------------------------------------------------------------
+  f32x4 acc[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) acc[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  {
+    const uint8_t* vb = a.v + (int64_t)b * a.v_sb + (int64_t)hk * a.v_sh + (int64_t)t0 * a.v_st;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      // the lane's 8 token rows of this step, 8 elements each
+      uint32_t lo[8], hi[8];  // INT8: bytes d0..d3 / d4..d7; INT4: elements 0,2,4,6 / 1,3,5,7
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t tok = 32 * s + 16 * (j >> 2) + 4 * g + (j & 3);
+        if constexpr (VBITS == 8) {
+          u32x2 w = {0x80808080u, 0x80808080u};  // value 0 after the sign flip below
+          if (tok < nt) {
+            w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(vb + (int64_t)tok * a.v_st + 8 * x));
+            w ^= u32x2{0x80808080u, 0x80808080u};
+          }
+          lo[j] = w[0];
+          hi[j] = w[1];
+        } else {
+          uint32_t w = 0x88888888u;
+          if (tok < nt) w = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(vb + (int64_t)tok * a.v_st + 4 * x));
+          lo[j] = (w >> 4) & 0x0F0F0F0Fu;
+          hi[j] = w & 0x0F0F0F0Fu;
+        }
+      }
+      const f16x8 pa = pack_h8(Elem<KVQ_F16>::pack2(sc[2 * s][0], sc[2 * s][1]), Elem<KVQ_F16>::pack2(sc[2 * s][2], sc[2 * s][3]),
+                               Elem<KVQ_F16>::pack2(sc[2 * s + 1][0], sc[2 * s + 1][1]),
+                               Elem<KVQ_F16>::pack2(sc[2 * s + 1][2], sc[2 * s + 1][3]));
+      uint32_t ca[4], cb[4];
+      constexpr int BIAS = VBITS == 8 ? 128 : 8;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (half == 0) {
+          transpose4x4(lo[0], lo[1], lo[2], lo[3], ca);  // tokens j = 0..3
+          transpose4x4(lo[4], lo[5], lo[6], lo[7], cb);  // tokens j = 4..7
+        } else {
+          transpose4x4(hi[0], hi[1], hi[2], hi[3], ca);
+          transpose4x4(hi[4], hi[5], hi[6], hi[7], cb);
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          uint32_t h[4];
+          bytes_to_h4<BIAS>(ca[n], h[0], h[1]);
+          bytes_to_h4<BIAS>(cb[n], h[2], h[3]);
+          acc[4 * half + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, pack_h8(h[0], h[1], h[2], h[3]), acc[4 * half + n], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- workspace: (m, l) per head, acc[heads][D] --------------------------------------------------
+  if (g == 0u && x < a.nq) {
+    float* o = a.ws + (((int64_t)b * a.Hq + hk * a.nq + x) * a.nsplit + split) * 2;
+    o[0] = m;
+    o[1] = l;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t h = 4 * g + r;
+    if (h < a.nq) {
+      // column index c of the MFMA set: INT8 d = 8x + c; INT4 c < 4 -> element 2c, else 2(c-4)+1
+      float o8[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int e = VBITS == 8 ? c : (c < 4 ? 2 * c : 2 * (c - 4) + 1);
+        o8[e] = acc[c][r] * svmax;
+      }
+      float* dst = a.ws + a.acc_off + (((int64_t)b * a.Hq + hk * a.nq + h) * a.nsplit + split) * a.D + 8 * x;
+      *reinterpret_cast<f32x4*>(dst) = f32x4{o8[0], o8[1], o8[2], o8[3]};
+      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{o8[4], o8[5], o8[6], o8[7]};
+    }
+  }
+}
+
+constexpr int kAttnMfmaTC = 128;
+
+constexpr int kAttnMaxSplit = 1024;
+
+// One workgroup per (query head, batch row): log-sum-exp merge of the splits and of the exact new
+// token. Split weights are computed once (one split per thread) and kept in LDS; the weighted sum
+// runs 256 / D split groups wide with independent loads.
 __global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_k(const AttnArgs a) {
   __shared__ float s_red[kAttnBlock / kWave];
-  __shared__ float s_new;
+  __shared__ float s_wt[kAttnMaxSplit];
+  __shared__ __attribute__((aligned(16))) float s_out[kAttnBlock * 4];
   const uint32_t tid = threadIdx.x;
   const uint32_t hq = blockIdx.x, b = blockIdx.y;
   const uint32_t hk = hq / a.nq;
   const bool has_new = a.kn != nullptr;
+  const uint32_t wave = tid >> 6, lane = tid & 63u;
+  auto block_reduce = [&](float v, bool is_max) -> float {
+    v = is_max ? wave_fmax(v) : wave_fsum(v);
+    __syncthreads();  // s_red free again
+    if (lane == 0u) s_red[wave] = v;
+    __syncthreads();
+    return is_max ? fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])) : (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  };
   float s_tok = -INFINITY;
   if (has_new) {
     float part = 0.0f;
     for (uint32_t d = tid; d < a.D; d += kAttnBlock)
       part += load_elem(a.q, (int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + d, a.dtype) *
               load_elem(a.kn, (int64_t)b * a.kn_sb + (int64_t)hk * a.kn_sh + d, a.dtype);
-    part = wave_fsum(part);
-    if ((tid & 63u) == 0u) s_red[tid >> 6] = part;
-    __syncthreads();
-    if (tid == 0u) s_new = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) * a.sm_scale;
-    __syncthreads();
-    s_tok = s_new;
+    s_tok = block_reduce(part, false) * a.sm_scale;
   }
-  const float* base = a.ws + ((int64_t)b * a.Hq + hq) * a.nsplit * (a.D + 2);
-  float M = s_tok;
-  for (uint32_t s = 0; s < a.nsplit; ++s) M = fmaxf(M, base[(int64_t)s * (a.D + 2)]);
-  float L = has_new ? __expf(s_tok - M) : 0.0f;
-  for (uint32_t s = 0; s < a.nsplit; ++s) {
-    const float* p = base + (int64_t)s * (a.D + 2);
-    L += p[1] * __expf(p[0] - M);
+  const float* ml = a.ws + ((int64_t)b * a.Hq + hq) * a.nsplit * 2;
+  const float* accb = a.ws + a.acc_off + ((int64_t)b * a.Hq + hq) * a.nsplit * a.D;
+  // this thread's splits: tid, tid + 256, ... (nsplit <= kAttnMaxSplit: at most 4)
+  float mloc[kAttnMaxSplit / kAttnBlock], lloc[kAttnMaxSplit / kAttnBlock];
+  float m_max = s_tok;
+#pragma unroll
+  for (int r = 0; r < kAttnMaxSplit / kAttnBlock; ++r) {
+    const uint32_t s = r * kAttnBlock + tid;
+    mloc[r] = s < a.nsplit ? ml[2 * s] : -INFINITY;
+    lloc[r] = s < a.nsplit ? ml[2 * s + 1] : 0.0f;
+    m_max = fmaxf(m_max, mloc[r]);
   }
-  const float inv = 1.0f / L;
-  for (uint32_t d = tid; d < a.D; d += kAttnBlock) {
-    float o = has_new ? __expf(s_tok - M) * load_elem(a.vn, (int64_t)b * a.vn_sb + (int64_t)hk * a.vn_sh + d, a.dtype)
-                      : 0.0f;
-    for (uint32_t s = 0; s < a.nsplit; ++s) {
-      const float* p = base + (int64_t)s * (a.D + 2);
-      o = fmaf(__expf(p[0] - M), p[2 + d], o);
+  const float M = block_reduce(m_max, true);
+  float lsum = 0.0f;
+#pragma unroll
+  for (int r = 0; r < kAttnMaxSplit / kAttnBlock; ++r) {
+    const uint32_t s = r * kAttnBlock + tid;
+    if (s < a.nsplit) {
+      const float w = __expf(mloc[r] - M);
+      s_wt[s] = w;
+      lsum += lloc[r] * w;
     }
-    o *= inv;
-    const int64_t oi = (int64_t)b * a.o_sb + (int64_t)hq * a.o_sh + d;
-    if (a.dtype == KVQ_F16) reinterpret_cast<f16*>(a.out)[oi] = (f16)o;
-    else reinterpret_cast<__bf16*>(a.out)[oi] = (__bf16)o;
+  }
+  const float w_new = has_new ? __expf(s_tok - M) : 0.0f;
+  const float L = block_reduce(lsum, false) + w_new;  // the barriers inside also publish s_wt
+  const float inv = 1.0f / L;
+  // weighted sum, 16 bytes per lane: thread = (split group g, 4 elements at d4); 1024 / D groups
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t dv = a.D >> 2;
+  const uint32_t groups = kAttnBlock / dv;  // 32, 16, 8 or 4
+  const uint32_t g = tid / dv, d4 = tid - g * dv;
+  f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(accb) + d4;
+    uint32_t s = g;
+    for (; s + 3u * groups < a.nsplit; s += 4u * groups) {  // 4 independent loads in flight
+      const f32x4 x0 = src[(int64_t)s * dv];
+      const f32x4 x1 = src[(int64_t)(s + groups) * dv];
+      const f32x4 x2 = src[(int64_t)(s + 2u * groups) * dv];
+      const f32x4 x3 = src[(int64_t)(s + 3u * groups) * dv];
+      o += x0 * s_wt[s] + x1 * s_wt[s + groups] + x2 * s_wt[s + 2u * groups] + x3 * s_wt[s + 3u * groups];
+    }
+    for (; s < a.nsplit; s += groups) o += src[(int64_t)s * dv] * s_wt[s];
+  }
+  *reinterpret_cast<f32x4*>(&s_out[tid * 4]) = o;  // [g][d]
+  __syncthreads();
+  if (tid < a.D) {
+    float t = 0.0f;
+    for (uint32_t k = 0; k < groups; ++k) t += s_out[k * a.D + tid];
+    if (has_new) t = fmaf(w_new, load_elem(a.vn, (int64_t)b * a.vn_sb + (int64_t)hk * a.vn_sh + tid, a.dtype), t);
+    t *= inv;
+    const int64_t oi = (int64_t)b * a.o_sb + (int64_t)hq * a.o_sh + tid;
+    if (a.dtype == KVQ_F16) reinterpret_cast<f16*>(a.out)[oi] = (f16)t;
+    else reinterpret_cast<__bf16*>(a.out)[oi] = (__bf16)t;
   }
 }
 
-static void plan(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit) {
-  // >= 2 workgroups per CU when the context allows it; TS a multiple of 128 (the widest token-lane
-  // stride) so that every split but the last is full
-  const int64_t want = 512;
+// tokens per workgroup: one loop iteration (D/16 lanes per token, kAttnUnroll tokens per lane) while
+// the grid stays below ~4096 workgroups, whole multiples of it beyond; never more than
+// kAttnMaxSplit splits
+static bool use_mfma(const kvq_attn_dims_t* d) {
+  const int64_t nq = d->Hkv > 0 ? d->Hq / d->Hkv : 0;
+  return d->D == 128 && nq >= 3 && nq <= 16 && !tunables().attn_force_valu;
+}
+static bool plan(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit) {
+  if (use_mfma(d)) {  // one wave per split of kAttnMfmaTC tokens
+    *ts = kAttnMfmaTC;
+    *nsplit = (uint32_t)((d->T + kAttnMfmaTC - 1) / kAttnMfmaTC);
+    return *nsplit <= (uint32_t)kAttnMaxSplit;
+  }
+  const int64_t step = (int64_t)(kAttnBlock / (d->D / 16)) * kAttnUnroll;
   const int64_t bh = d->B * d->Hkv > 0 ? d->B * d->Hkv : 1;
-  int64_t per = (d->T * bh + want - 1) / want;
-  per = (per + 127) / 128 * 128;
-  if (per < 128) per = 128;
-  if (per > kAttnMaxTS) per = kAttnMaxTS;
+  int64_t m = (d->T * bh + step * 4096 - 1) / (step * 4096);
+  if (m < 1) m = 1;
+  int64_t per = m * step;
+  if (per > kAttnMaxTS) per = kAttnMaxTS / step * step;
+  if ((d->T + per - 1) / per > kAttnMaxSplit) per = kAttnMaxTS / step * step;
   *ts = (uint32_t)per;
   *nsplit = (uint32_t)((d->T + per - 1) / per);
+  return *nsplit <= (uint32_t)kAttnMaxSplit;
 }
 
 template <int KBITS, int VBITS>
 static void launch_partial(const AttnArgs& a, hipStream_t st) {
   const dim3 grid(a.nsplit, a.Hkv, a.B);
+  if (a.TS == (uint32_t)kAttnMfmaTC && a.D == 128 && a.nq >= 3 && !tunables().attn_force_valu) {
+    hipLaunchKernelGGL((decode_attn_partial_mfma_k<KBITS, VBITS, kAttnMfmaTC>), grid, dim3(kWave), 0, st, a);
+    return;
+  }
   if (a.nq == 1) hipLaunchKernelGGL((decode_attn_partial_k<KBITS, VBITS, 1>), grid, dim3(kAttnBlock), 0, st, a);
   else if (a.nq == 2) hipLaunchKernelGGL((decode_attn_partial_k<KBITS, VBITS, 2>), grid, dim3(kAttnBlock), 0, st, a);
   else if (a.nq <= 4) hipLaunchKernelGGL((decode_attn_partial_k<KBITS, VBITS, 4>), grid, dim3(kAttnBlock), 0, st, a);
@@ -401,9 +778,11 @@ extern "C" {
 
 int64_t kvq_decode_attn_workspace(const kvq_attn_dims_t* d) {
   if (!d || d->B <= 0 || d->Hq <= 0 || d->Hkv <= 0 || d->T < 0 || d->D <= 0) return -1;
+  if (d->D != 32 && d->D != 64 && d->D != 128 && d->D != 256) return -1;
   uint32_t ts, ns;
-  plan(d, &ts, &ns);
-  return d->B * d->Hq * (int64_t)(ns > 0 ? ns : 1) * (d->D + 2);
+  if (!plan(d, &ts, &ns)) return -1;
+  const int64_t rows = d->B * d->Hq * (int64_t)(ns > 0 ? ns : 1);
+  return (rows * 2 + 3) / 4 * 4 + rows * d->D;
 }
 
 int kvq_decode_attn(const void* q, int64_t q_sb, int64_t q_sh, const uint8_t* k_store, const kvq_strides_t* k_st,
@@ -418,8 +797,8 @@ int kvq_decode_attn(const void* q, int64_t q_sb, int64_t q_sh, const uint8_t* k_
     return KVQ_E_NULL;
   }
   if (d->B <= 0 || d->Hq <= 0 || d->Hkv <= 0 || d->T < 0 || d->B >= (1 << 16) || d->Hkv >= (1 << 16) ||
-      d->T >= (int64_t(1) << 31) || d->Hq % d->Hkv != 0 || d->Hq / d->Hkv > 8) {
-    set_error("%s: bad dims B=%lld Hq=%lld Hkv=%lld T=%lld (need Hq %% Hkv == 0, Hq / Hkv <= 8)", name, (long long)d->B,
+      d->T >= (int64_t(1) << 31) || d->Hq % d->Hkv != 0 || d->Hq / d->Hkv > (use_mfma(d) ? 16 : 8)) {
+    set_error("%s: bad dims B=%lld Hq=%lld Hkv=%lld T=%lld (need Hq %% Hkv == 0, Hq / Hkv <= 8, or <= 16 at head_dim 128)", name, (long long)d->B,
               (long long)d->Hq, (long long)d->Hkv, (long long)d->T);
     return KVQ_E_DIMS;
   }
@@ -481,7 +860,15 @@ int kvq_decode_attn(const void* q, int64_t q_sb, int64_t q_sh, const uint8_t* k_
   a.nq = (uint32_t)(d->Hq / d->Hkv);
   a.lpt_shift = ilog2_exact(d->D / 16);
   a.dtype = dtype;
-  plan(d, &a.TS, &a.nsplit);
+  if (!plan(d, &a.TS, &a.nsplit)) {
+    set_error("%s: T=%lld needs more than %d splits of %d tokens", name, (long long)d->T, kAttnMaxSplit, kAttnMaxTS);
+    return KVQ_E_DIMS;
+  }
+  a.acc_off = ((int64_t)a.B * a.Hq * a.nsplit * 2 + 3) / 4 * 4;
+  if (d->T > 0 && !aligned(workspace, 16)) {
+    set_error("%s: workspace must be 16-byte aligned", name);
+    return KVQ_E_DIMS;
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a.nsplit > 0) {
     if (k_bits == 8 && v_bits == 8) launch_partial<8, 8>(a, st);

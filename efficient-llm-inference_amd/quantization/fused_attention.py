@@ -1,0 +1,162 @@
+"""Decode with attention computed straight from the quantised store (scope row N1, second form).
+
+The reference dequantises the whole cache to fp16 before every forward
+(``QuantizedKVCache.to_past_key_values``, reference src/quantization/ops.py:345-355, called from
+src/benchmarking/benchmarker.py:470-471) and the model's attention then reads that fp16 copy. Here
+the model's attention function IS the HIP kernel ``kvq_decode_attn``: it reads the INT8 / packed
+INT4 rows and their per-token scales, adds the new token's exact K/V as one more softmax term
+(what the reference's ``cat`` does), and no fp16 copy of the cache exists at any time — the
+resident KV really is ``estimated_bytes()``.
+
+Plumbing (transformers >= 4.54 / 5.x):
+
+  * :class:`FusedQuantizedCache` owns a :class:`QuantizedKVCache` and hands the model a
+    ``DynamicCache`` whose layers quantise what ``update()`` receives into the store (2 launches per
+    layer) and pass the new tokens' exact K/V on to the attention function;
+  * ``kvq_fused`` is registered with transformers' ``AttentionInterface``; inside
+    :func:`fused_attention` the model's ``_attn_implementation`` points at it. A single-token
+    query runs ``kernels.decode_attn`` on the layer's store; a prompt (empty cache) runs exact
+    causal SDPA over the prompt's own K/V, as the reference's un-quantised prompt forward does.
+
+Numerics: fp32 accumulation over exact integer x fp16 products; the rounding of each dequantised
+value to fp16 that the reference's tuple path performs is skipped, so logits agree within fp16
+tolerance, not bit-for-bit (tests/test_gpu_attn.py, tests/test_gpu_benchmarker.py).
+Limits (fail loudly): fp16 / bf16 models, head_dim in {32, 64, 128, 256}, at most 8 query heads
+per kv head, no padding mask during decode, no chunked prefill into a non-empty cache.
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import Optional
+
+import torch
+
+from .. import kernels
+from .ops import QuantizedKVCache
+
+try:
+    from transformers import AttentionInterface
+    from transformers.cache_utils import DynamicCache, DynamicLayer
+    from transformers.masking_utils import AttentionMaskInterface, sdpa_mask
+except Exception:  # pragma: no cover - older transformers: the staged / tuple paths are used instead
+    AttentionInterface = None
+    DynamicCache = DynamicLayer = None
+
+ATTN_NAME = "kvq_fused"
+_ACTIVE: Optional["FusedQuantizedCache"] = None
+
+
+def available() -> bool:
+    return AttentionInterface is not None and DynamicLayer is not None
+
+
+if DynamicLayer is not None:
+
+    class _FusedLayer(DynamicLayer):
+        """One layer of the HF cache, backed by group ``index`` of the K and V stores."""
+
+        def __init__(self, owner: "FusedQuantizedCache", index: int):
+            super().__init__()
+            self._owner = owner
+            self._index = index
+            self.is_initialized = True
+            self.past = 0  # tokens in the store before the forward in flight
+            self.keys = self.values = None  # nothing dequantised is ever kept
+
+        def update(self, key_states: torch.Tensor, value_states: torch.Tensor, *args, **kwargs):
+            qc, i = self._owner.qcache, self._index
+            self.past = qc._k.lens[i]
+            self.dtype, self.device = key_states.dtype, key_states.device
+            k, v = key_states, value_states
+            if k.shape[-2] > 1:  # prompt: a dense copy takes the single-pass quantise path
+                k, v = k.contiguous(), v.contiguous()
+            qc._k.append([k], g0=i)  # one launch each: this layer's K group / V group
+            qc._v.append([v], g0=i)
+            return key_states, value_states  # the new tokens' exact K/V go on to the attention function
+
+        def get_seq_length(self) -> int:
+            return self._owner.qcache._k.lens[self._index]
+
+
+class FusedQuantizedCache:
+    """A :class:`QuantizedKVCache` the model appends to and attends over directly."""
+
+    def __init__(self, n_layers: int, mode: str = "int8", device: str = "cuda",
+                 compute_dtype: torch.dtype = torch.float16, reserve: int = 0):
+        if not available():
+            raise RuntimeError("kvq: this transformers version has no AttentionInterface / DynamicLayer")
+        self.qcache = QuantizedKVCache(n_layers=n_layers, mode=mode, device=device, compute_dtype=compute_dtype)
+        if reserve:
+            self.qcache.reserve(reserve)
+        self.cache = DynamicCache()
+        self.cache.layers = [_FusedLayer(self, i) for i in range(n_layers)]
+        self._ws: Optional[torch.Tensor] = None
+
+    def workspace(self, B: int, Hq: int, Hkv: int, T: int, D: int, device) -> torch.Tensor:
+        need = kernels.decode_attn_workspace(B, Hq, Hkv, max(T, 1), D)
+        if self._ws is None or self._ws.numel() < need:
+            # sized for the reserved capacity so that decode never reallocates
+            cap = max(self.qcache._k.cap, T, 1)
+            need = max(need, kernels.decode_attn_workspace(B, Hq, Hkv, cap, D))
+            self._ws = torch.empty(need, dtype=torch.float32, device=device)
+        return self._ws
+
+    def estimated_bytes(self) -> int:
+        return self.qcache.estimated_bytes()
+
+
+def _fused_attention_forward(module, query, key, value, attention_mask=None, dropout: float = 0.0,
+                             scaling: Optional[float] = None, **kwargs):
+    """transformers attention-interface function: ``(attn_output [B, n, Hq, D], None)``."""
+    owner = _ACTIVE
+    if owner is None:
+        raise RuntimeError("kvq: the 'kvq_fused' attention runs only inside fused_attention(model, cache)")
+    if dropout:
+        raise RuntimeError("kvq: fused decode attention is inference-only (dropout must be 0)")
+    B, Hq, n, D = query.shape
+    Hkv = key.shape[1]
+    scale = float(scaling) if scaling is not None else D ** -0.5
+    layer = owner.cache.layers[module.layer_idx]
+    if n > 1 or layer.past == 0:
+        # the prompt forward (or the very first token): exact attention over the tokens' own K/V,
+        # like the reference's un-quantised prompt pass (benchmarker.py:445-449)
+        if layer.past != 0:
+            raise RuntimeError("kvq: multi-token forward into a non-empty quantised cache is not supported")
+        if attention_mask is not None:
+            raise RuntimeError("kvq: fused attention does not take a padding mask")
+        if Hkv != Hq:
+            key = key.repeat_interleave(Hq // Hkv, dim=1)
+            value = value.repeat_interleave(Hq // Hkv, dim=1)
+        out = torch.nn.functional.scaled_dot_product_attention(query, key, value, is_causal=n > 1, scale=scale)
+        return out.transpose(1, 2).contiguous(), None
+    if attention_mask is not None:
+        raise RuntimeError("kvq: fused decode attention does not take a padding mask")
+    qc, i = owner.qcache, module.layer_idx
+    T = layer.past
+    out = torch.empty(B, 1, Hq, D, dtype=query.dtype, device=query.device)
+    kernels.decode_attn(
+        query[:, :, 0], qc._k.q[i], qc._k.scales[i], qc._k.kind, qc._v.q[i], qc._v.scales[i], qc._v.kind, T,
+        out[:, 0], owner.workspace(B, Hq, Hkv, T, D, query.device), scale, key[:, :, 0], value[:, :, 0])
+    return out, None
+
+
+@contextlib.contextmanager
+def fused_attention(model, cache: FusedQuantizedCache):
+    """Route ``model``'s attention through the quantised store of ``cache`` for the duration."""
+    global _ACTIVE
+    if not available():
+        raise RuntimeError("kvq: this transformers version has no AttentionInterface / DynamicLayer")
+    AttentionInterface.register(ATTN_NAME, _fused_attention_forward)
+    AttentionMaskInterface.register(ATTN_NAME, sdpa_mask)
+    before = model.config._attn_implementation
+    prev_active = _ACTIVE
+    model.set_attn_implementation(ATTN_NAME)
+    _ACTIVE = cache
+    try:
+        yield cache.cache
+    finally:
+        _ACTIVE = prev_active
+        model.set_attn_implementation(before)
+
+
+__all__ = ["FusedQuantizedCache", "fused_attention", "available", "ATTN_NAME"]

@@ -50,6 +50,15 @@ def test_method_validation(bench_cpu):
         with pytest.raises(RuntimeError, match="MI355X"):  # hot path has no CPU implementation
             bench_cpu.benchmark_method(["<40>"], method=m, max_new_tokens=2, window_size=8, keep_last=8, chunk_size=4,
                                        prefix_len=2, block_size=8, keep_per_block=2, old_budget=4)
+    # fused attention over the quantised store: same rule, and the model's attention setting is restored
+    before = bench_cpu.model.config._attn_implementation
+    bench_cpu.fused_attention = True
+    try:
+        with pytest.raises(RuntimeError, match="MI355X"):
+            bench_cpu.benchmark_method(["<40>"], method="quant_mixed", max_new_tokens=2)
+    finally:
+        bench_cpu.fused_attention = False
+    assert bench_cpu.model.config._attn_implementation == before
 
 
 def test_cache_format_shim_roundtrip():

@@ -100,6 +100,8 @@ CASES = [  # B, Hq, Hkv, T, D
     (1, 4, 4, 200, 256),     # widest head_dim
     (3, 4, 2, 1, 64),        # a single stored token
     (1, 32, 8, 5000, 128),   # several splits of different fill
+    (1, 16, 1, 300, 128),    # 16 query heads on one kv head: every MFMA column in use
+    (2, 6, 2, 200, 128),     # 3 per kv head at head_dim 128: MFMA kernel with padded heads
 ]
 
 
@@ -108,6 +110,39 @@ CASES = [  # B, Hq, Hkv, T, D
 def test_decode_attn_matches_oracle(K, case, kinds):
     for dtype, with_new in (("f16", True), ("f16", False), ("bf16", True)):
         _run_case(K, *case, kinds[0], kinds[1], dtype, with_new)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[4] == 128 and 3 <= c[1] // c[2] <= 8])
+@pytest.mark.parametrize("kinds", [("int8", "int4"), ("int4", "int8")])
+def test_decode_attn_valu_kernel_on_grouped_heads(K, case, kinds):
+    """head_dim 128 with 3..16 query heads per kv head takes the MFMA kernel by default; the VALU
+    kernel must give the same answer on those shapes (it serves every other head_dim)."""
+    from efficient_llm_inference_amd import _lib
+    _lib.set_tunable("attn_force_valu", 1)
+    try:
+        _run_case(K, *case, kinds[0], kinds[1], "f16", True)
+    finally:
+        _lib.set_tunable("attn_force_valu", 0)
+
+
+def test_decode_attn_tiny_magnitudes(K):
+    """V scales near the fp16 underflow range: P is normalised by the largest scale before the f16
+    pack of the MFMA kernel, so small-magnitude caches keep their precision."""
+    rng = np.random.default_rng(5)
+    B, Hq, Hkv, T, D = 1, 8, 2, 300, 128
+    k = rng.standard_normal((1, B, Hkv, T, D)).astype(np.float16)
+    v = (rng.standard_normal((1, B, Hkv, T, D)) * 3e-4).astype(np.float16)
+    kq, _, ks = O.quantize_tokens(k, "int8")
+    vq, _, vs = O.quantize_tokens(v, "int4")
+    q = rng.standard_normal((B, Hq, D)).astype(np.float16)
+    sm = D ** -0.5
+    ref = O.decode_attention(q, kq[0], ks[0], "int8", vq[0], vs[0], "int4", D, sm)
+    out = torch.empty(B, Hq, D, dtype=torch.float16, device="cuda")
+    ws = torch.empty(K.decode_attn_workspace(B, Hq, Hkv, T, D), dtype=torch.float32, device="cuda")
+    K.decode_attn(to_torch(q), to_torch(kq[0]), to_torch(ks[0]), "int8", to_torch(vq[0]), to_torch(vs[0]), "int4", T, out, ws, sm)
+    got = to_numpy(out).astype(np.float64)
+    scale = np.abs(ref).max()
+    assert scale > 0 and (np.abs(got - ref) <= 4e-3 * scale + 1e-7).all(), float(np.abs(got - ref).max() / scale)
 
 
 def test_decode_attn_only_new_token(K):

@@ -159,3 +159,75 @@ def test_bf16_model_decodes_with_bf16_compute():
     assert a1 == a2 and a1[1] == 8
     res = b.benchmark_method(["<40>"], "paged_attention", max_new_tokens=4, block_size=8)
     assert res["total_new_tokens"] == 4
+
+
+@pytest.mark.parametrize("mode", ["int8", "mixed", "int4"])
+def test_fused_attention_decode_tracks_tuple_path(mode):
+    """Scope row N1, second form: the model attends straight over the INT8 / INT4 store
+    (kvq_decode_attn as its attention function, no fp16 copy of the cache). Teacher-forced with the
+    tuple path's tokens, every step's logits agree within fp16 tolerance; layer 0's store (a
+    function of the embeddings only) is bit-identical; the reported cache size is the same."""
+    import efficient_llm_inference_amd as E
+    from efficient_llm_inference_amd import KVCacheBenchmarker
+    from efficient_llm_inference_amd.benchmarking import from_legacy_tuple, to_legacy_tuple
+    from efficient_llm_inference_amd.benchmarking.offline import load_model
+    from efficient_llm_inference_amd.quantization import fused_attention as FA
+    model, tok = load_model("gpt2-mini", "cuda", torch.float16)
+    n_new = 24
+    with torch.no_grad():
+        ids = tok("<150>", return_tensors="pt").input_ids.cuda()
+        out = model(input_ids=ids, use_cache=True)
+        logits = out.logits[:, -1, :]
+        kv = to_legacy_tuple(out.past_key_values)
+        qc = E.QuantizedKVCache(len(kv), mode, incremental=False)
+        qc.init_from_prompt_past(kv)
+        first_logits = logits.float()
+        ref_logits, toks = [], []
+        for _ in range(n_new):
+            nxt = torch.argmax(logits, dim=-1, keepdim=True)
+            toks.append(nxt)
+            out = model(input_ids=nxt, use_cache=True, past_key_values=from_legacy_tuple(qc.to_past_key_values()))
+            logits = out.logits[:, -1, :]
+            qc.append_from_past(to_legacy_tuple(out.past_key_values))
+            ref_logits.append(logits.float())
+
+        fc = FA.FusedQuantizedCache(len(kv), mode=mode, reserve=ids.shape[-1] + n_new)
+        impl_before = model.config._attn_implementation
+        with FA.fused_attention(model, fc) as cache:
+            out = model(input_ids=ids, use_cache=True, past_key_values=cache)
+            assert torch.allclose(out.logits[:, -1, :].float(), first_logits, atol=2e-2, rtol=0)  # exact prompt attention
+            worst = 0.0
+            for step, nxt in enumerate(toks):
+                out = model(input_ids=nxt, use_cache=True, past_key_values=cache)
+                got = out.logits[:, -1, :].float()
+                ref = ref_logits[step]
+                worst = max(worst, float((got - ref).abs().max() / ref.abs().max()))
+            assert worst < 2e-2, worst
+        assert model.config._attn_implementation == impl_before
+        T = ids.shape[-1] + n_new
+        assert fc.qcache._k.lens == [T] * len(kv) and cache.get_seq_length() == T
+        assert torch.equal(fc.qcache._k.q[0, :, :, :T], qc._k.q[0, :, :, :T])
+        assert torch.equal(fc.qcache._k.scales[0, :T], qc._k.scales[0, :T])
+        assert fc.estimated_bytes() == qc.estimated_bytes()
+        assert fc.qcache._k.stage is None and fc.qcache._v.stage is None  # no fp16 copy was ever made
+
+    bench = KVCacheBenchmarker(model, tok, device="cuda")
+    a = bench.generate_with_quantized_kv("<150>", n_new, mode=mode)
+    bench.fused_attention = True
+    b = bench.generate_with_quantized_kv("<150>", n_new, mode=mode)
+    assert b[1] == n_new and b[2] == a[2]
+    res = bench.benchmark_method(["<60>", "<61>"], f"quant_{mode}", max_new_tokens=6)
+    assert res["total_new_tokens"] == 12 and res["est_kv_cache_mb_avg"] > 0
+
+
+def test_fused_attention_rejects_unsupported_head_dim(rig):
+    """gpt2-tiny has head_dim 16: the fused kernel refuses it loudly (no silent fallback)."""
+    from efficient_llm_inference_amd._lib import KvqError
+    bench = rig[0]
+    bench.fused_attention = True
+    try:
+        with pytest.raises(KvqError):
+            bench.generate_with_quantized_kv("<20>", 4, mode="int8")
+    finally:
+        bench.fused_attention = False
+    assert bench.model.config._attn_implementation != "kvq_fused"
