@@ -70,6 +70,8 @@ def parse():
                          "step re-reads lines the 256 MiB Infinity Cache may still hold (1 = the decode loop's "
                          "behaviour: the same cache every step; its 256 MiB INT4 store then stays cache-resident)")
     ap.add_argument("--cpu-sample-layers", type=int, default=32)
+    ap.add_argument("--tunable", action="append", default=[], metavar="KEY=VALUE",
+                    help="A-B only: kvq_set_tunable(KEY, VALUE) before the run (include/kvq_hip.h lists the keys)")
     ap.add_argument("--fused-attention", action="store_true",
                     help="decode:* workloads with quant_* methods: attend straight over the quantised store "
                          "(kvq_decode_attn) instead of the staged fp16 copy")
@@ -342,6 +344,9 @@ def main():
     from efficient_llm_inference_amd import _lib, sharding
 
     _lib.load()
+    for kv in args.tunable:
+        key, _, val = kv.partition("=")
+        _lib.set_tunable(key, int(val))
     if args.workload.startswith("decode"):
         run_decode(args, rank, world, dev)
         if world > 1:

@@ -19,6 +19,8 @@
 //                          writes (m, l, acc[D]) per (b, hq, split) to the workspace
 //   decode_attn_merge_k    grid (hq, batch): log-sum-exp merge of the splits and of the new token
 // 16 elements per lane per token: 16-byte (INT8) / 8-byte (INT4) loads, D/16 lanes per token.
+#include <type_traits>
+
 #include "kvq_common.h"
 
 namespace kvq {
@@ -48,6 +50,7 @@ struct AttnArgs {
   uint32_t B, Hq, Hkv, T, D, TS, nsplit, nq;
   int32_t lpt_shift;  // log2(D / 16): lanes per token
   int32_t dtype;      // KVQ_F16 | KVQ_BF16 (q, k_new, v_new, out)
+  int32_t mfma;       // host: the MFMA partial kernel serves this call
 };
 
 __device__ inline f16x2 bits_h2(uint32_t u) {
@@ -492,6 +495,26 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
     for (int c = 0; c < 4; ++c) qb[c] = pack_h8(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
   }
 
+  // V rows of a 32-token step: raw bytes, double buffered; step 0 is requested before the scores
+  // are computed so that its latency hides behind phase one (requesting every step up front costs
+  // a wave per SIMD in registers and measured slower: 16.4 vs 14.4 us at batch 1, 71 vs 52 us at 8)
+  typedef typename std::conditional<VBITS == 8, u32x2, uint32_t>::type vraw_t;
+  const uint8_t* vb = a.v + (int64_t)b * a.v_sb + (int64_t)hk * a.v_sh + (int64_t)t0 * a.v_st + (VBITS == 8 ? 8 : 4) * x;
+  auto load_v_step = [&](int s, vraw_t (&dst)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t tok = 32 * s + 16 * (j >> 2) + 4 * g + (j & 3);
+      if constexpr (VBITS == 8) {
+        dst[j] = u32x2{0u, 0u};  // int8 zeros
+        if (tok < nt) dst[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(vb + (int64_t)tok * a.v_st));
+      } else {
+        dst[j] = 0x88888888u;  // nibble 8 = value 0
+        if (tok < nt) dst[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(vb + (int64_t)tok * a.v_st));
+      }
+    }
+  };
+  vraw_t vr[2][8];
+
   // ---- S = K Q^T: tile i, token row x -----------------------------------------------------------
   f32x4 sc[NT];
   {
@@ -509,6 +532,7 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
           raw[i][c] = KBITS == 8 ? u32x4{0u, 0u, 0u, 0u} : u32x4{0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u};
       }
     }
+    load_v_step(0, vr[0]);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       f32x4 c4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -572,27 +596,19 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
 #pragma unroll
   for (int n = 0; n < 8; ++n) acc[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   {
-    const uint8_t* vb = a.v + (int64_t)b * a.v_sb + (int64_t)hk * a.v_sh + (int64_t)t0 * a.v_st;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
+      if (s + 1 < NS) load_v_step(s + 1, vr[(s + 1) & 1]);
       // the lane's 8 token rows of this step, 8 elements each
-      uint32_t lo[8], hi[8];  // INT8: bytes d0..d3 / d4..d7; INT4: elements 0,2,4,6 / 1,3,5,7
+      uint32_t lo[8], hi[8];  // INT8: bytes d0..d3 / d4..d7 (sign flipped); INT4: elements 0,2,4,6 / 1,3,5,7
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const uint32_t tok = 32 * s + 16 * (j >> 2) + 4 * g + (j & 3);
         if constexpr (VBITS == 8) {
-          u32x2 w = {0x80808080u, 0x80808080u};  // value 0 after the sign flip below
-          if (tok < nt) {
-            w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(vb + (int64_t)tok * a.v_st + 8 * x));
-            w ^= u32x2{0x80808080u, 0x80808080u};
-          }
-          lo[j] = w[0];
-          hi[j] = w[1];
+          lo[j] = vr[s & 1][j][0] ^ 0x80808080u;
+          hi[j] = vr[s & 1][j][1] ^ 0x80808080u;
         } else {
-          uint32_t w = 0x88888888u;
-          if (tok < nt) w = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(vb + (int64_t)tok * a.v_st + 4 * x));
-          lo[j] = (w >> 4) & 0x0F0F0F0Fu;
-          hi[j] = w & 0x0F0F0F0Fu;
+          lo[j] = (vr[s & 1][j] >> 4) & 0x0F0F0F0Fu;
+          hi[j] = vr[s & 1][j] & 0x0F0F0F0Fu;
         }
       }
       const f16x8 pa = pack_h8(Elem<KVQ_F16>::pack2(sc[2 * s][0], sc[2 * s][1]), Elem<KVQ_F16>::pack2(sc[2 * s][2], sc[2 * s][3]),
@@ -740,9 +756,11 @@ static bool use_mfma(const kvq_attn_dims_t* d) {
   return d->D == 128 && nq >= 3 && nq <= 16 && !tunables().attn_force_valu;
 }
 static bool plan(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit) {
-  if (use_mfma(d)) {  // one wave per split of kAttnMfmaTC tokens
-    *ts = kAttnMfmaTC;
-    *nsplit = (uint32_t)((d->T + kAttnMfmaTC - 1) / kAttnMfmaTC);
+  if (use_mfma(d)) {  // one wave per split of TC tokens
+    int64_t tc = tunables().attn_mfma_tc == 64 ? 64 : kAttnMfmaTC;
+    if ((d->T + tc - 1) / tc > kAttnMaxSplit) tc = kAttnMfmaTC;
+    *ts = (uint32_t)tc;
+    *nsplit = (uint32_t)((d->T + tc - 1) / tc);
     return *nsplit <= (uint32_t)kAttnMaxSplit;
   }
   const int64_t step = (int64_t)(kAttnBlock / (d->D / 16)) * kAttnUnroll;
@@ -760,8 +778,9 @@ static bool plan(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit) {
 template <int KBITS, int VBITS>
 static void launch_partial(const AttnArgs& a, hipStream_t st) {
   const dim3 grid(a.nsplit, a.Hkv, a.B);
-  if (a.TS == (uint32_t)kAttnMfmaTC && a.D == 128 && a.nq >= 3 && !tunables().attn_force_valu) {
-    hipLaunchKernelGGL((decode_attn_partial_mfma_k<KBITS, VBITS, kAttnMfmaTC>), grid, dim3(kWave), 0, st, a);
+  if (a.mfma) {
+    if (a.TS == 64u) hipLaunchKernelGGL((decode_attn_partial_mfma_k<KBITS, VBITS, 64>), grid, dim3(kWave), 0, st, a);
+    else hipLaunchKernelGGL((decode_attn_partial_mfma_k<KBITS, VBITS, kAttnMfmaTC>), grid, dim3(kWave), 0, st, a);
     return;
   }
   if (a.nq == 1) hipLaunchKernelGGL((decode_attn_partial_k<KBITS, VBITS, 1>), grid, dim3(kAttnBlock), 0, st, a);
@@ -860,6 +879,7 @@ int kvq_decode_attn(const void* q, int64_t q_sb, int64_t q_sh, const uint8_t* k_
   a.nq = (uint32_t)(d->Hq / d->Hkv);
   a.lpt_shift = ilog2_exact(d->D / 16);
   a.dtype = dtype;
+  a.mfma = use_mfma(d) ? 1 : 0;
   if (!plan(d, &a.TS, &a.nsplit)) {
     set_error("%s: T=%lld needs more than %d splits of %d tokens", name, (long long)d->T, kAttnMaxSplit, kAttnMaxTS);
     return KVQ_E_DIMS;
