@@ -38,6 +38,7 @@ EXPORTS = (
     "kvq_gather_tokens",
     "kvq_decode_attn_workspace",
     "kvq_decode_attn",
+    "kvq_decode_step",
     "kvq_set_tunable",
     "kvq_get_tunable",
 )
@@ -102,6 +103,9 @@ def _declare(lib):
     lib.kvq_decode_attn.restype = c_int
     lib.kvq_decode_attn.argtypes = [P, c_int64, c_int64, P, ST, P, c_int, P, ST, P, c_int, P, c_int64, c_int64,
                                     P, c_int64, c_int64, P, c_int64, c_int64, c_int, c_float, P, c_int64, AD, P]
+    lib.kvq_decode_step.restype = c_int
+    lib.kvq_decode_step.argtypes = [P, c_int64, c_int64, P, c_int64, c_int64, P, c_int64, c_int64, P, ST, P, c_int,
+                                    P, ST, P, c_int, P, c_int64, c_int64, c_int, c_float, c_float, P, c_int64, AD, P]
     lib.kvq_chunk_summary_len.restype = c_int64
     lib.kvq_chunk_summary_len.argtypes = [c_int64, c_int64, c_int64]
     lib.kvq_set_tunable.restype = c_int

@@ -902,4 +902,38 @@ int kvq_decode_attn(const void* q, int64_t q_sb, int64_t q_sh, const uint8_t* k_
   return check_launch(name);
 }
 
+
+int kvq_decode_step(const void* q, int64_t q_sb, int64_t q_sh, const void* k_new, int64_t kn_sb, int64_t kn_sh,
+                    const void* v_new, int64_t vn_sb, int64_t vn_sh, uint8_t* k_store, const kvq_strides_t* k_st,
+                    float* k_scales, int k_bits, uint8_t* v_store, const kvq_strides_t* v_st, float* v_scales,
+                    int v_bits, void* out, int64_t o_sb, int64_t o_sh, int dtype, float sm_scale, float eps,
+                    float* workspace, int64_t workspace_floats, const kvq_attn_dims_t* d, void* stream) {
+  const char* name = "kvq_decode_step";
+  if (!d || !k_new || !v_new || !k_store || !v_store || !k_scales || !v_scales || !k_st || !v_st || !workspace) {
+    set_error("%s: NULL argument", name);
+    return KVQ_E_NULL;
+  }
+  // 1. attention over the T stored tokens + the exact new token
+  int rc = kvq_decode_attn(q, q_sb, q_sh, k_store, k_st, k_scales, k_bits, v_store, v_st, v_scales, v_bits, k_new,
+                           kn_sb, kn_sh, v_new, vn_sb, vn_sh, out, o_sb, o_sh, dtype, sm_scale, workspace,
+                           workspace_floats, d, stream);
+  if (rc) return rc;
+  // 2. quantise the new token into slot T (append_from_past, ops.py:323-330): one group, one token.
+  //    Stream order keeps the attention's reads of [0, T) ahead of these writes to slot T.
+  const kvq_dims_t qd = {1, d->B, d->Hkv, 1, d->D};
+  const kvq_strides_t kin = {0, kn_sb, kn_sh, d->D}, vin = {0, vn_sb, vn_sh, d->D};
+  float* absmax_ws = workspace;  // only the generic two-pass path uses it (1 float); the attention is already enqueued
+  rc = k_bits == 8
+           ? kvq_quant_i8_tokens(k_new, nullptr, &kin, dtype, reinterpret_cast<int8_t*>(k_store + d->T * k_st->t), k_st,
+                                 k_scales + d->T, 0, absmax_ws, eps, &qd, stream)
+           : kvq_quant_i4_tokens(k_new, nullptr, &kin, dtype, k_store + d->T * k_st->t, k_st, k_scales + d->T, 0,
+                                 absmax_ws, eps, &qd, stream);
+  if (rc) return rc;
+  return v_bits == 8
+             ? kvq_quant_i8_tokens(v_new, nullptr, &vin, dtype, reinterpret_cast<int8_t*>(v_store + d->T * v_st->t), v_st,
+                                   v_scales + d->T, 0, absmax_ws, eps, &qd, stream)
+             : kvq_quant_i4_tokens(v_new, nullptr, &vin, dtype, v_store + d->T * v_st->t, v_st, v_scales + d->T, 0,
+                                   absmax_ws, eps, &qd, stream);
+}
+
 }  // extern "C"

@@ -290,3 +290,64 @@ def decode_attn(q: torch.Tensor, k_store: torch.Tensor, k_scales: torch.Tensor, 
         kn[0], kn[1], kn[2], vn[0], vn[1], vn[2],
         c_void_p(out.data_ptr()), out.stride(0), out.stride(1), dtype_code(q.dtype), float(sm_scale),
         c_void_p(workspace.data_ptr()), workspace.numel(), byref(dims), _lib.current_stream(q.device)), "decode_attn")
+
+
+class DecodeStepPlan:
+    """Pre-validated arguments of :func:`decode_step` for one layer of one store: everything that
+    does not change from token to token (pointers, strides, kinds), so that the per-step host cost
+    is one ctypes call. Rebuild it when the store is reallocated or the query layout changes."""
+
+    __slots__ = ("key", "k_ptr", "v_ptr", "ks_ptr", "vs_ptr", "kst", "vst", "kbits", "vbits", "B", "Hq", "Hkv", "D",
+                 "cap", "dtype_code", "eps", "keep")
+
+    def __init__(self, q: torch.Tensor, k_store: torch.Tensor, k_scales: torch.Tensor, k_kind: str,
+                 v_store: torch.Tensor, v_scales: torch.Tensor, v_kind: str, eps: float):
+        for name, t in (("q", q), ("k_store", k_store), ("v_store", v_store), ("k_scales", k_scales), ("v_scales", v_scales)):
+            require_gpu(t, name)
+        if q.dim() != 3 or q.dtype not in (torch.float16, torch.bfloat16):
+            raise _lib.KvqError(f"kvq: decode_step needs a [B,Hq,D] fp16 / bf16 query, got {tuple(q.shape)} {q.dtype}")
+        B, Hq, D = q.shape
+        if k_store.dim() != 4 or v_store.dim() != 4 or k_store.shape[:3] != v_store.shape[:3] or k_store.size(0) != B:
+            raise _lib.KvqError("kvq: decode_step stores must be [B,Hkv,Tcap,Dq] views of one layer")
+        if k_store.dtype != QDTYPE[k_kind] or v_store.dtype != QDTYPE[v_kind]:
+            raise _lib.KvqError("kvq: decode_step store dtype does not match its kind")
+        if k_store.size(3) != packed_dim(k_kind, D) or v_store.size(3) != packed_dim(v_kind, D):
+            raise _lib.KvqError("kvq: decode_step store last dim does not match head_dim")
+        if k_store.stride(3) != 1 or v_store.stride(3) != 1 or k_scales.dtype != torch.float32 or v_scales.dtype != torch.float32:
+            raise _lib.KvqError("kvq: decode_step stores must be row-contiguous, scales float32")
+        if k_scales.dim() != 1 or v_scales.dim() != 1 or k_scales.stride(0) != 1 or v_scales.stride(0) != 1:
+            raise _lib.KvqError("kvq: decode_step scales must be contiguous [Tcap] rows")
+        self.cap = min(k_store.size(2), v_store.size(2), k_scales.numel(), v_scales.numel())
+        self.B, self.Hq, self.Hkv, self.D = B, Hq, k_store.size(1), D
+        self.k_ptr, self.v_ptr = c_void_p(k_store.data_ptr()), c_void_p(v_store.data_ptr())
+        self.ks_ptr, self.vs_ptr = c_void_p(k_scales.data_ptr()), c_void_p(v_scales.data_ptr())
+        self.kst = KvqStrides(0, k_store.stride(0), k_store.stride(1), k_store.stride(2))
+        self.vst = KvqStrides(0, v_store.stride(0), v_store.stride(1), v_store.stride(2))
+        self.kbits, self.vbits = KIND_BITS[k_kind], KIND_BITS[v_kind]
+        self.dtype_code = dtype_code(q.dtype)
+        self.eps = float(eps)
+        self.key = (k_store.data_ptr(), v_store.data_ptr(), q.dtype, B, Hq, D)
+        self.keep = (k_store, v_store, k_scales, v_scales)
+
+
+def decode_step(plan: DecodeStepPlan, q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, T: int,
+                out: torch.Tensor, workspace: torch.Tensor, sm_scale: float) -> None:
+    """Attention over the ``T`` stored tokens + the new token, then the new token quantised into slot
+    ``T`` of the stores: one layer's whole decode step in one call (kvq_decode_step). q / out
+    ``[B,Hq,D]``, k_new / v_new ``[B,Hkv,D]`` (last dim contiguous). The caller bumps its token
+    count afterwards."""
+    if T < 0 or T >= plan.cap:
+        raise _lib.KvqError(f"kvq: decode_step slot {T} is outside the store (capacity {plan.cap})")
+    if (q.shape != (plan.B, plan.Hq, plan.D) or out.shape != q.shape or k_new.shape != (plan.B, plan.Hkv, plan.D)
+            or v_new.shape != k_new.shape or not (q.is_cuda and k_new.is_cuda and v_new.is_cuda and out.is_cuda)
+            or q.stride(2) != 1 or k_new.stride(2) != 1 or v_new.stride(2) != 1 or out.stride(2) != 1
+            or k_new.dtype != q.dtype or v_new.dtype != q.dtype or out.dtype != q.dtype):
+        raise _lib.KvqError("kvq: decode_step tensors do not match the plan (shape / dtype / device / contiguity)")
+    dims = _lib.KvqAttnDims(plan.B, plan.Hq, plan.Hkv, T, plan.D)
+    check(_lib.load().kvq_decode_step(
+        c_void_p(q.data_ptr()), q.stride(0), q.stride(1),
+        c_void_p(k_new.data_ptr()), k_new.stride(0), k_new.stride(1),
+        c_void_p(v_new.data_ptr()), v_new.stride(0), v_new.stride(1),
+        plan.k_ptr, byref(plan.kst), plan.ks_ptr, plan.kbits, plan.v_ptr, byref(plan.vst), plan.vs_ptr, plan.vbits,
+        c_void_p(out.data_ptr()), out.stride(0), out.stride(1), plan.dtype_code, float(sm_scale), plan.eps,
+        c_void_p(workspace.data_ptr()), workspace.numel(), byref(dims), _lib.current_stream(q.device)), "decode_step")

@@ -11,8 +11,9 @@ resident KV really is ``estimated_bytes()``.
 Plumbing (transformers >= 4.54 / 5.x):
 
   * :class:`FusedQuantizedCache` owns a :class:`QuantizedKVCache` and hands the model a
-    ``DynamicCache`` whose layers quantise what ``update()`` receives into the store (2 launches per
-    layer) and pass the new tokens' exact K/V on to the attention function;
+    ``DynamicCache`` whose layers quantise the prompt's K/V into the store (2 launches per layer) and
+    pass the new tokens' exact K/V on to the attention function; a decode token is quantised by the
+    same host call that attends (``kvq_decode_step``: one ctypes call per layer and step);
   * ``kvq_fused`` is registered with transformers' ``AttentionInterface``; inside
     :func:`fused_attention` the model's ``_attn_implementation`` points at it. A single-token
     query runs ``kernels.decode_attn`` on the layer's store; a prompt (empty cache) runs exact
@@ -61,17 +62,25 @@ if DynamicLayer is not None:
             self._index = index
             self.is_initialized = True
             self.past = 0  # tokens in the store before the forward in flight
+            self.pending = False  # the new token still has to be quantised (done by the attention call)
+            self.plan = None  # kernels.DecodeStepPlan of this layer
             self.keys = self.values = None  # nothing dequantised is ever kept
 
         def update(self, key_states: torch.Tensor, value_states: torch.Tensor, *args, **kwargs):
             qc, i = self._owner.qcache, self._index
             self.past = qc._k.lens[i]
             self.dtype, self.device = key_states.dtype, key_states.device
-            k, v = key_states, value_states
-            if k.shape[-2] > 1:  # prompt: a dense copy takes the single-pass quantise path
-                k, v = k.contiguous(), v.contiguous()
-            qc._k.append([k], g0=i)  # one launch each: this layer's K group / V group
-            qc._v.append([v], g0=i)
+            if key_states.shape[-2] == 1 and self.past > 0:
+                # decode: the attention function quantises this token into slot `past` in the same
+                # host call that attends (kvq_decode_step); only the capacity is settled here
+                qc._k.reserve(self.past + 1)
+                qc._v.reserve(self.past + 1)
+                self.pending = True
+                return key_states, value_states
+            # prompt: a dense copy takes the single-pass quantise path; one launch per store
+            qc._k.append([key_states.contiguous()], g0=i)
+            qc._v.append([value_states.contiguous()], g0=i)
+            self.pending = False
             return key_states, value_states  # the new tokens' exact K/V go on to the attention function
 
         def get_seq_length(self) -> int:
@@ -134,9 +143,15 @@ def _fused_attention_forward(module, query, key, value, attention_mask=None, dro
     qc, i = owner.qcache, module.layer_idx
     T = layer.past
     out = torch.empty(B, 1, Hq, D, dtype=query.dtype, device=query.device)
-    kernels.decode_attn(
-        query[:, :, 0], qc._k.q[i], qc._k.scales[i], qc._k.kind, qc._v.q[i], qc._v.scales[i], qc._v.kind, T,
-        out[:, 0], owner.workspace(B, Hq, Hkv, T, D, query.device), scale, key[:, :, 0], value[:, :, 0])
+    q3 = query[:, :, 0]
+    plan = layer.plan
+    if plan is None or plan.key != (qc._k.q[i].data_ptr(), qc._v.q[i].data_ptr(), query.dtype, B, Hq, D):
+        plan = layer.plan = kernels.DecodeStepPlan(q3, qc._k.q[i], qc._k.scales[i], qc._k.kind, qc._v.q[i],
+                                                   qc._v.scales[i], qc._v.kind, qc._k.eps)
+    kernels.decode_step(plan, q3, key[:, :, 0], value[:, :, 0], T, out[:, 0],
+                        owner.workspace(B, Hq, Hkv, T, D, query.device), scale)
+    qc._k.lens[i] = qc._v.lens[i] = T + 1  # the step appended the token
+    layer.pending = False
     return out, None
 
 

@@ -187,6 +187,19 @@ int kvq_decode_attn(const void* q, int64_t q_stride_b, int64_t q_stride_h,
                     void* out, int64_t out_stride_b, int64_t out_stride_h, int dtype, float sm_scale,
                     float* workspace, int64_t workspace_floats, const kvq_attn_dims_t* dims, void* stream);
 
+/* kvq_decode_attn over the T stored tokens + the new token, THEN the new token's K / V quantised into
+ * slot T of the stores (scales[T]): everything one layer does per decode step in the reference
+ * (append_from_past ops.py:323-330, to_past_key_values :345-355, attention) behind one call.
+ * The caller guarantees capacity for slot T (k_st / v_st describe the whole [B,Hkv,Tcap,Dq] store)
+ * and counts the token as stored afterwards. workspace as for kvq_decode_attn (>= 1 float). */
+int kvq_decode_step(const void* q, int64_t q_stride_b, int64_t q_stride_h,
+                    const void* k_new, int64_t kn_stride_b, int64_t kn_stride_h,
+                    const void* v_new, int64_t vn_stride_b, int64_t vn_stride_h,
+                    uint8_t* k_store, const kvq_strides_t* k_st, float* k_scales, int k_bits,
+                    uint8_t* v_store, const kvq_strides_t* v_st, float* v_scales, int v_bits,
+                    void* out, int64_t out_stride_b, int64_t out_stride_h, int dtype, float sm_scale, float eps,
+                    float* workspace, int64_t workspace_floats, const kvq_attn_dims_t* dims, void* stream);
+
 /* ---- tuning knobs (benchmarks only; defaults are what ships) ----------------------------- */
 
 /* key: "dequant_variant" (0..30, -1 = shipped default), "dequant_grid" (workgroups, 0 = one chunk

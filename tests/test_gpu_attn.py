@@ -145,6 +145,49 @@ def test_decode_attn_tiny_magnitudes(K):
     assert scale > 0 and (np.abs(got - ref) <= 4e-3 * scale + 1e-7).all(), float(np.abs(got - ref).max() / scale)
 
 
+@pytest.mark.parametrize("shape", [(1, 12, 12, 77, 64), (2, 32, 8, 300, 128)])
+@pytest.mark.parametrize("kinds", [("int8", "int4"), ("int4", "int8")])
+def test_decode_step_attends_then_appends(K, shape, kinds):
+    """kvq_decode_step = kvq_decode_attn over the stored tokens + the new one, then the new token's
+    K / V quantised into slot T: output within tolerance of the oracle, slot T bit-exact with the
+    oracle's quantiser, every other slot untouched."""
+    B, Hq, Hkv, T, D = shape
+    rng = np.random.default_rng(T)
+    k = rng.standard_normal((1, B, Hkv, T + 1, D)).astype(np.float16)
+    v = rng.standard_normal((1, B, Hkv, T + 1, D)).astype(np.float16)
+    kq, _, ks = O.quantize_tokens(k, kinds[0])
+    vq, _, vs = O.quantize_tokens(v, kinds[1])
+    q = rng.standard_normal((B, Hq, D)).astype(np.float16)
+    sm = D ** -0.5
+    ref = O.decode_attention(q, kq[0][:, :, :T], ks[0][:T], kinds[0], vq[0][:, :, :T], vs[0][:T], kinds[1], D, sm,
+                             k[0][:, :, T].astype(np.float32), v[0][:, :, T].astype(np.float32))
+    cap = T + 5
+    k_store = torch.full((B, Hkv, cap, kq.shape[-1]), 9, dtype=K.QDTYPE[kinds[0]], device="cuda")
+    v_store = torch.full((B, Hkv, cap, vq.shape[-1]), 9, dtype=K.QDTYPE[kinds[1]], device="cuda")
+    k_sc = torch.full((cap,), -1.0, device="cuda")
+    v_sc = torch.full((cap,), -1.0, device="cuda")
+    k_store[:, :, :T] = to_torch(kq[0][:, :, :T])
+    v_store[:, :, :T] = to_torch(vq[0][:, :, :T])
+    k_sc[:T] = to_torch(ks[0][:T])
+    v_sc[:T] = to_torch(vs[0][:T])
+    qt = to_torch(q)
+    kn, vn = to_torch(k[0][:, :, T].copy()), to_torch(v[0][:, :, T].copy())
+    out = torch.empty_like(qt)
+    ws = torch.empty(K.decode_attn_workspace(B, Hq, Hkv, cap, D), dtype=torch.float32, device="cuda")
+    plan = K.DecodeStepPlan(qt, k_store, k_sc, kinds[0], v_store, v_sc, kinds[1], 1e-8)
+    K.decode_step(plan, qt, kn, vn, T, out, ws, sm)
+    torch.cuda.synchronize()
+    got = to_numpy(out).astype(np.float64)
+    assert (np.abs(got - ref) <= TOL["f16"] * (np.abs(ref) + np.abs(ref).max())).all()
+    assert np.array_equal(to_numpy(k_store[:, :, :T + 1]), kq[0]) and np.array_equal(to_numpy(v_store[:, :, :T + 1]), vq[0])
+    assert np.array_equal(to_numpy(k_sc[:T + 1]), ks[0]) and np.array_equal(to_numpy(v_sc[:T + 1]), vs[0])
+    assert int((k_store[:, :, T + 1:] != 9).sum()) == 0 and int((v_store[:, :, T + 1:] != 9).sum()) == 0
+    assert float((k_sc[T + 1:] + 1.0).abs().sum()) == 0.0 and float((v_sc[T + 1:] + 1.0).abs().sum()) == 0.0
+    from efficient_llm_inference_amd._lib import KvqError
+    with pytest.raises(KvqError):  # no capacity for the slot
+        K.decode_step(plan, qt, kn, vn, cap, out, ws, sm)
+
+
 def test_decode_attn_only_new_token(K):
     # empty store: the softmax has the new token alone, out == v_new
     _run_case(K, 2, 8, 4, 0, 64, "int8", "int4", "f16", True)
