@@ -94,6 +94,14 @@ def cpu_baseline(L, B, H, T, D, sample_layers):
         C.dequantize_tokens(q, sc, "int4", D, "f16")
         dt = min(dt, time.perf_counter() - t0)
     n = n_layers * B * H * T * D
+    # the quantise side of the same path (rows a1/a2): scalar C port, fp16 -> INT4, on 4 layers
+    nq_layers = max(1, min(4, n_layers))
+    xq = (rng.standard_normal((nq_layers, B, H, T, D), dtype=np.float32)).astype(np.float16)
+    C.quantize_tokens(xq[:1, :, :, :64], "int4")
+    tq0 = time.perf_counter()
+    C.quantize_tokens(xq, "int4")
+    dq_s = time.perf_counter() - tq0
+    nq = nq_layers * B * H * T * D
     # the reference's literal call structure (per-slice op chains + T-way cat) on a small sample
     import torch as _t
     from oracle import literal_loop as LL
@@ -114,6 +122,9 @@ def cpu_baseline(L, B, H, T, D, sample_layers):
         "sample": f"INT4->fp16 dequantise of {n_layers}/{L} layers of the V set "
                   f"[{n_layers},{B},{H},{T},{D}] ({n} elements, best of 3 passes: {dt:.2f} s), oracle/kvq_oracle.c scalar",
         "host_cores_available": os.cpu_count(),
+        "quantise": {"value": round(nq * BYTES_PER_ELT["int4"] / dq_s / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+                     "sample": f"fp16->INT4 per-token quantise of {nq_layers}/{L} layers [{nq_layers},{B},{H},{T},{D}] "
+                               f"({dq_s:.2f} s), oracle/kvq_oracle.c scalar"},
         "literal_loop": {"value": round(n_lit * BYTES_PER_ELT["int4"] / dl / 1e9, 5), "unit": "GB/s",
                          "sample": f"per-slice dequantise + {Ts}-way cat of one layer's V [{B},{H},{Ts},{D}] with torch-CPU ops "
                                    f"({dl:.2f} s), the reference's own call structure (oracle/literal_loop.py)",
