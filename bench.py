@@ -236,6 +236,14 @@ def run_evict(args, rank, world, dev):
         }), flush=True)
 
 
+def _traffic(workload, key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), or None"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(workload, {}).get(key)
+    except Exception:
+        return None
+
+
 def run_attn(args, rank, world, dev):
     """One STEP = the attention of one decode step over the quantised store of every layer
     (kvq_decode_attn per layer: split-T partial kernel + merge), new token's exact K/V included.
@@ -308,7 +316,7 @@ def run_attn(args, rank, world, dev):
                        "bytes_per_step": int(step_bytes), "parallelism": f"batch-shard x{world}, no collective"},
             "roofline": {"kernel": "decode_attn_partial_k + decode_attn_merge_k (per layer call)", "bound": "hbm",
                          "achieved": round(layer_bytes / (layer_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(layer_bytes / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(layer_bytes / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": _traffic(args.workload, "decode_attn_per_layer_call"),
                          "algorithmic_bytes_per_launch": int(layer_bytes), "avg_launch_ms": round(layer_ms, 5),
                          "timer": "HIP events around the timed region / (steps * layers)"},
             "staged_path_sdpa": {"what": "torch SDPA over an fp16 copy of one layer's KV (what the staged decode runs)",
