@@ -314,7 +314,7 @@ def run_attn(args, rank, world, dev):
             "config": {"workload": args.workload, "shape_L_B_Hq_Hkv_T_D": [L, B, Hq, Hkv, T, D], "mode": mode,
                        "step": "one decode step: kvq_decode_attn per layer (2 launches each), host launch gaps included",
                        "bytes_per_step": int(step_bytes), "parallelism": f"batch-shard x{world}, no collective"},
-            "roofline": {"kernel": "decode_attn_partial_k + decode_attn_merge_k (per layer call)", "bound": "hbm",
+            "roofline": {"kernel": ("decode_attn_partial_mfma_k" if D == 128 and 3 <= Hq // Hkv <= 16 else "decode_attn_partial_k") + " + decode_attn_merge_k (per layer call)", "bound": "hbm",
                          "achieved": round(layer_bytes / (layer_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(layer_bytes / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": _traffic(args.workload, "decode_attn_per_layer_call"),
                          "algorithmic_bytes_per_launch": int(layer_bytes), "avg_launch_ms": round(layer_ms, 5),

@@ -13,12 +13,16 @@
 // rounding of the dequantised value to fp16 is skipped (<= 2^-11 relative per element), so the
 // result is within fp16 tolerance of the reference, not bit-identical (test tolerance 2e-3).
 //
-// Split-T flash decoding, HBM-bound byte streaming on VALU (no MFMA: one query row per head):
-//   decode_attn_partial_k  grid (split, kv head, batch), 256 threads, TS tokens per workgroup,
-//                          all Hq/Hkv query heads of the kv head in one pass (K/V read once);
-//                          writes (m, l, acc[D]) per (b, hq, split) to the workspace
-//   decode_attn_merge_k    grid (hq, batch): log-sum-exp merge of the splits and of the new token
-// 16 elements per lane per token: 16-byte (INT8) / 8-byte (INT4) loads, D/16 lanes per token.
+// Split-T flash decoding:
+//   decode_attn_partial_k       VALU kernel (any supported head_dim, <= 8 query heads per kv head):
+//                               grid (split, kv head, batch), 256 threads, TS tokens per workgroup, all
+//                               Hq/Hkv query heads of the kv head in one pass (K/V read once); 16
+//                               elements per lane per token: 16-byte (INT8) / 8-byte (INT4) loads
+//   decode_attn_partial_mfma_k  head_dim 128 with 3..16 query heads per kv head: both products on the
+//                               matrix cores, one wave per 128-token split (see its header below)
+//   both write (m, l) and acc[D] per (batch, query head, split) to the caller's workspace
+//   decode_attn_merge_k         grid (query head, batch): log-sum-exp merge of the splits and of the
+//                               exact new token
 #include <type_traits>
 
 #include "kvq_common.h"
@@ -101,7 +105,6 @@ template <>
 struct Raw16<8> {
   u32x4 w;
   __device__ inline void load(const uint8_t* p) { w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
-  __device__ inline void zero() { w = u32x4{0u, 0u, 0u, 0u}; }
   // exact f16 pairs of the int8 values: byte ^ 0x80 = q + 128; 0x6400 | u is the f16 1024 + u
   __device__ inline void to_h2(f16x2 (&kp)[8]) const {
     const f16x2 bias = {(f16)1152.0f, (f16)1152.0f};
@@ -130,7 +133,6 @@ template <>
 struct Raw16<4> {
   u32x2 w;
   __device__ inline void load(const uint8_t* p) { w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p)); }
-  __device__ inline void zero() { w = u32x2{0x88888888u, 0x88888888u}; }  // nibble 8 = value 0
   // nibble = q + 8, even element in the HIGH nibble (ops.py:61-63); pair order per 8 elements:
   // (e0,e2) (e4,e6) (e1,e3) (e5,e7) — convert_q16<true> arranges the query the same way
   __device__ inline void to_h2(f16x2 (&kp)[8]) const {
@@ -695,7 +697,7 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
 
 constexpr int kAttnMfmaTC = 128;
 
-constexpr int kAttnMaxSplit = 1024;
+constexpr int kAttnMaxSplit = 4096;  // merge: LDS weights + 16 (m, l) pairs per thread; T <= 512 Ki tokens at 128 per split
 
 // One workgroup per (query head, batch row): log-sum-exp merge of the splits and of the exact new
 // token. Split weights are computed once (one split per thread) and kept in LDS; the weighted sum
@@ -727,26 +729,16 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_k(const AttnArgs
   }
   const float* ml = a.ws + ((int64_t)b * a.Hq + hq) * a.nsplit * 2;
   const float* accb = a.ws + a.acc_off + ((int64_t)b * a.Hq + hq) * a.nsplit * a.D;
-  // this thread's splits: tid, tid + 256, ... (nsplit <= kAttnMaxSplit: at most 4)
-  float mloc[kAttnMaxSplit / kAttnBlock], lloc[kAttnMaxSplit / kAttnBlock];
+  // this thread's splits: tid, tid + 256, ...; (m, l) is read twice (second time from cache) rather
+  // than kept in a register array sized for kAttnMaxSplit
   float m_max = s_tok;
-#pragma unroll
-  for (int r = 0; r < kAttnMaxSplit / kAttnBlock; ++r) {
-    const uint32_t s = r * kAttnBlock + tid;
-    mloc[r] = s < a.nsplit ? ml[2 * s] : -INFINITY;
-    lloc[r] = s < a.nsplit ? ml[2 * s + 1] : 0.0f;
-    m_max = fmaxf(m_max, mloc[r]);
-  }
+  for (uint32_t s = tid; s < a.nsplit; s += kAttnBlock) m_max = fmaxf(m_max, ml[2 * s]);
   const float M = block_reduce(m_max, true);
   float lsum = 0.0f;
-#pragma unroll
-  for (int r = 0; r < kAttnMaxSplit / kAttnBlock; ++r) {
-    const uint32_t s = r * kAttnBlock + tid;
-    if (s < a.nsplit) {
-      const float w = __expf(mloc[r] - M);
-      s_wt[s] = w;
-      lsum += lloc[r] * w;
-    }
+  for (uint32_t s = tid; s < a.nsplit; s += kAttnBlock) {
+    const float w = __expf(ml[2 * s] - M);
+    s_wt[s] = w;
+    lsum += ml[2 * s + 1] * w;
   }
   const float w_new = has_new ? __expf(s_tok - M) : 0.0f;
   const float L = block_reduce(lsum, false) + w_new;  // the barriers inside also publish s_wt

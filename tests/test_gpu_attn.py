@@ -188,6 +188,14 @@ def test_decode_step_attends_then_appends(K, shape, kinds):
         K.decode_step(plan, qt, kn, vn, cap, out, ws, sm)
 
 
+def test_decode_attn_many_splits(K):
+    """Contexts long enough that the merge handles more than one split per thread (MFMA kernel:
+    313 splits of 128 tokens) and that the VALU kernel's splits hold several loop iterations."""
+    _run_case(K, 1, 8, 2, 40000, 128, "int8", "int4", "f16", True)
+    _run_case(K, 1, 2, 2, 40000, 64, "int4", "int8", "f16", True)
+    _run_case(K, 4, 8, 8, 9000, 32, "int8", "int8", "f16", False)  # 4 x 8 x 9000 tokens: 2 iterations per split
+
+
 def test_decode_attn_only_new_token(K):
     # empty store: the softmax has the new token alone, out == v_new
     _run_case(K, 2, 8, 4, 0, 64, "int8", "int4", "f16", True)

@@ -220,6 +220,20 @@ def test_fused_attention_decode_tracks_tuple_path(mode):
     assert res["total_new_tokens"] == 12 and res["est_kv_cache_mb_avg"] > 0
 
 
+def test_fused_attention_bf16_model():
+    """bf16 weights (the Llama-family dtype): the fused path quantises bf16 K/V (scales rounded to
+    bf16, like the reference's) and attends from bf16 queries; same cache size as the staged path and
+    mostly the same tokens (bf16 logits of a random-init model have near-ties, so not all)."""
+    from efficient_llm_inference_amd import KVCacheBenchmarker
+    from efficient_llm_inference_amd.benchmarking.offline import load_model
+    model, tok = load_model("gpt2-mini", "cuda", torch.bfloat16)
+    b = KVCacheBenchmarker(model, tok, device="cuda")
+    staged = b.generate_with_quantized_kv("<90>", 12, "mixed")
+    b.fused_attention = True
+    fused = b.generate_with_quantized_kv("<90>", 12, "mixed")
+    assert fused[1] == 12 and fused[2] == staged[2]
+
+
 def test_fused_attention_rejects_unsupported_head_dim(rig):
     """gpt2-tiny has head_dim 16: the fused kernel refuses it loudly (no silent fallback)."""
     from efficient_llm_inference_amd._lib import KvqError
