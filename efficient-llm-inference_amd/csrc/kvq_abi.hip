@@ -27,7 +27,7 @@ int check_launch(const char* what) {
 }
 
 Tunables& tunables() {
-  static Tunables t = {-1, 0, 0, 0, 0, 64, 64, 8, 0, 0, 0, 128, 1};
+  static Tunables t = {-1, 0, 0, 0, 0, 64, 64, 8, 0, 0, 0, 3, 128, 1};
   return t;
 }
 
@@ -54,6 +54,7 @@ int kvq_set_tunable(const char* key, int64_t value) {
   else if (!strcmp(key, "quant_nv")) t.quant_nv = value;
   else if (!strcmp(key, "quant_lds_pad")) t.quant_lds_pad = value;
   else if (!strcmp(key, "attn_force_valu")) t.attn_force_valu = value;
+  else if (!strcmp(key, "attn_mfma_min_nq")) t.attn_mfma_min_nq = value;
   else if (!strcmp(key, "attn_mfma_tc")) t.attn_mfma_tc = value;
   else {
     kvq::set_error("kvq_set_tunable: unknown key '%s'", key);
@@ -77,6 +78,7 @@ int64_t kvq_get_tunable(const char* key) {
   if (!strcmp(key, "quant_nv")) return t.quant_nv;
   if (!strcmp(key, "quant_lds_pad")) return t.quant_lds_pad;
   if (!strcmp(key, "attn_force_valu")) return t.attn_force_valu;
+  if (!strcmp(key, "attn_mfma_min_nq")) return t.attn_mfma_min_nq;
   if (!strcmp(key, "attn_mfma_tc")) return t.attn_mfma_tc;
   return 0;
 }

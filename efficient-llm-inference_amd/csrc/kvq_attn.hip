@@ -780,7 +780,8 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_k(const AttnArgs
 // kAttnMaxSplit splits
 static bool use_mfma(const kvq_attn_dims_t* d) {
   const int64_t nq = d->Hkv > 0 ? d->Hq / d->Hkv : 0;
-  return d->D == 128 && nq >= 3 && nq <= 16 && !tunables().attn_force_valu;
+  const int64_t min_nq = tunables().attn_mfma_min_nq > 0 ? tunables().attn_mfma_min_nq : 3;
+  return d->D == 128 && nq >= min_nq && nq <= 16 && !tunables().attn_force_valu;
 }
 static bool plan(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit) {
   if (use_mfma(d)) {  // one wave per split of TC tokens

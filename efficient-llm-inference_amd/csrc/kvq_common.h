@@ -45,6 +45,7 @@ struct Tunables {
   int64_t quant_no_regmax;       // 1 = keep the LDS abs-max in one-wave tiles (A-B)
   int64_t quant_lds_pad;         // A-B: bytes of unused dynamic LDS on the one-wave quantise launch (caps waves per CU)
   int64_t attn_force_valu;       // 1 = decode attention never takes the MFMA kernel (tests / A-B)
+  int64_t attn_mfma_min_nq;      // fewest query heads per kv head that take the MFMA kernel at head_dim 128 (default 3)
   int64_t attn_mfma_tc;          // tokens per one-wave split of the MFMA kernel: 128 (default) or 64
   int64_t nt_loads;              // non-temporal input loads in the quantise / pool kernels (default 1: +2-3 % on quantise)
 };

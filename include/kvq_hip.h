@@ -203,7 +203,7 @@ int kvq_decode_step(const void* q, int64_t q_stride_b, int64_t q_stride_h,
 /* ---- tuning knobs (benchmarks only; defaults are what ships) ----------------------------- */
 
 /* key: "dequant_variant" (0..30, -1 = shipped default), "dequant_grid" (workgroups, 0 = one chunk
- * each), "quant_force_two_pass" (0/1), "quant_direct_stores" (0/1), "pool_grid" (workgroup cap, 0 = none), "nt_loads" (0/1), "quant_block" (64|128|256), "quant_nv" (8|4|16), "quant_lds_pad" (bytes of unused dynamic LDS, occupancy A-B), "quant_no_regmax" (0/1), "pool_block" (64|128|256).
+ * each), "quant_force_two_pass" (0/1), "quant_direct_stores" (0/1), "pool_grid" (workgroup cap, 0 = none), "nt_loads" (0/1), "quant_block" (64|128|256), "quant_nv" (8|4|16), "quant_lds_pad" (bytes of unused dynamic LDS, occupancy A-B), "quant_no_regmax" (0/1), "pool_block" (64|128|256), "attn_force_valu" (0/1), "attn_mfma_min_nq" (default 3), "attn_mfma_tc" (128|64).
  * Returns 0, or KVQ_E_DIMS for an unknown key. Process-global. */
 int kvq_set_tunable(const char* key, int64_t value);
 int64_t kvq_get_tunable(const char* key);
