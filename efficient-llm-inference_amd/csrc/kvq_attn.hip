@@ -946,8 +946,13 @@ int kvq_decode_step(const void* q, int64_t q_sb, int64_t q_sh, const void* k_new
                            kn_sb, kn_sh, v_new, vn_sb, vn_sh, out, o_sb, o_sh, dtype, sm_scale, workspace,
                            workspace_floats, d, stream);
   if (rc) return rc;
-  // 2. quantise the new token into slot T (append_from_past, ops.py:323-330): one group, one token.
+  // 2. quantise the new token into slot T (append_from_past, ops.py:323-330): K and V in ONE launch
+  //    (quant_new_token_pair_k), or the regular calls for very large slices.
   //    Stream order keeps the attention's reads of [0, T) ahead of these writes to slot T.
+  if (launch_quant_new_token_pair(k_new, kn_sb, kn_sh, v_new, vn_sb, vn_sh, k_store + d->T * k_st->t, k_st->b, k_st->h,
+                                  k_scales + d->T, k_bits, v_store + d->T * v_st->t, v_st->b, v_st->h, v_scales + d->T,
+                                  v_bits, dtype, eps, d->B, d->Hkv, d->D, reinterpret_cast<hipStream_t>(stream)))
+    return check_launch(name);
   const kvq_dims_t qd = {1, d->B, d->Hkv, 1, d->D};
   const kvq_strides_t kin = {0, kn_sb, kn_sh, d->D}, vin = {0, vn_sb, vn_sh, d->D};
   float* absmax_ws = workspace;  // only the generic two-pass path uses it (1 float); the attention is already enqueued

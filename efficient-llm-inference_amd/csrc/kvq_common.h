@@ -51,6 +51,12 @@ struct Tunables {
 };
 Tunables& tunables();
 
+// kvq_quant.hip: K and V of one new token in one launch (false: slices too large, use the regular calls)
+bool launch_quant_new_token_pair(const void* k_new, int64_t kn_sb, int64_t kn_sh, const void* v_new, int64_t vn_sb,
+                                 int64_t vn_sh, uint8_t* k_slot, int64_t ks_b, int64_t ks_h, float* k_scale, int k_bits,
+                                 uint8_t* v_slot, int64_t vs_b, int64_t vs_h, float* v_scale, int v_bits, int dtype,
+                                 float eps, int64_t B, int64_t H, int64_t D, hipStream_t st);
+
 // ------------------------------------------------------------------ element conversion
 
 template <int DT>
