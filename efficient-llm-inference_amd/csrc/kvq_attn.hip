@@ -463,15 +463,21 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
   // V rows of every 32-token step, raw bytes: step 0 is requested with the K rows, the others as
   // soon as the K registers are free (all of them up front costs a wave per SIMD in registers)
   typedef typename std::conditional<VBITS == 8, u32x2, uint32_t>::type vraw_t;
-  const uint8_t* vb = a.v + (int64_t)b * a.v_sb + (int64_t)hk * a.v_sh + (int64_t)t0 * a.v_st + (VBITS == 8 ? 8 : 4) * x;
+  // K / V rows are read with BUFFER loads: descriptor (uniform base of this split's rows, size =
+  // the split's valid bytes) + one constant 32-bit lane offset + a scalar row offset, so a load costs no
+  // VALU address arithmetic, and rows past the split's end read as zeros instead of being clamped or
+  // branched around (their scores are masked to -inf, their P is exactly 0).
+  const bool full = nt == (uint32_t)TC;  // uniform
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(a.v + (int64_t)b * a.v_sb + (int64_t)hk * a.v_sh + (int64_t)t0 * a.v_st), 0,
+      (int)(nt * (uint32_t)a.v_st), 0x00020000);
+  const uint32_t v_lane = 4u * g * (uint32_t)a.v_st + (VBITS == 8 ? 8u : 4u) * x;
   auto load_v_step = [&](int s, vraw_t (&dst)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      // rows past the split's end are clamped to its last row, not skipped: their P is exactly 0
-      uint32_t tok = 32 * s + 16 * (j >> 2) + 4 * g + (j & 3);
-      tok = tok < nt ? tok : nt - 1u;
-      if constexpr (VBITS == 8) dst[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(vb + (int64_t)tok * a.v_st));
-      else dst[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(vb + (int64_t)tok * a.v_st));
+      const uint32_t row = 32 * s + 16 * (j >> 2) + (j & 3);  // + 4 g from the lane offset
+      if constexpr (VBITS == 8) dst[j] = __builtin_amdgcn_raw_buffer_load_b64(v_rsrc, v_lane, row * (uint32_t)a.v_st, 2);
+      else dst[j] = __builtin_amdgcn_raw_buffer_load_b32(v_rsrc, v_lane, row * (uint32_t)a.v_st, 2);
     }
   };
   // mixed mode (INT8 K, INT4 V): every later step fits the registers the K rows free (3 waves per SIMD
@@ -482,17 +488,18 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
   // ---- S = K Q^T: tile i, token row x -----------------------------------------------------------
   f32x4 sc[NT];
   f16x8 qb[4];
+  float svmax = 0.0f;
   {
     const uint8_t* kb = a.k + (int64_t)b * a.k_sb + (int64_t)hk * a.k_sh + (int64_t)t0 * a.k_st;
     constexpr int NL = KBITS == 8 ? 2 : 1;  // 16-byte loads per token row and lane
     u32x4 raw[NT][NL];
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(kb), 0, (int)(nt * (uint32_t)a.k_st), 0x00020000);
+    const uint32_t k_lane = x * (uint32_t)a.k_st + 16u * g;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      uint32_t tok = 16 * i + x;  // clamped like the V rows: those scores are masked to -inf below
-      tok = tok < nt ? tok : nt - 1u;
 #pragma unroll
       for (int c = 0; c < NL; ++c)
-        raw[i][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (int64_t)tok * a.k_st + 64 * c + 16 * g));
+        raw[i][c] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_lane, 16 * i * (uint32_t)a.k_st + 64 * c, 2);
     }
     load_v_step(0, vr[0]);
     // query and scales are REQUESTED here too, before anything waits: one round trip for all of it
@@ -528,11 +535,21 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
       ksv[r] = a.k_scale[t0 + ic];
       vsv[r] = a.v_scale[t0 + ic];
     }
+    // scores are kept in the log2 domain (one v_exp_f32 per probability); V scales are staged
+    // already divided by the split's largest one (the f16 pack of P needs the range, see header)
 #pragma unroll
     for (int r = 0; r < TC / kWave; ++r) {
       const uint32_t i = r * kWave + lane;
-      s_ks[i] = i < nt ? ksv[r] * a.sm_scale : 0.0f;
-      s_vs[i] = i < nt ? vsv[r] : 0.0f;
+      if (i >= nt) vsv[r] = 0.0f;
+      svmax = fmaxf(svmax, vsv[r]);
+    }
+    svmax = wave_fmax(svmax);
+    const float svn = svmax > 0.0f ? 1.0f / svmax : 0.0f;
+#pragma unroll
+    for (int r = 0; r < TC / kWave; ++r) {
+      const uint32_t i = r * kWave + lane;
+      s_ks[i] = ksv[r] * (a.sm_scale * 1.44269504088896341f);
+      s_vs[i] = vsv[r] * svn;
     }
     // ---- Q^T operands: head x, the 8 d's of this lane group per k-step (zeros for padded heads) ----
     {
@@ -591,35 +608,31 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
   }
   __syncthreads();  // one wave: publishes s_ks / s_vs
 
-  // ---- softmax over this split for head x; P scaled by sv / max sv --------------------------------
-  float m = -INFINITY, svmax = 0.0f;
-  f32x4 sv[NT];
+  // ---- softmax over this split for head x (log2 domain); P scaled by sv / max sv ------------------
+  float m = -INFINITY;
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const f32x4 ks = *reinterpret_cast<const f32x4*>(&s_ks[16 * i + 4 * g]);
-    sv[i] = *reinterpret_cast<const f32x4*>(&s_vs[16 * i + 4 * g]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool ok = (uint32_t)(16 * i + 4 * g + r) < nt;
-      sc[i][r] = ok ? sc[i][r] * ks[r] : -INFINITY;
+      sc[i][r] *= ks[r];
+      if (!full && (uint32_t)(16 * i + 4 * g + r) >= nt) sc[i][r] = -INFINITY;
       m = fmaxf(m, sc[i][r]);
-      svmax = fmaxf(svmax, sv[i][r]);
     }
   }
   m = fmaxf(m, __shfl_xor(m, 16));
   m = fmaxf(m, __shfl_xor(m, 32));
-  svmax = fmaxf(svmax, __shfl_xor(svmax, 16));
-  svmax = fmaxf(svmax, __shfl_xor(svmax, 32));
-  const float svn = svmax > 0.0f ? 1.0f / svmax : 0.0f;
   float l = 0.0f;
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+  for (int i = 0; i < NT; ++i) {
+    const f32x4 sv = *reinterpret_cast<const f32x4*>(&s_vs[16 * i + 4 * g]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float p = __expf(sc[i][r] - m);  // tokens past nt: exp(-inf) = 0
+      const float p = __builtin_amdgcn_exp2f(sc[i][r] - m);  // tokens past nt: exp2(-inf) = 0
       l += p;
-      sc[i][r] = p * (sv[i][r] * svn);
+      sc[i][r] = p * sv[r];
     }
+  }
   l += __shfl_xor(l, 16);
   l += __shfl_xor(l, 32);
 
@@ -674,7 +687,7 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
   // ---- workspace: (m, l) per head, acc[heads][D] --------------------------------------------------
   if (g == 0u && x < a.nq) {
     float* o = a.ws + (((int64_t)b * a.Hq + hk * a.nq + x) * a.nsplit + split) * 2;
-    o[0] = m;
+    o[0] = m * 0.693147180559945309f;  // back to the natural-log domain the merge kernel works in
     o[1] = l;
   }
 #pragma unroll
@@ -882,6 +895,10 @@ int kvq_decode_attn(const void* q, int64_t q_sb, int64_t q_sh, const uint8_t* k_
   if (d->T > 0 && (!aligned(k_store, kal) || k_st->b % kal || k_st->h % kal || k_st->t % kal || !aligned(v_store, val) ||
                    v_st->b % val || v_st->h % val || v_st->t % val)) {
     set_error("%s: store rows must be %d / %d byte aligned", name, kal, val);
+    return KVQ_E_DIMS;
+  }
+  if (d->T > 0 && (d->T * k_st->t >= (int64_t(1) << 31) || d->T * v_st->t >= (int64_t(1) << 31))) {
+    set_error("%s: one (batch, kv head) row of the store must stay below 2 GiB", name);
     return KVQ_E_DIMS;
   }
   if (!aligned(q, 16) || q_sb % 8 || q_sh % 8) {
