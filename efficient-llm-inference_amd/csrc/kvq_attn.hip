@@ -464,9 +464,10 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
   // soon as the K registers are free (all of them up front costs a wave per SIMD in registers)
   typedef typename std::conditional<VBITS == 8, u32x2, uint32_t>::type vraw_t;
   // K / V rows are read with BUFFER loads: descriptor (uniform base of this split's rows, size =
-  // the split's valid bytes) + one constant 32-bit lane offset + a scalar row offset, so a load costs no
-  // VALU address arithmetic, and rows past the split's end read as zeros instead of being clamped or
-  // branched around (their scores are masked to -inf, their P is exactly 0).
+  // the split's valid bytes) + a 32-bit offset (constant lane part + uniform row part: one v_add per
+  // load instead of 64-bit address arithmetic); rows past the split's end are out of the descriptor's
+  // range and read as zeros instead of being clamped or branched around (their scores are masked to
+  // -inf, their P is exactly 0), and nothing outside the split's rows is ever touched.
   const bool full = nt == (uint32_t)TC;  // uniform
   const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint8_t*>(a.v + (int64_t)b * a.v_sb + (int64_t)hk * a.v_sh + (int64_t)t0 * a.v_st), 0,
@@ -476,8 +477,9 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const uint32_t row = 32 * s + 16 * (j >> 2) + (j & 3);  // + 4 g from the lane offset
-      if constexpr (VBITS == 8) dst[j] = __builtin_amdgcn_raw_buffer_load_b64(v_rsrc, v_lane, row * (uint32_t)a.v_st, 2);
-      else dst[j] = __builtin_amdgcn_raw_buffer_load_b32(v_rsrc, v_lane, row * (uint32_t)a.v_st, 2);
+      // the row offset rides in the VECTOR offset (one v_add): that is the operand the range check covers
+      if constexpr (VBITS == 8) dst[j] = __builtin_amdgcn_raw_buffer_load_b64(v_rsrc, v_lane + row * (uint32_t)a.v_st, 0, 2);
+      else dst[j] = __builtin_amdgcn_raw_buffer_load_b32(v_rsrc, v_lane + row * (uint32_t)a.v_st, 0, 2);
     }
   };
   // mixed mode (INT8 K, INT4 V): every later step fits the registers the K rows free (3 waves per SIMD
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
     for (int i = 0; i < NT; ++i) {
 #pragma unroll
       for (int c = 0; c < NL; ++c)
-        raw[i][c] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_lane, 16 * i * (uint32_t)a.k_st + 64 * c, 2);
+        raw[i][c] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_lane + 16 * i * (uint32_t)a.k_st + 64 * c, 0, 2);
     }
     load_v_step(0, vr[0]);
     // query and scales are REQUESTED here too, before anything waits: one round trip for all of it
