@@ -164,8 +164,11 @@ def run_decode(args, rank, world, dev):
             "scaling": "weak", "vs_baseline": None, "dtype": "f16 model, u8/u4 KV", "data": "synthetic",
             "config": {"workload": args.workload, "arch": arch, "method": method, "fused_attention": bool(args.fused_attention),
                        "prompt_tokens": n_prompt,
-                       "new_tokens": n_new, "weights": "random-init (offline)", "layers": cfg.n_layer,
-                       "heads": cfg.n_head, "head_dim": cfg.n_embd // cfg.n_head,
+                       "new_tokens": n_new, "weights": "random-init (offline)",
+                       "layers": getattr(cfg, "num_hidden_layers", None) or cfg.n_layer,
+                       "heads": getattr(cfg, "num_attention_heads", None) or cfg.n_head,
+                       "kv_heads": getattr(cfg, "num_key_value_heads", None) or getattr(cfg, "num_attention_heads", None) or cfg.n_head,
+                       "head_dim": getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads,
                        "parallelism": f"prompt-shard x{world}, one all_reduce of counters"},
             "est_kv_cache_mb": round(res["est_kv_cache_mb_avg"], 3),
             "full_cache_tokens_per_sec": round(base["tokens_per_sec"], 2),

@@ -18,6 +18,12 @@ ARCH = {  # architectural constants of the named models (nothing is downloaded)
     "gpt2-tiny": dict(n_layer=2, n_head=4, n_embd=64, n_positions=256, vocab_size=260),
     "gpt2-mini": dict(n_layer=3, n_head=4, n_embd=256, n_positions=512, vocab_size=260),  # head_dim 64
 }
+LLAMA_ARCH = {  # grouped-query Llama-family shapes (random init): the grouping and head_dim of Llama-3-8B
+    "llama-mini": dict(hidden_size=1024, intermediate_size=2048, num_hidden_layers=4, num_attention_heads=8,
+                       num_key_value_heads=2, head_dim=128, vocab_size=260, max_position_embeddings=4096),
+    "llama-8b-4layers": dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=4, num_attention_heads=32,
+                             num_key_value_heads=8, head_dim=128, vocab_size=260, max_position_embeddings=32768),
+}
 
 
 class ByteTokenizer:
@@ -69,8 +75,16 @@ def load_model(name_or_path: str = "gpt2", device: str = "cuda", dtype: torch.dt
         tok = AutoTokenizer.from_pretrained(name_or_path, local_files_only=True)
         model = AutoModelForCausalLM.from_pretrained(name_or_path, local_files_only=True, dtype=dtype)
         return model.to(device).eval(), tok
+    if name_or_path in LLAMA_ARCH:
+        from transformers import LlamaConfig, LlamaForCausalLM
+        a = LLAMA_ARCH[name_or_path]
+        torch.manual_seed(seed)
+        cfg = LlamaConfig(bos_token_id=0, eos_token_id=256, pad_token_id=None, tie_word_embeddings=False, **a)
+        model = LlamaForCausalLM(cfg).to(device=device, dtype=dtype).eval()
+        return model, RepeatTokenizer(vocab_size=a["vocab_size"])
     if name_or_path not in ARCH:
-        raise ValueError(f"unknown architecture '{name_or_path}' (known: {sorted(ARCH)}); or pass a local path")
+        raise ValueError(f"unknown architecture '{name_or_path}' (known: {sorted(list(ARCH) + list(LLAMA_ARCH))}); "
+                         "or pass a local path")
     a = ARCH[name_or_path]
     torch.manual_seed(seed)
     cfg = GPT2Config(bos_token_id=0, eos_token_id=min(256, a["vocab_size"] - 1), **a)

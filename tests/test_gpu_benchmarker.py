@@ -220,6 +220,58 @@ def test_fused_attention_decode_tracks_tuple_path(mode):
     assert res["total_new_tokens"] == 12 and res["est_kv_cache_mb_avg"] > 0
 
 
+def test_llama_grouped_query_model_all_paths():
+    """A Llama-architecture model (random init; 8 query heads on 2 kv heads, head_dim 128 — Llama-3-8B's
+    grouping): the tuple, staged and fused-attention decodes all run through HF's Llama attention; the
+    fused path takes the MFMA kernel. Teacher-forced logits of the fused path track the tuple path."""
+    import efficient_llm_inference_amd as E
+    from efficient_llm_inference_amd import KVCacheBenchmarker
+    from efficient_llm_inference_amd.benchmarking import from_legacy_tuple, to_legacy_tuple
+    from efficient_llm_inference_amd.benchmarking.offline import load_model
+    from efficient_llm_inference_amd.quantization import fused_attention as FA
+    model, tok = load_model("llama-mini", "cuda", torch.float16)
+    bench = KVCacheBenchmarker(model, tok, device="cuda")
+    n_new = 16
+    bench.inplace_decode = False
+    a = bench.generate_with_quantized_kv("<200>", n_new, mode="mixed")
+    bench.inplace_decode = True
+    b = bench.generate_with_quantized_kv("<200>", n_new, mode="mixed")
+    assert a == b and a[1] == n_new  # staged == tuple, token for token
+    for method in ("sliding_window", "chunked_cache", "paged_attention", "budget_cache"):
+        res = bench.benchmark_method(["<150>"], method, max_new_tokens=4, window_size=64, chunk_size=16, keep_last=32,
+                                     block_size=16, old_budget=8)
+        assert res["total_new_tokens"] == 4, method
+    with torch.no_grad():
+        ids = tok("<200>", return_tensors="pt").input_ids.cuda()
+        out = model(input_ids=ids, use_cache=True)
+        kv = to_legacy_tuple(out.past_key_values)
+        assert kv[0][0].shape[1] == 2 and kv[0][0].shape[-1] == 128  # kv heads, head_dim
+        qc = E.QuantizedKVCache(len(kv), "mixed", incremental=False)
+        qc.init_from_prompt_past(kv)
+        logits = out.logits[:, -1, :]
+        ref_logits, toks = [], []
+        for _ in range(n_new):
+            nxt = torch.argmax(logits, dim=-1, keepdim=True)
+            toks.append(nxt)
+            out = model(input_ids=nxt, use_cache=True, past_key_values=from_legacy_tuple(qc.to_past_key_values()))
+            logits = out.logits[:, -1, :]
+            qc.append_from_past(to_legacy_tuple(out.past_key_values))
+            ref_logits.append(logits.float())
+        fc = FA.FusedQuantizedCache(len(kv), mode="mixed", reserve=ids.shape[-1] + n_new)
+        with FA.fused_attention(model, fc) as cache:
+            model(input_ids=ids, use_cache=True, past_key_values=cache)
+            worst = 0.0
+            for step, nxt in enumerate(toks):
+                got = model(input_ids=nxt, use_cache=True, past_key_values=cache).logits[:, -1, :].float()
+                worst = max(worst, float((got - ref_logits[step]).abs().max() / ref_logits[step].abs().max()))
+        assert worst < 2e-2, worst
+        assert torch.equal(fc.qcache._k.q[0, :, :, :ids.shape[-1]], qc._k.q[0, :, :, :ids.shape[-1]])
+        assert fc.estimated_bytes() == qc.estimated_bytes()
+    bench.fused_attention = True
+    c = bench.generate_with_quantized_kv("<200>", n_new, mode="mixed")
+    assert c[1] == n_new and c[2] == a[2]
+
+
 def test_fused_attention_bf16_model():
     """bf16 weights (the Llama-family dtype): the fused path quantises bf16 K/V (scales rounded to
     bf16, like the reference's) and attends from bf16 queries; same cache size as the staged path and
