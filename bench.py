@@ -52,6 +52,7 @@ ATTN = {  # name: (L, B, Hq, Hkv, T, D, mode)
     "llama3_8b_decode_attn_seq16k_b8": (32, 8, 32, 8, 16384, 128, "mixed"),
     "gpt2_decode_attn_seq1k": (12, 1, 12, 12, 1024, 64, "int8"),
     "llama2_7b_decode_attn_seq4k_b8": (32, 8, 32, 32, 4096, 128, "mixed"),  # multi-head (one query head per kv head)
+    "llama32_1b_decode_attn_seq16k_b8": (16, 8, 32, 8, 16384, 64, "mixed"),  # grouped-query at head_dim 64
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 BYTES_PER_ELT = {"int8": 3.0, "int4": 2.5}  # q read + fp16 write
@@ -318,7 +319,7 @@ def run_attn(args, rank, world, dev):
             "config": {"workload": args.workload, "shape_L_B_Hq_Hkv_T_D": [L, B, Hq, Hkv, T, D], "mode": mode,
                        "step": "one decode step: kvq_decode_attn per layer (2 launches each), host launch gaps included",
                        "bytes_per_step": int(step_bytes), "parallelism": f"batch-shard x{world}, no collective"},
-            "roofline": {"kernel": ("decode_attn_partial_mfma_k" if D == 128 and 3 <= Hq // Hkv <= 16 else "decode_attn_partial_k (or _mfma_k under --tunable attn_mfma_min_nq)") + " + decode_attn_merge_k (per layer call)", "bound": "hbm",
+            "roofline": {"kernel": ("decode_attn_partial_mfma_k" if D in (64, 128) and 3 <= Hq // Hkv <= 16 else "decode_attn_partial_k (or _mfma_k under --tunable attn_mfma_min_nq)") + " + decode_attn_merge_k (per layer call)", "bound": "hbm",
                          "achieved": round(layer_bytes / (layer_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(layer_bytes / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": _traffic(args.workload, "decode_attn_per_layer_call"),
                          "algorithmic_bytes_per_launch": int(layer_bytes), "avg_launch_ms": round(layer_ms, 5),

@@ -18,7 +18,7 @@
 //                               grid (split, kv head, batch), 256 threads, TS tokens per workgroup, all
 //                               Hq/Hkv query heads of the kv head in one pass (K/V read once); 16
 //                               elements per lane per token: 16-byte (INT8) / 8-byte (INT4) loads
-//   decode_attn_partial_mfma_k  head_dim 128 with 3..16 query heads per kv head: both products on the
+//   decode_attn_partial_mfma_k  head_dim 64 / 128 with 3..16 query heads per kv head: both products on the
 //                               matrix cores, one wave per 128-token split (see its header below)
 //   both write (m, l) and acc[D] per (batch, query head, split) to the caller's workspace
 //   decode_attn_merge_k         grid (query head, batch): log-sum-exp merge of the splits and of the
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_partial_k(const AttnAr
 }
 
 // ---------------------------------------------------------------------------- MFMA variant
-// Grouped-query heads (3..16 query heads per kv head, head_dim 128): the per-element VALU cost of
+// Grouped-query heads (3..16 query heads per kv head, head_dim 64 or 128): the per-element VALU cost of
 // the kernel above grows with the group size (one dot2 / fma per element and head) and it ends up
 // VALU-bound (llama 4:1 grouping: 2.1 TB/s at batch 8). Here both products run on the matrix
 // cores as 16x16x32 f16 MFMAs with the heads padded to 16 columns; the VALU only converts
@@ -448,10 +448,20 @@ __device__ inline void transpose4x4(uint32_t a0, uint32_t a1, uint32_t a2, uint3
   c[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
 }
 
-template <int KBITS, int VBITS, int TC>
+template <int KBITS, int VBITS, int TC, int HD>
 __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnArgs a) {
-  constexpr int NT = TC / 16;  // 16-token score tiles
-  constexpr int NS = TC / 32;  // 32-token P V steps
+  static_assert(HD == 64 || HD == 128, "head_dim of the MFMA kernel");
+  constexpr int NT = TC / 16;   // 16-token score tiles
+  constexpr int NS = TC / 32;   // 32-token P V steps
+  constexpr int KS = HD / 32;   // k-steps of the score product
+  constexpr int DVN = HD / 16;  // MFMAs (d values per lane) of a P V step
+  // K row bytes per lane group and load: 16 (8 for INT4 at head_dim 64); loads per row and lane
+  constexpr int CBK = (HD * KBITS / 8) / 4 < 16 ? 8 : 16;
+  constexpr int NL = (HD * KBITS / 8) / (4 * CBK);
+  constexpr int EPC = CBK * 8 / KBITS;  // elements per chunk
+  constexpr int SPL = EPC / 8;          // k-steps per load
+  static_assert(NL * SPL == KS, "k-step bookkeeping");
+  constexpr int VB = DVN * VBITS / 8;   // V bytes per lane and row: 8, 4 or 2
   __shared__ __attribute__((aligned(16))) float s_ks[TC];
   __shared__ __attribute__((aligned(16))) float s_vs[TC];
   const uint32_t lane = threadIdx.x;
@@ -460,9 +470,6 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
   const uint32_t t0 = split * TC;
   const uint32_t nt = a.T - t0 < (uint32_t)TC ? a.T - t0 : (uint32_t)TC;
 
-  // V rows of every 32-token step, raw bytes: step 0 is requested with the K rows, the others as
-  // soon as the K registers are free (all of them up front costs a wave per SIMD in registers)
-  typedef typename std::conditional<VBITS == 8, u32x2, uint32_t>::type vraw_t;
   // K / V rows are read with BUFFER loads: descriptor (uniform base of this split's rows, size =
   // the split's valid bytes) + a 32-bit offset (constant lane part + uniform row part: one v_add per
   // load instead of 64-bit address arithmetic); rows past the split's end are out of the descriptor's
@@ -472,62 +479,75 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
   const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint8_t*>(a.v + (int64_t)b * a.v_sb + (int64_t)hk * a.v_sh + (int64_t)t0 * a.v_st), 0,
       (int)(nt * (uint32_t)a.v_st), 0x00020000);
-  const uint32_t v_lane = 4u * g * (uint32_t)a.v_st + (VBITS == 8 ? 8u : 4u) * x;
-  auto load_v_step = [&](int s, vraw_t (&dst)[8]) {
+  const uint32_t v_lane = 4u * g * (uint32_t)a.v_st + (uint32_t)VB * x;
+  // V rows of a 32-token step, raw bytes (two dwords hold up to 8 bytes)
+  struct VRaw {
+    uint32_t w0, w1;
+  };
+  auto load_v_step = [&](int s, VRaw (&dst)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const uint32_t row = 32 * s + 16 * (j >> 2) + (j & 3);  // + 4 g from the lane offset
       // the row offset rides in the VECTOR offset (one v_add): that is the operand the range check covers
-      if constexpr (VBITS == 8) dst[j] = __builtin_amdgcn_raw_buffer_load_b64(v_rsrc, v_lane + row * (uint32_t)a.v_st, 0, 2);
-      else dst[j] = __builtin_amdgcn_raw_buffer_load_b32(v_rsrc, v_lane + row * (uint32_t)a.v_st, 0, 2);
+      const uint32_t off = v_lane + row * (uint32_t)a.v_st;
+      if constexpr (VB == 8) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(v_rsrc, off, 0, 2);
+        dst[j].w0 = v[0];
+        dst[j].w1 = v[1];
+      } else if constexpr (VB == 4) {
+        dst[j].w0 = __builtin_amdgcn_raw_buffer_load_b32(v_rsrc, off, 0, 2);
+        dst[j].w1 = 0u;
+      } else {
+        dst[j].w0 = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(v_rsrc, off, 0, 2);
+        dst[j].w1 = 0u;
+      }
     }
   };
   // mixed mode (INT8 K, INT4 V): every later step fits the registers the K rows free (3 waves per SIMD
   // either way); the other kind pairs keep one step of look-ahead
   constexpr bool V_EARLY = KBITS == 8 && VBITS == 4;
-  vraw_t vr[V_EARLY ? NS : 2][8];
+  VRaw vr[V_EARLY ? NS : 2][8];
 
   // ---- S = K Q^T: tile i, token row x -----------------------------------------------------------
   f32x4 sc[NT];
-  f16x8 qb[4];
+  f16x8 qb[KS];
   float svmax = 0.0f;
   {
     const uint8_t* kb = a.k + (int64_t)b * a.k_sb + (int64_t)hk * a.k_sh + (int64_t)t0 * a.k_st;
-    constexpr int NL = KBITS == 8 ? 2 : 1;  // 16-byte loads per token row and lane
-    u32x4 raw[NT][NL];
+    uint32_t raw[NT][NL][CBK / 4];
     const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(kb), 0, (int)(nt * (uint32_t)a.k_st), 0x00020000);
-    const uint32_t k_lane = x * (uint32_t)a.k_st + 16u * g;
+    const uint32_t k_lane = x * (uint32_t)a.k_st + (uint32_t)CBK * g;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
 #pragma unroll
-      for (int c = 0; c < NL; ++c)
-        raw[i][c] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_lane + 16 * i * (uint32_t)a.k_st + 64 * c, 0, 2);
+      for (int c = 0; c < NL; ++c) {
+        const uint32_t off = k_lane + 16 * i * (uint32_t)a.k_st + 4 * CBK * c;
+        if constexpr (CBK == 16) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, off, 0, 2);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) raw[i][c][j] = v[j];
+        } else {
+          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(k_rsrc, off, 0, 2);
+          raw[i][c][0] = v[0];
+          raw[i][c][1] = v[1];
+        }
+      }
     }
     load_v_step(0, vr[0]);
-    // query and scales are REQUESTED here too, before anything waits: one round trip for all of it
-    uint32_t w[16];
+    // query and scales are REQUESTED here too, before anything waits: one round trip for all of it.
+    // k-step (c, wi) of this lane group covers d = EPC (4 c + g) + 8 wi + j (INT4: j in pair order)
+    uint32_t w[4 * KS];
     {
       const uint32_t hx = x < a.nq ? x : 0u;  // padded heads read head 0 and are zeroed below
       const char* qp = reinterpret_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)(hk * a.nq + hx) * a.q_sh) * 2;
-      if constexpr (KBITS == 8) {  // k-step s: d = 64 (s >> 1) + 16 g + 8 (s & 1) + j
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const u32x4 lo = *reinterpret_cast<const u32x4*>(qp + (64 * c + 16 * g) * 2);
-          const u32x4 hi = *reinterpret_cast<const u32x4*>(qp + (64 * c + 16 * g + 8) * 2);
+      for (int c = 0; c < NL; ++c)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            w[8 * c + j] = lo[j];
-            w[8 * c + 4 + j] = hi[j];
-          }
+        for (int wi = 0; wi < SPL; ++wi) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(qp + (EPC * (4 * c + g) + 8 * wi) * 2);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[4 * (c * SPL + wi) + j] = v[j];
         }
-      } else {  // k-step s: d = 32 g + 8 s + (0,2,4,6,1,3,5,7)[j]
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const u32x4 v = *reinterpret_cast<const u32x4*>(qp + (32 * g + 8 * c) * 2);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) w[4 * c + j] = v[j];
-        }
-      }
     }
     float ksv[TC / kWave], vsv[TC / kWave];
 #pragma unroll
@@ -557,14 +577,14 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
     {
       if (a.dtype == KVQ_BF16) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < 4 * KS; ++j) {
           const f16x2 h = {(f16)__uint_as_float(w[j] << 16), (f16)__uint_as_float(w[j] & 0xFFFF0000u)};
           w[j] = h2_bits(h);
         }
       }
       if constexpr (KBITS == 4) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < KS; ++c) {
           const uint32_t w0 = w[4 * c], w1 = w[4 * c + 1], w2 = w[4 * c + 2], w3 = w[4 * c + 3];
           w[4 * c + 0] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);  // (q0, q2)
           w[4 * c + 1] = __builtin_amdgcn_perm(w3, w2, 0x05040100u);  // (q4, q6)
@@ -574,30 +594,32 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
       }
       if (x >= a.nq) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) w[j] = 0u;
+        for (int j = 0; j < 4 * KS; ++j) w[j] = 0u;
       }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) qb[c] = pack_h8(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
+      for (int c = 0; c < KS; ++c) qb[c] = pack_h8(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       f32x4 c4 = {0.0f, 0.0f, 0.0f, 0.0f};
-      if constexpr (KBITS == 8) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          uint32_t h[8];
+      for (int c = 0; c < NL; ++c) {
+        if constexpr (KBITS == 8) {  // two words = 8 elements = one k-step
 #pragma unroll
-          for (int j = 0; j < 4; ++j) bytes_to_h4<128>(raw[i][c][j] ^ 0x80808080u, h[2 * j], h[2 * j + 1]);
-          c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack_h8(h[0], h[1], h[2], h[3]), qb[2 * c], c4, 0, 0, 0);
-          c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack_h8(h[4], h[5], h[6], h[7]), qb[2 * c + 1], c4, 0, 0, 0);
-        }
-      } else {
+          for (int wi = 0; wi < SPL; ++wi) {
+            uint32_t h[4];
+            bytes_to_h4<128>(raw[i][c][2 * wi] ^ 0x80808080u, h[0], h[1]);
+            bytes_to_h4<128>(raw[i][c][2 * wi + 1] ^ 0x80808080u, h[2], h[3]);
+            c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack_h8(h[0], h[1], h[2], h[3]), qb[c * SPL + wi], c4, 0, 0, 0);
+          }
+        } else {  // one word = 8 elements = one k-step
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {  // one 4-byte word = 8 elements = one k-step
-          uint32_t h[4];
-          bytes_to_h4<8>((raw[i][0][j] >> 4) & 0x0F0F0F0Fu, h[0], h[1]);  // (e0,e2) (e4,e6)
-          bytes_to_h4<8>(raw[i][0][j] & 0x0F0F0F0Fu, h[2], h[3]);         // (e1,e3) (e5,e7)
-          c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack_h8(h[0], h[1], h[2], h[3]), qb[j], c4, 0, 0, 0);
+          for (int wi = 0; wi < SPL; ++wi) {
+            uint32_t h[4];
+            bytes_to_h4<8>((raw[i][c][wi] >> 4) & 0x0F0F0F0Fu, h[0], h[1]);  // (e0,e2) (e4,e6)
+            bytes_to_h4<8>(raw[i][c][wi] & 0x0F0F0F0Fu, h[2], h[3]);         // (e1,e3) (e5,e7)
+            c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack_h8(h[0], h[1], h[2], h[3]), qb[c * SPL + wi], c4, 0, 0, 0);
+          }
         }
       }
       sc[i] = c4;
@@ -638,10 +660,10 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
   l += __shfl_xor(l, 16);
   l += __shfl_xor(l, 32);
 
-  // ---- O = P V --------------------------------------------------------------------------------------
-  f32x4 acc[8];
+  // ---- O = P V: column x <-> d = DVN x + e(c) for MFMA c ---------------------------------------------
+  f32x4 acc[DVN];
 #pragma unroll
-  for (int n = 0; n < 8; ++n) acc[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int n = 0; n < DVN; ++n) acc[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -649,32 +671,34 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
         if (s + 1 < NS) load_v_step(s + 1, vr[(s + 1) & 1]);
       }
       const int vi = V_EARLY ? s : (s & 1);  // constant after unrolling
-      // the lane's 8 token rows of this step, 8 elements each
-      uint32_t lo[8], hi[8];  // INT8: bytes d0..d3 / d4..d7 (sign flipped); INT4: elements 0,2,4,6 / 1,3,5,7
+      // the lane's 8 token rows of this step as byte images, 4 elements per dword:
+      //   head_dim 128: img[0] = elements 0..3 (INT4: 0,2,4,6), img[1] = 4..7 (INT4: 1,3,5,7)
+      //   head_dim 64:  img[0] = elements 0..3 (INT4: 0,2,1,3)
+      uint32_t img[DVN / 4][8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if constexpr (VBITS == 8) {
-          lo[j] = vr[vi][j][0] ^ 0x80808080u;
-          hi[j] = vr[vi][j][1] ^ 0x80808080u;
+        const uint32_t w0 = vr[vi][j].w0, w1 = vr[vi][j].w1;
+        if constexpr (HD == 128 && VBITS == 8) {
+          img[0][j] = w0 ^ 0x80808080u;
+          img[1][j] = w1 ^ 0x80808080u;
+        } else if constexpr (HD == 128) {
+          img[0][j] = (w0 >> 4) & 0x0F0F0F0Fu;
+          img[1][j] = w0 & 0x0F0F0F0Fu;
+        } else if constexpr (VBITS == 8) {
+          img[0][j] = w0 ^ 0x80808080u;
         } else {
-          lo[j] = (vr[vi][j] >> 4) & 0x0F0F0F0Fu;
-          hi[j] = vr[vi][j] & 0x0F0F0F0Fu;
+          img[0][j] = ((w0 >> 4) & 0x0F0Fu) | ((w0 & 0x0F0Fu) << 16);
         }
       }
       const f16x8 pa = pack_h8(Elem<KVQ_F16>::pack2(sc[2 * s][0], sc[2 * s][1]), Elem<KVQ_F16>::pack2(sc[2 * s][2], sc[2 * s][3]),
                                Elem<KVQ_F16>::pack2(sc[2 * s + 1][0], sc[2 * s + 1][1]),
                                Elem<KVQ_F16>::pack2(sc[2 * s + 1][2], sc[2 * s + 1][3]));
-      uint32_t ca[4], cb[4];
       constexpr int BIAS = VBITS == 8 ? 128 : 8;
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        if (half == 0) {
-          transpose4x4(lo[0], lo[1], lo[2], lo[3], ca);  // tokens j = 0..3
-          transpose4x4(lo[4], lo[5], lo[6], lo[7], cb);  // tokens j = 4..7
-        } else {
-          transpose4x4(hi[0], hi[1], hi[2], hi[3], ca);
-          transpose4x4(hi[4], hi[5], hi[6], hi[7], cb);
-        }
+      for (int half = 0; half < DVN / 4; ++half) {
+        uint32_t ca[4], cb[4];
+        transpose4x4(img[half][0], img[half][1], img[half][2], img[half][3], ca);  // tokens j = 0..3
+        transpose4x4(img[half][4], img[half][5], img[half][6], img[half][7], cb);  // tokens j = 4..7
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
           uint32_t h[4];
@@ -696,16 +720,18 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
   for (int r = 0; r < 4; ++r) {
     const uint32_t h = 4 * g + r;
     if (h < a.nq) {
-      // column index c of the MFMA set: INT8 d = 8x + c; INT4 c < 4 -> element 2c, else 2(c-4)+1
-      float o8[8];
+      // element e of MFMA c. head_dim 128: INT8 c; INT4 c < 4 ? 2c : 2(c-4)+1. head_dim 64: INT8 c; INT4 0,2,1,3
+      float o8[DVN];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int e = VBITS == 8 ? c : (c < 4 ? 2 * c : 2 * (c - 4) + 1);
+      for (int c = 0; c < DVN; ++c) {
+        int e = c;
+        if constexpr (VBITS == 4 && HD == 128) e = c < 4 ? 2 * c : 2 * (c - 4) + 1;
+        if constexpr (VBITS == 4 && HD == 64) e = c == 1 ? 2 : (c == 2 ? 1 : c);
         o8[e] = acc[c][r] * svmax;
       }
-      float* dst = a.ws + a.acc_off + (((int64_t)b * a.Hq + hk * a.nq + h) * a.nsplit + split) * a.D + 8 * x;
-      *reinterpret_cast<f32x4*>(dst) = f32x4{o8[0], o8[1], o8[2], o8[3]};
-      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{o8[4], o8[5], o8[6], o8[7]};
+      float* dst = a.ws + a.acc_off + (((int64_t)b * a.Hq + hk * a.nq + h) * a.nsplit + split) * a.D + DVN * x;
+#pragma unroll
+      for (int c = 0; c < DVN; c += 4) *reinterpret_cast<f32x4*>(dst + c) = f32x4{o8[c], o8[c + 1], o8[c + 2], o8[c + 3]};
     }
   }
 }
@@ -796,11 +822,11 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_k(const AttnArgs
 static bool use_mfma(const kvq_attn_dims_t* d) {
   const int64_t nq = d->Hkv > 0 ? d->Hq / d->Hkv : 0;
   const int64_t min_nq = tunables().attn_mfma_min_nq > 0 ? tunables().attn_mfma_min_nq : 3;
-  return d->D == 128 && nq >= min_nq && nq <= 16 && !tunables().attn_force_valu;
+  return (d->D == 128 || d->D == 64) && nq >= min_nq && nq <= 16 && !tunables().attn_force_valu;
 }
 static bool plan(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit) {
   if (use_mfma(d)) {  // one wave per split of TC tokens
-    int64_t tc = tunables().attn_mfma_tc == 64 ? 64 : kAttnMfmaTC;
+    int64_t tc = tunables().attn_mfma_tc == 64 && d->D == 128 ? 64 : kAttnMfmaTC;
     if ((d->T + tc - 1) / tc > kAttnMaxSplit) tc = kAttnMfmaTC;
     *ts = (uint32_t)tc;
     *nsplit = (uint32_t)((d->T + tc - 1) / tc);
@@ -822,8 +848,9 @@ template <int KBITS, int VBITS>
 static void launch_partial(const AttnArgs& a, hipStream_t st) {
   const dim3 grid(a.nsplit, a.Hkv, a.B);
   if (a.mfma) {
-    if (a.TS == 64u) hipLaunchKernelGGL((decode_attn_partial_mfma_k<KBITS, VBITS, 64>), grid, dim3(kWave), 0, st, a);
-    else hipLaunchKernelGGL((decode_attn_partial_mfma_k<KBITS, VBITS, kAttnMfmaTC>), grid, dim3(kWave), 0, st, a);
+    if (a.D == 64u) hipLaunchKernelGGL((decode_attn_partial_mfma_k<KBITS, VBITS, kAttnMfmaTC, 64>), grid, dim3(kWave), 0, st, a);
+    else if (a.TS == 64u) hipLaunchKernelGGL((decode_attn_partial_mfma_k<KBITS, VBITS, 64, 128>), grid, dim3(kWave), 0, st, a);
+    else hipLaunchKernelGGL((decode_attn_partial_mfma_k<KBITS, VBITS, kAttnMfmaTC, 128>), grid, dim3(kWave), 0, st, a);
     return;
   }
   if (a.nq == 1) hipLaunchKernelGGL((decode_attn_partial_k<KBITS, VBITS, 1>), grid, dim3(kAttnBlock), 0, st, a);
@@ -860,7 +887,7 @@ int kvq_decode_attn(const void* q, int64_t q_sb, int64_t q_sh, const uint8_t* k_
   }
   if (d->B <= 0 || d->Hq <= 0 || d->Hkv <= 0 || d->T < 0 || d->B >= (1 << 16) || d->Hkv >= (1 << 16) ||
       d->T >= (int64_t(1) << 31) || d->Hq % d->Hkv != 0 || d->Hq / d->Hkv > (use_mfma(d) ? 16 : 8)) {
-    set_error("%s: bad dims B=%lld Hq=%lld Hkv=%lld T=%lld (need Hq %% Hkv == 0, Hq / Hkv <= 8, or <= 16 at head_dim 128)", name, (long long)d->B,
+    set_error("%s: bad dims B=%lld Hq=%lld Hkv=%lld T=%lld (need Hq %% Hkv == 0, Hq / Hkv <= 8, or <= 16 at head_dim 64 / 128)", name, (long long)d->B,
               (long long)d->Hq, (long long)d->Hkv, (long long)d->T);
     return KVQ_E_DIMS;
   }

@@ -23,7 +23,7 @@ Numerics: fp32 accumulation over exact integer x fp16 products; the rounding of 
 value to fp16 that the reference's tuple path performs is skipped, so logits agree within fp16
 tolerance, not bit-for-bit (tests/test_gpu_attn.py, tests/test_gpu_benchmarker.py).
 Limits (fail loudly): fp16 / bf16 models, head_dim in {32, 64, 128, 256}, at most 8 query heads
-per kv head, no padding mask during decode, no chunked prefill into a non-empty cache.
+per kv head (16 at head_dim 64 / 128), no padding mask during decode, no chunked prefill into a non-empty cache.
 """
 from __future__ import annotations
 

@@ -158,7 +158,7 @@ int kvq_gather_tokens(const void* in_base, const void* const* in_ptrs, const kvq
 /* ---- decode attention over the quantised store -------------------------- */
 
 typedef struct {
-  int64_t B, Hq, Hkv, T, D; /* T = stored (quantised) tokens attended; Hq % Hkv == 0, Hq/Hkv <= 8 */
+  int64_t B, Hq, Hkv, T, D; /* T = stored (quantised) tokens attended; Hq % Hkv == 0, Hq/Hkv <= 8 (<= 16 at head_dim 64 / 128) */
 } kvq_attn_dims_t;
 
 /* Workspace floats kvq_decode_attn needs for these dims (-1 on bad dims). */

@@ -102,6 +102,8 @@ CASES = [  # B, Hq, Hkv, T, D
     (1, 32, 8, 5000, 128),   # several splits of different fill
     (1, 16, 1, 300, 128),    # 16 query heads on one kv head: every MFMA column in use
     (2, 6, 2, 200, 128),     # 3 per kv head at head_dim 128: MFMA kernel with padded heads
+    (1, 32, 8, 700, 64),     # Llama-3.2-1B grouping: 4 per kv head at head_dim 64 (MFMA kernel, 4 d per lane)
+    (2, 16, 2, 131, 64),     # 8 per kv head at head_dim 64, ragged split
 ]
 
 
@@ -112,7 +114,7 @@ def test_decode_attn_matches_oracle(K, case, kinds):
         _run_case(K, *case, kinds[0], kinds[1], dtype, with_new)
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if c[4] == 128 and 3 <= c[1] // c[2] <= 8])
+@pytest.mark.parametrize("case", [c for c in CASES if c[4] in (64, 128) and 3 <= c[1] // c[2] <= 8])
 @pytest.mark.parametrize("kinds", [("int8", "int4"), ("int4", "int8")])
 def test_decode_attn_valu_kernel_on_grouped_heads(K, case, kinds):
     """head_dim 128 with 3..16 query heads per kv head takes the MFMA kernel by default; the VALU
