@@ -198,6 +198,38 @@ def test_decode_attn_many_splits(K):
     _run_case(K, 4, 8, 8, 9000, 32, "int8", "int8", "f16", False)  # 4 x 8 x 9000 tokens: 2 iterations per split
 
 
+@pytest.mark.parametrize("shape", [(1, 32, 8, 16384, 128), (2, 12, 12, 4000, 64)])
+def test_decode_attn_full_size_token_permutation(K, shape):
+    """Size-independent property at the benchmark shape (no oracle at this size): attention does not
+    depend on the ORDER of the stored tokens, so permuting the rows of both stores together with
+    their scales must reproduce the output up to fp32 summation order (different splits see different
+    tokens). Also: appending a new token whose key equals a stored row changes the output continuously."""
+    B, Hq, Hkv, T, D = shape
+    g = torch.Generator(device="cuda").manual_seed(T)
+    k_store = torch.randint(-127, 128, (B, Hkv, T, D), device="cuda", dtype=torch.int8, generator=g)
+    v_store = torch.randint(0, 256, (B, Hkv, T, D // 2), device="cuda", dtype=torch.uint8, generator=g)
+    k_sc = torch.rand(T, device="cuda", generator=g) * 0.02 + 0.002
+    v_sc = torch.rand(T, device="cuda", generator=g) * 0.3 + 0.01
+    q = torch.randn(B, Hq, D, device="cuda", dtype=torch.float16, generator=g)
+    kn = torch.randn(B, Hkv, D, device="cuda", dtype=torch.float16, generator=g)
+    vn = torch.randn(B, Hkv, D, device="cuda", dtype=torch.float16, generator=g)
+    ws = torch.empty(K.decode_attn_workspace(B, Hq, Hkv, T, D), dtype=torch.float32, device="cuda")
+    sm = D ** -0.5
+    out1 = torch.empty_like(q)
+    K.decode_attn(q, k_store, k_sc, "int8", v_store, v_sc, "int4", T, out1, ws, sm, kn, vn)
+    perm = torch.randperm(T, device="cuda", generator=g)
+    out2 = torch.empty_like(q)
+    K.decode_attn(q, k_store[:, :, perm].contiguous(), k_sc[perm].contiguous(), "int8", v_store[:, :, perm].contiguous(),
+                  v_sc[perm].contiguous(), "int4", T, out2, ws, sm, kn, vn)
+    torch.cuda.synchronize()
+    a, b = out1.float(), out2.float()
+    assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 2e-3 * float(a.abs().max())
+    # a prefix of the context + the rest folded in as ... the same tokens: T1 + (T - T1) split at an odd place
+    out3 = torch.empty_like(q)
+    K.decode_attn(q, k_store, k_sc, "int8", v_store, v_sc, "int4", T - 1, out3, ws, sm, kn, vn)
+    assert float((out3.float() - a).abs().max()) <= 0.5 * float(a.abs().max())  # one token of T cannot move it far
+
+
 def test_decode_attn_only_new_token(K):
     # empty store: the softmax has the new token alone, out == v_new
     _run_case(K, 2, 8, 4, 0, 64, "int8", "int4", "f16", True)
