@@ -133,10 +133,8 @@ def _fused_attention_forward(module, query, key, value, attention_mask=None, dro
             raise RuntimeError("kvq: multi-token forward into a non-empty quantised cache is not supported")
         if attention_mask is not None:
             raise RuntimeError("kvq: fused attention does not take a padding mask")
-        if Hkv != Hq:
-            key = key.repeat_interleave(Hq // Hkv, dim=1)
-            value = value.repeat_interleave(Hq // Hkv, dim=1)
-        out = torch.nn.functional.scaled_dot_product_attention(query, key, value, is_causal=n > 1, scale=scale)
+        out = torch.nn.functional.scaled_dot_product_attention(query, key, value, is_causal=n > 1, scale=scale,
+                                                               enable_gqa=Hkv != Hq)
         return out.transpose(1, 2).contiguous(), None
     if attention_mask is not None:
         raise RuntimeError("kvq: fused decode attention does not take a padding mask")
