@@ -30,15 +30,20 @@ def main():
     prompts = ["<128>", "<256>", "<384>"] if not os.path.isdir(name) else [
         "The future of artificial intelligence is", "Efficient inference for large language models requires"]
     ref_text, _ = bench.generate_with_cache(prompts[0], cfg.max_new_tokens)
-    print(f"{'method':<12} {'tok/s':>9} {'KV MB':>9} {'similarity':>11}")
-    for method in ("full_cache", "quant_int8", "quant_mixed", "quant_int4"):
+    print(f"{'method':<18} {'tok/s':>9} {'KV MB':>9} {'similarity':>11}")
+    for method, fused in (("full_cache", False), ("quant_int8", False), ("quant_mixed", False), ("quant_int4", False),
+                          ("quant_int8", True), ("quant_mixed", True), ("quant_int4", True)):
+        # fused: the model attends straight over the INT8 / INT4 store (no fp16 copy of the cache)
+        bench.fused_attention = fused
         res = bench.benchmark_method(prompts, method=method, max_new_tokens=cfg.max_new_tokens)
         if method == "full_cache":
             sim = 1.0
         else:
             text, _, _ = bench.generate_with_quantized_kv(prompts[0], cfg.max_new_tokens, mode=method[6:])
             sim = text_similarity(ref_text, text)
-        print(f"{method:<12} {res['tokens_per_sec']:>9.1f} {res['est_kv_cache_mb_avg']:>9.3f} {sim:>11.3f}")
+        label = method + ("+fused" if fused else "")
+        print(f"{label:<18} {res['tokens_per_sec']:>9.1f} {res['est_kv_cache_mb_avg']:>9.3f} {sim:>11.3f}")
+    bench.fused_attention = False
 
 
 if __name__ == "__main__":
