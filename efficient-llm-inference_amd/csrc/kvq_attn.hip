@@ -743,8 +743,18 @@ constexpr int kAttnMaxSplit = 4096;  // merge: LDS weights + 16 (m, l) pairs per
 // One workgroup per (query head, batch row): log-sum-exp merge of the splits and of the exact new
 // token. Split weights are computed once (one split per thread) and kept in LDS; the weighted sum
 // runs 256 / D split groups wide with independent loads.
-__global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_k(const AttnArgs a) {
+// With fuse_quant, two extra workgroups (blockIdx.x = Hq, Hq + 1 of batch row 0) quantise the new
+// token's K / V into slot T of the stores (quant_new_token_block): nothing in this launch reads that
+// slot, and the partial kernel that read [0, T) has finished, so a decode step is two launches.
+__global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_k(const AttnArgs a, const NewTokenArgs nt, const int fuse_quant) {
   __shared__ float s_red[kAttnBlock / kWave];
+  if (blockIdx.x >= a.Hq) {
+    if (fuse_quant && blockIdx.y == 0u) {
+      if (a.dtype == KVQ_F16) quant_new_token_block<KVQ_F16>(nt, blockIdx.x - a.Hq, s_red);
+      else quant_new_token_block<KVQ_BF16>(nt, blockIdx.x - a.Hq, s_red);
+    }
+    return;
+  }
   __shared__ float s_wt[kAttnMaxSplit];
   __shared__ __attribute__((aligned(16))) float s_out[kAttnBlock * 4];
   const uint32_t tid = threadIdx.x;
@@ -874,13 +884,15 @@ int64_t kvq_decode_attn_workspace(const kvq_attn_dims_t* d) {
   return (rows * 2 + 3) / 4 * 4 + rows * d->D;
 }
 
-int kvq_decode_attn(const void* q, int64_t q_sb, int64_t q_sh, const uint8_t* k_store, const kvq_strides_t* k_st,
-                    const float* k_scales, int k_bits, const uint8_t* v_store, const kvq_strides_t* v_st,
-                    const float* v_scales, int v_bits, const void* k_new, int64_t kn_sb, int64_t kn_sh,
-                    const void* v_new, int64_t vn_sb, int64_t vn_sh, void* out, int64_t o_sb, int64_t o_sh, int dtype,
-                    float sm_scale, float* workspace, int64_t workspace_floats, const kvq_attn_dims_t* d,
-                    void* stream) {
-  const char* name = "kvq_decode_attn";
+}  // extern "C"
+
+// shared body of kvq_decode_attn / kvq_decode_step; nt != nullptr: quantise the new token in the merge launch
+static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64_t q_sh, const uint8_t* k_store,
+                            const kvq_strides_t* k_st, const float* k_scales, int k_bits, const uint8_t* v_store,
+                            const kvq_strides_t* v_st, const float* v_scales, int v_bits, const void* k_new,
+                            int64_t kn_sb, int64_t kn_sh, const void* v_new, int64_t vn_sb, int64_t vn_sh, void* out,
+                            int64_t o_sb, int64_t o_sh, int dtype, float sm_scale, float* workspace,
+                            int64_t workspace_floats, const kvq_attn_dims_t* d, void* stream, const NewTokenArgs* nt) {
   if (!d || !q || !out) {
     set_error("%s: NULL q / out / dims", name);
     return KVQ_E_NULL;
@@ -972,8 +984,23 @@ int kvq_decode_attn(const void* q, int64_t q_sb, int64_t q_sh, const uint8_t* k_
     const int rc = check_launch(name);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(decode_attn_merge_k, dim3(a.Hq, a.B), dim3(kAttnBlock), 0, st, a);
+  NewTokenArgs none = {};
+  hipLaunchKernelGGL(decode_attn_merge_k, dim3(a.Hq + (nt ? 2u : 0u), a.B), dim3(kAttnBlock), 0, st, a, nt ? *nt : none,
+                     nt ? 1 : 0);
   return check_launch(name);
+}
+
+extern "C" {
+
+int kvq_decode_attn(const void* q, int64_t q_sb, int64_t q_sh, const uint8_t* k_store, const kvq_strides_t* k_st,
+                    const float* k_scales, int k_bits, const uint8_t* v_store, const kvq_strides_t* v_st,
+                    const float* v_scales, int v_bits, const void* k_new, int64_t kn_sb, int64_t kn_sh,
+                    const void* v_new, int64_t vn_sb, int64_t vn_sh, void* out, int64_t o_sb, int64_t o_sh, int dtype,
+                    float sm_scale, float* workspace, int64_t workspace_floats, const kvq_attn_dims_t* d,
+                    void* stream) {
+  return decode_attn_impl("kvq_decode_attn", q, q_sb, q_sh, k_store, k_st, k_scales, k_bits, v_store, v_st, v_scales, v_bits,
+                          k_new, kn_sb, kn_sh, v_new, vn_sb, vn_sh, out, o_sb, o_sh, dtype, sm_scale, workspace,
+                          workspace_floats, d, stream, nullptr);
 }
 
 
@@ -987,18 +1014,26 @@ int kvq_decode_step(const void* q, int64_t q_sb, int64_t q_sh, const void* k_new
     set_error("%s: NULL argument", name);
     return KVQ_E_NULL;
   }
-  // 1. attention over the T stored tokens + the exact new token
+  // The new token's K / V go into slot T (append_from_past, ops.py:323-330). Small slices (the usual
+  // case) are quantised by two extra workgroups of the attention's merge launch: a decode step is two
+  // launches. Nothing reads slot T in that launch, and the partial kernel has read [0, T) before it.
+  if (d->B * d->Hkv * d->D <= 65536 && (dtype == KVQ_F16 || dtype == KVQ_BF16) && d->T >= 0) {
+    NewTokenArgs nt;
+    nt.x[0] = k_new; nt.xs_b[0] = kn_sb; nt.xs_h[0] = kn_sh;
+    nt.x[1] = v_new; nt.xs_b[1] = vn_sb; nt.xs_h[1] = vn_sh;
+    nt.q[0] = k_store + d->T * k_st->t; nt.qs_b[0] = k_st->b; nt.qs_h[0] = k_st->h; nt.scale[0] = k_scales + d->T; nt.bits[0] = k_bits;
+    nt.q[1] = v_store + d->T * v_st->t; nt.qs_b[1] = v_st->b; nt.qs_h[1] = v_st->h; nt.scale[1] = v_scales + d->T; nt.bits[1] = v_bits;
+    nt.B = (uint32_t)d->B; nt.H = (uint32_t)d->Hkv; nt.D = (uint32_t)d->D; nt.eps = eps;
+    return decode_attn_impl(name, q, q_sb, q_sh, k_store, k_st, k_scales, k_bits, v_store, v_st, v_scales, v_bits, k_new, kn_sb,
+                            kn_sh, v_new, vn_sb, vn_sh, out, o_sb, o_sh, dtype, sm_scale, workspace, workspace_floats, d,
+                            stream, &nt);
+  }
+  // large slices: attention first, then the regular quantise calls (stream order keeps the
+  // attention's reads of [0, T) ahead of the writes to slot T)
   int rc = kvq_decode_attn(q, q_sb, q_sh, k_store, k_st, k_scales, k_bits, v_store, v_st, v_scales, v_bits, k_new,
                            kn_sb, kn_sh, v_new, vn_sb, vn_sh, out, o_sb, o_sh, dtype, sm_scale, workspace,
                            workspace_floats, d, stream);
   if (rc) return rc;
-  // 2. quantise the new token into slot T (append_from_past, ops.py:323-330): K and V in ONE launch
-  //    (quant_new_token_pair_k), or the regular calls for very large slices.
-  //    Stream order keeps the attention's reads of [0, T) ahead of these writes to slot T.
-  if (launch_quant_new_token_pair(k_new, kn_sb, kn_sh, v_new, vn_sb, vn_sh, k_store + d->T * k_st->t, k_st->b, k_st->h,
-                                  k_scales + d->T, k_bits, v_store + d->T * v_st->t, v_st->b, v_st->h, v_scales + d->T,
-                                  v_bits, dtype, eps, d->B, d->Hkv, d->D, reinterpret_cast<hipStream_t>(stream)))
-    return check_launch(name);
   const kvq_dims_t qd = {1, d->B, d->Hkv, 1, d->D};
   const kvq_strides_t kin = {0, kn_sb, kn_sh, d->D}, vin = {0, vn_sb, vn_sh, d->D};
   float* absmax_ws = workspace;  // only the generic two-pass path uses it (1 float); the attention is already enqueued

@@ -51,11 +51,6 @@ struct Tunables {
 };
 Tunables& tunables();
 
-// kvq_quant.hip: K and V of one new token in one launch (false: slices too large, use the regular calls)
-bool launch_quant_new_token_pair(const void* k_new, int64_t kn_sb, int64_t kn_sh, const void* v_new, int64_t vn_sb,
-                                 int64_t vn_sh, uint8_t* k_slot, int64_t ks_b, int64_t ks_h, float* k_scale, int k_bits,
-                                 uint8_t* v_slot, int64_t vs_b, int64_t vs_h, float* v_scale, int v_bits, int dtype,
-                                 float eps, int64_t B, int64_t H, int64_t D, hipStream_t st);
 
 // ------------------------------------------------------------------ element conversion
 
@@ -246,6 +241,73 @@ __device__ inline float block_max_nonneg(float v, float* s_red) {
   for (int i = 1; i < kBlock / kWave; ++i) r = fmaxf(r, s_red[i]);
   __syncthreads();
   return r;
+}
+
+// ------------------------------------------------------------------ the reference's quantiser, one element
+template <int BITS>
+struct QRange;
+template <>
+struct QRange<8> {
+  static constexpr float qmax = 127.0f, qmin = -127.0f;
+};
+template <>
+struct QRange<4> {
+  static constexpr float qmax = 7.0f, qmin = -8.0f;
+};
+
+template <int BITS>
+__device__ inline int quant1(float x, float s32) {
+  const float r = rintf(x / s32);  // IEEE fp32 divide + round-half-even, as torch does
+  return (int)fminf(fmaxf(r, QRange<BITS>::qmin), QRange<BITS>::qmax);
+}
+
+// K and V of ONE new token (a decode step's append, ops.py:323-330): slice w (0 = K, 1 = V) of
+// [B,H,1,D] is quantised by ONE workgroup of kBlock threads into slot T of its store. The slices are
+// a few KB, so the arithmetic is the reference's own (IEEE divide per element), bit-identical with
+// the bulk kernels by construction. Runs as two extra workgroups of the attention merge launch
+// (kvq_decode_step) or as its own two-workgroup launch.
+struct NewTokenArgs {
+  const void* x[2];
+  int64_t xs_b[2], xs_h[2];  // elements
+  uint8_t* q[2];             // slot T of the store
+  int64_t qs_b[2], qs_h[2];  // bytes
+  float* scale[2];           // &scales[T]
+  int32_t bits[2];
+  uint32_t B, H, D;
+  float eps;
+};
+
+template <int IDT>
+__device__ inline void quant_new_token_block(const NewTokenArgs& a, uint32_t w, float* s_red) {
+  const uint32_t tid = threadIdx.x;
+  const void* x = a.x[w];
+  const uint32_t n = a.B * a.H * a.D;
+  float m = 0.0f;
+  for (uint32_t i = tid; i < n; i += kBlock) {
+    const uint32_t d = i % a.D, r = i / a.D;
+    m = fmaxf(m, fabsf(load1<IDT>(x, (int64_t)(r / a.H) * a.xs_b[w] + (int64_t)(r % a.H) * a.xs_h[w] + d)));
+  }
+  m = block_max_nonneg(m, s_red);
+  if (a.bits[w] == 8) {
+    const float s32 = fmaxf(m / QRange<8>::qmax, a.eps);
+    if (tid == 0) *a.scale[w] = Elem<IDT>::round_trip(s32);
+    for (uint32_t i = tid; i < n; i += kBlock) {
+      const uint32_t d = i % a.D, r = i / a.D;
+      const float v = load1<IDT>(x, (int64_t)(r / a.H) * a.xs_b[w] + (int64_t)(r % a.H) * a.xs_h[w] + d);
+      a.q[w][(int64_t)(r / a.H) * a.qs_b[w] + (int64_t)(r % a.H) * a.qs_h[w] + d] = (uint8_t)(int8_t)quant1<8>(v, s32);
+    }
+  } else {
+    const float s32 = fmaxf(m / QRange<4>::qmax, a.eps);
+    if (tid == 0) *a.scale[w] = Elem<IDT>::round_trip(s32);
+    const uint32_t Dq = (a.D + 1) / 2;
+    for (uint32_t i = tid; i < a.B * a.H * Dq; i += kBlock) {
+      const uint32_t j = i % Dq, r = i / Dq;
+      const int64_t xo = (int64_t)(r / a.H) * a.xs_b[w] + (int64_t)(r % a.H) * a.xs_h[w];
+      const int hi = quant1<4>(load1<IDT>(x, xo + 2 * j), s32) + 8;
+      const int lo = 2 * j + 1 < a.D ? quant1<4>(load1<IDT>(x, xo + 2 * j + 1), s32) + 8 : 8;
+      a.q[w][(int64_t)(r / a.H) * a.qs_b[w] + (int64_t)(r % a.H) * a.qs_h[w] + j] = (uint8_t)(((hi & 0xF) << 4) | (lo & 0xF));
+    }
+  }
 }
 
 static inline int ilog2_exact(int64_t v) {  // log2 if power of two else -1

@@ -55,23 +55,6 @@ struct QuantArgs {
   int32_t bh_contig; // rows addressable as r * stride_h on both sides
 };
 
-template <int BITS>
-struct QRange;
-template <>
-struct QRange<8> {
-  static constexpr float qmax = 127.0f, qmin = -127.0f;
-};
-template <>
-struct QRange<4> {
-  static constexpr float qmax = 7.0f, qmin = -8.0f;
-};
-
-template <int BITS>
-__device__ inline int quant1(float x, float s32) {
-  const float r = rintf(x / s32);  // IEEE fp32 divide + round-half-even, as torch does
-  return (int)fminf(fmaxf(r, QRange<BITS>::qmin), QRange<BITS>::qmax);
-}
-
 // ---------------------------------------------------------------------------- fused single pass
 
 // DPP lane exchange inside a 16-lane row (single VALU op, no LDS traffic)
@@ -480,74 +463,6 @@ __global__ __launch_bounds__(kBlock) void quant_tokens_generic_k(const QuantArgs
     }
     if (b == 0 && h == 0 && j == 0) a.scales[g * a.ssg + t] = Elem<IDT>::round_trip(s32);
   }
-}
-
-// ---------------------------------------------------------------------------- decode step: K and V of one new token
-// One launch for the two single-token quantisations of a decode step (kvq_decode_step): block 0
-// quantises the K slice [B,H,1,D], block 1 the V slice, each with its own bit width, into slot T of
-// its store. The slices are a few KB, so the arithmetic is the reference's own (IEEE divide per
-// element, `quant1`), bit-identical with the kernels above by construction.
-struct NewTokenArgs {
-  const void* x[2];
-  int64_t xs_b[2], xs_h[2];  // elements
-  uint8_t* q[2];             // slot T of the store
-  int64_t qs_b[2], qs_h[2];  // bytes
-  float* scale[2];           // &scales[T]
-  int32_t bits[2];
-  uint32_t B, H, D;
-  float eps;
-};
-
-template <int IDT>
-__global__ __launch_bounds__(kBlock) void quant_new_token_pair_k(const NewTokenArgs a) {
-  __shared__ float s_red[kBlock / kWave];
-  const uint32_t w = blockIdx.x, tid = threadIdx.x;
-  const void* x = a.x[w];
-  const uint32_t n = a.B * a.H * a.D;
-  float m = 0.0f;
-  for (uint32_t i = tid; i < n; i += kBlock) {
-    const uint32_t d = i % a.D, r = i / a.D;
-    m = fmaxf(m, fabsf(load1<IDT>(x, (int64_t)(r / a.H) * a.xs_b[w] + (int64_t)(r % a.H) * a.xs_h[w] + d)));
-  }
-  m = block_max_nonneg(m, s_red);
-  if (a.bits[w] == 8) {
-    const float s32 = fmaxf(m / QRange<8>::qmax, a.eps);
-    if (tid == 0) *a.scale[w] = Elem<IDT>::round_trip(s32);
-    for (uint32_t i = tid; i < n; i += kBlock) {
-      const uint32_t d = i % a.D, r = i / a.D;
-      const float v = load1<IDT>(x, (int64_t)(r / a.H) * a.xs_b[w] + (int64_t)(r % a.H) * a.xs_h[w] + d);
-      a.q[w][(int64_t)(r / a.H) * a.qs_b[w] + (int64_t)(r % a.H) * a.qs_h[w] + d] = (uint8_t)(int8_t)quant1<8>(v, s32);
-    }
-  } else {
-    const float s32 = fmaxf(m / QRange<4>::qmax, a.eps);
-    if (tid == 0) *a.scale[w] = Elem<IDT>::round_trip(s32);
-    const uint32_t Dq = (a.D + 1) / 2;
-    for (uint32_t i = tid; i < a.B * a.H * Dq; i += kBlock) {
-      const uint32_t j = i % Dq, r = i / Dq;
-      const int64_t xo = (int64_t)(r / a.H) * a.xs_b[w] + (int64_t)(r % a.H) * a.xs_h[w];
-      const int hi = quant1<4>(load1<IDT>(x, xo + 2 * j), s32) + 8;
-      const int lo = 2 * j + 1 < a.D ? quant1<4>(load1<IDT>(x, xo + 2 * j + 1), s32) + 8 : 8;
-      a.q[w][(int64_t)(r / a.H) * a.qs_b[w] + (int64_t)(r % a.H) * a.qs_h[w] + j] = (uint8_t)(((hi & 0xF) << 4) | (lo & 0xF));
-    }
-  }
-}
-
-// host entry for kvq_decode_step (kvq_attn.hip); returns false when the slices are too large for
-// the two-block kernel and the caller should use the regular quantise calls
-bool launch_quant_new_token_pair(const void* k_new, int64_t kn_sb, int64_t kn_sh, const void* v_new, int64_t vn_sb,
-                                 int64_t vn_sh, uint8_t* k_slot, int64_t ks_b, int64_t ks_h, float* k_scale, int k_bits,
-                                 uint8_t* v_slot, int64_t vs_b, int64_t vs_h, float* v_scale, int v_bits, int dtype,
-                                 float eps, int64_t B, int64_t H, int64_t D, hipStream_t st) {
-  if (B * H * D > 65536 || (dtype != KVQ_F16 && dtype != KVQ_BF16)) return false;
-  NewTokenArgs a;
-  a.x[0] = k_new; a.xs_b[0] = kn_sb; a.xs_h[0] = kn_sh;
-  a.x[1] = v_new; a.xs_b[1] = vn_sb; a.xs_h[1] = vn_sh;
-  a.q[0] = k_slot; a.qs_b[0] = ks_b; a.qs_h[0] = ks_h; a.scale[0] = k_scale; a.bits[0] = k_bits;
-  a.q[1] = v_slot; a.qs_b[1] = vs_b; a.qs_h[1] = vs_h; a.scale[1] = v_scale; a.bits[1] = v_bits;
-  a.B = (uint32_t)B; a.H = (uint32_t)H; a.D = (uint32_t)D; a.eps = eps;
-  if (dtype == KVQ_F16) hipLaunchKernelGGL(quant_new_token_pair_k<KVQ_F16>, dim3(2), dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL(quant_new_token_pair_k<KVQ_BF16>, dim3(2), dim3(kBlock), 0, st, a);
-  return true;
 }
 
 // ---------------------------------------------------------------------------- host side

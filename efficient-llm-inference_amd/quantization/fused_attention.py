@@ -13,7 +13,7 @@ Plumbing (transformers >= 4.54 / 5.x):
   * :class:`FusedQuantizedCache` owns a :class:`QuantizedKVCache` and hands the model a
     ``DynamicCache`` whose layers quantise the prompt's K/V into the store (2 launches per layer) and
     pass the new tokens' exact K/V on to the attention function; a decode token is quantised by the
-    same host call that attends (``kvq_decode_step``: one ctypes call per layer and step);
+    same host call that attends (``kvq_decode_step``: one ctypes call, two launches per layer and step);
   * ``kvq_fused`` is registered with transformers' ``AttentionInterface``; inside
     :func:`fused_attention` the model's ``_attn_implementation`` points at it. A single-token
     query runs ``kernels.decode_attn`` on the layer's store; a prompt (empty cache) runs exact

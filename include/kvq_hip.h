@@ -191,7 +191,8 @@ int kvq_decode_attn(const void* q, int64_t q_stride_b, int64_t q_stride_h,
  * slot T of the stores (scales[T]): everything one layer does per decode step in the reference
  * (append_from_past ops.py:323-330, to_past_key_values :345-355, attention) behind one call.
  * The caller guarantees capacity for slot T (k_st / v_st describe the whole [B,Hkv,Tcap,Dq] store)
- * and counts the token as stored afterwards. workspace as for kvq_decode_attn (>= 1 float). */
+ * and counts the token as stored afterwards. workspace as for kvq_decode_attn (>= 1 float).
+ * Two launches: the new token is quantised by two extra workgroups of the merge launch. */
 int kvq_decode_step(const void* q, int64_t q_stride_b, int64_t q_stride_h,
                     const void* k_new, int64_t kn_stride_b, int64_t kn_stride_h,
                     const void* v_new, int64_t vn_stride_b, int64_t vn_stride_h,
