@@ -100,14 +100,19 @@ class FusedQuantizedCache:
         self.cache = DynamicCache()
         self.cache.layers = [_FusedLayer(self, i) for i in range(n_layers)]
         self._ws: Optional[torch.Tensor] = None
+        self._ws_key = None
+        self._ws_T = 0
 
     def workspace(self, B: int, Hq: int, Hkv: int, T: int, D: int, device) -> torch.Tensor:
-        need = kernels.decode_attn_workspace(B, Hq, Hkv, max(T, 1), D)
-        if self._ws is None or self._ws.numel() < need:
-            # sized for the reserved capacity so that decode never reallocates
+        """Scratch for the split partials, sized once for the reserved capacity (decode never reallocates
+        and asks the library for the size only when the shape or the capacity changes)."""
+        key = (B, Hq, Hkv, D, self.qcache._k.cap)
+        if self._ws is None or self._ws_key != key or T > self._ws_T:
             cap = max(self.qcache._k.cap, T, 1)
-            need = max(need, kernels.decode_attn_workspace(B, Hq, Hkv, cap, D))
+            # + two splits' worth of slack: the split count at T < cap can exceed the one at cap by rounding
+            need = kernels.decode_attn_workspace(B, Hq, Hkv, cap, D) + 2 * B * Hq * (D + 2) + 4
             self._ws = torch.empty(need, dtype=torch.float32, device=device)
+            self._ws_key, self._ws_T = key, cap
         return self._ws
 
     def estimated_bytes(self) -> int:
