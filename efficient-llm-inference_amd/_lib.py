@@ -37,6 +37,7 @@ EXPORTS = (
     "kvq_chunk_summary_len",
     "kvq_gather_tokens",
     "kvq_decode_attn_workspace",
+    "kvq_decode_attn_workspace_cap",
     "kvq_decode_attn",
     "kvq_decode_step",
     "kvq_set_tunable",
@@ -100,6 +101,8 @@ def _declare(lib):
     AD = POINTER(KvqAttnDims)
     lib.kvq_decode_attn_workspace.restype = c_int64
     lib.kvq_decode_attn_workspace.argtypes = [AD]
+    lib.kvq_decode_attn_workspace_cap.restype = c_int64
+    lib.kvq_decode_attn_workspace_cap.argtypes = [AD]
     lib.kvq_decode_attn.restype = c_int
     lib.kvq_decode_attn.argtypes = [P, c_int64, c_int64, P, ST, P, c_int, P, ST, P, c_int, P, c_int64, c_int64,
                                     P, c_int64, c_int64, P, c_int64, c_int64, c_int, c_float, P, c_int64, AD, P]

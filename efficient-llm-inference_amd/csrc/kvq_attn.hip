@@ -992,6 +992,23 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
 
 extern "C" {
 
+// The split count is not monotone in T (tokens per split grow with T), so a decode loop that sizes
+// its workspace ONCE for a capacity asks for the maximum over every T' <= T.
+int64_t kvq_decode_attn_workspace_cap(const kvq_attn_dims_t* d) {
+  if (!d || d->B <= 0 || d->Hq <= 0 || d->Hkv <= 0 || d->T < 0 || d->D <= 0) return -1;
+  if (d->D != 32 && d->D != 64 && d->D != 128 && d->D != 256) return -1;
+  kvq_attn_dims_t t = *d;
+  uint32_t ts, ns, ns_max = 1;
+  if (!plan(&t, &ts, &ns)) return -1;
+  ns_max = ns > ns_max ? ns : ns_max;
+  for (int64_t tt = 32; tt < d->T; tt += 32) {  // + 1 below covers a change of split size between two probes
+    t.T = tt;
+    if (plan(&t, &ts, &ns) && ns > ns_max) ns_max = ns;
+  }
+  const int64_t rows = d->B * d->Hq * (int64_t)(ns_max + 1);
+  return (rows * 2 + 3) / 4 * 4 + rows * d->D;
+}
+
 int kvq_decode_attn(const void* q, int64_t q_sb, int64_t q_sh, const uint8_t* k_store, const kvq_strides_t* k_st,
                     const float* k_scales, int k_bits, const uint8_t* v_store, const kvq_strides_t* v_st,
                     const float* v_scales, int v_bits, const void* k_new, int64_t kn_sb, int64_t kn_sh,

@@ -232,6 +232,15 @@ def decode_attn_workspace(B: int, Hq: int, Hkv: int, T: int, D: int) -> int:
     return n
 
 
+def decode_attn_workspace_cap(B: int, Hq: int, Hkv: int, Tcap: int, D: int) -> int:
+    """fp32 elements that cover :func:`decode_attn` / :func:`decode_step` for EVERY context length up to
+    ``Tcap`` (the per-T size is not monotone): what a decode loop allocates once."""
+    n = int(_lib.load().kvq_decode_attn_workspace_cap(byref(_lib.KvqAttnDims(B, Hq, Hkv, Tcap, D))))
+    if n < 0:
+        raise _lib.KvqError(f"kvq: bad decode-attention dims B={B} Hq={Hq} Hkv={Hkv} T={Tcap} D={D}")
+    return n
+
+
 def decode_attn(q: torch.Tensor, k_store: torch.Tensor, k_scales: torch.Tensor, k_kind: str,
                 v_store: torch.Tensor, v_scales: torch.Tensor, v_kind: str, T: int, out: torch.Tensor,
                 workspace: torch.Tensor, sm_scale: float, k_new: torch.Tensor | None = None,

@@ -109,9 +109,8 @@ class FusedQuantizedCache:
         key = (B, Hq, Hkv, D, self.qcache._k.cap)
         if self._ws is None or self._ws_key != key or T > self._ws_T:
             cap = max(self.qcache._k.cap, T, 1)
-            # + two splits' worth of slack: the split count at T < cap can exceed the one at cap by rounding
-            need = kernels.decode_attn_workspace(B, Hq, Hkv, cap, D) + 2 * B * Hq * (D + 2) + 4
-            self._ws = torch.empty(need, dtype=torch.float32, device=device)
+            # the per-T size is not monotone in T: ask for the maximum over every T <= cap
+            self._ws = torch.empty(kernels.decode_attn_workspace_cap(B, Hq, Hkv, cap, D), dtype=torch.float32, device=device)
             self._ws_key, self._ws_T = key, cap
         return self._ws
 

@@ -163,6 +163,9 @@ typedef struct {
 
 /* Workspace floats kvq_decode_attn needs for these dims (-1 on bad dims). */
 int64_t kvq_decode_attn_workspace(const kvq_attn_dims_t* dims);
+/* Largest kvq_decode_attn_workspace over every T' <= dims->T (it is not monotone in T): what a decode
+ * loop allocates once for its reserved capacity. */
+int64_t kvq_decode_attn_workspace_cap(const kvq_attn_dims_t* dims);
 
 /* One decode step of one layer without materialising the fp16 cache. Replaces, for a single
  * query token, QuantizedKVCache.to_past_key_values (src/quantization/ops.py:345-355: dequantise

@@ -107,3 +107,23 @@ def test_no_cpu_fallback_in_product():
         E.QuantizedKVCache(1, "int2")
     with pytest.raises(ValueError, match="Empty cache"):
         E.QuantizedLayerKV("int8").get_kv()
+
+
+def test_decode_attn_workspace_cap_covers_every_length():
+    """Host-only: the per-T workspace size of kvq_decode_attn is not monotone in T (tokens per split
+    grow with the context), so a decode loop sizes its scratch with kvq_decode_attn_workspace_cap; it
+    must cover every T up to the capacity."""
+    import random
+
+    from efficient_llm_inference_amd import kernels as K
+    rng = random.Random(7)
+    for _ in range(60):
+        B = rng.choice([1, 2, 8, 64])
+        Hkv = rng.choice([1, 2, 8, 12, 32])
+        Hq = Hkv * rng.choice([1, 2, 4, 8])
+        D = rng.choice([32, 64, 128, 256])
+        cap = rng.choice([100, 1000, 5000, 40000, 200000])
+        capn = K.decode_attn_workspace_cap(B, Hq, Hkv, cap, D)
+        for T in [1, 63, 64, 65, 127, 128, 129, 4095, 4096, 4097, cap] + [rng.randint(1, cap) for _ in range(40)]:
+            if T <= cap:
+                assert K.decode_attn_workspace(B, Hq, Hkv, T, D) <= capn, (B, Hq, Hkv, D, cap, T)
