@@ -395,6 +395,40 @@ class QuantizedKVCache:
             v = self._v.dequant(self.compute_dtype)
         return tuple((k[i], v[i]) for i in range(len(self.layers)))
 
+    @torch.no_grad()
+    def attend(self, layer: int, q: torch.Tensor, k_new: Optional[torch.Tensor] = None,
+               v_new: Optional[torch.Tensor] = None, sm_scale: Optional[float] = None,
+               append: bool = False) -> torch.Tensor:
+        """Single-token attention of ``layer`` straight from the quantised store (no dequantised copy):
+        ``softmax(q K^T * sm_scale) V`` over every stored token, plus the exact ``k_new`` / ``v_new``
+        ``[B, Hkv, D]`` as one more token when given — what ``to_past_key_values()`` followed by the
+        model's attention computes (reference ops.py:345-355, benchmarker.py:470-471), within fp16
+        tolerance. ``q`` is ``[B, Hq, D]`` fp16 / bf16 (Hq a multiple of the cache's kv heads). With
+        ``append=True`` the new token is also quantised into the store (``append_from_past`` for this
+        layer, ops.py:323-330) by the same call."""
+        k, v = self._k, self._v
+        T = k.lens[layer]
+        if T != v.lens[layer] or k.q is None:
+            raise ValueError("Empty cache")
+        if append and (k_new is None or v_new is None):
+            raise ValueError("kvq: append=True needs k_new and v_new")
+        B, Hq, D = q.shape
+        scale = float(sm_scale) if sm_scale is not None else D ** -0.5
+        out = torch.empty_like(q)
+        need = kernels.decode_attn_workspace_cap(B, Hq, k.H, max(k.cap, T + 1), D)
+        if getattr(self, "_attn_ws", None) is None or self._attn_ws.numel() < need:
+            self._attn_ws = torch.empty(need, dtype=torch.float32, device=q.device)
+        if append:
+            k.reserve(T + 1)
+            v.reserve(T + 1)
+            plan = kernels.DecodeStepPlan(q, k.q[layer], k.scales[layer], k.kind, v.q[layer], v.scales[layer], v.kind, k.eps)
+            kernels.decode_step(plan, q, k_new, v_new, T, out, self._attn_ws, scale)
+            k.lens[layer] = v.lens[layer] = T + 1
+        else:
+            kernels.decode_attn(q, k.q[layer], k.scales[layer], k.kind, v.q[layer], v.scales[layer], v.kind, T, out,
+                                self._attn_ws, scale, k_new, v_new)
+        return out
+
     def estimated_bytes(self) -> int:
         """Total bytes over layers (reference ops.py:357-363)."""
         return sum(layer.estimated_bytes() for layer in self.layers)
