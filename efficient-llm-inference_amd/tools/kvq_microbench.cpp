@@ -143,6 +143,20 @@ struct Timer {
   }
 };
 
+// bufcheck: the range check the MFMA attention kernel relies on (kvq_attn.hip): a raw buffer load
+// whose vector offset lies at or beyond num_records returns 0 and touches nothing.
+__global__ void bufcheck_k(const uint8_t* base, uint32_t valid_bytes, uint32_t* out) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, (int)valid_bytes, 0x00020000);
+  const uint32_t off = threadIdx.x * 16u;  // 64 lanes x 16 B = 1 KiB; valid_bytes = 512: lanes 32.. are out of range
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 2);
+  const uint32_t b = __builtin_amdgcn_raw_buffer_load_b32(r, off + 8u, 0, 2);
+  const uint32_t c = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, off + 2u, 0, 2);
+  out[threadIdx.x * 3 + 0] = a[0] | a[1] | a[2] | a[3];
+  out[threadIdx.x * 3 + 1] = b;
+  out[threadIdx.x * 3 + 2] = c;
+}
+
 static int64_t G = 32, B = 1, H = 8, T = 16384, D = 128;  // override: KVQ_G / KVQ_T (G*T kept = 524288 by the caller)
 
 int main(int argc, char** argv) {
@@ -154,6 +168,27 @@ int main(int argc, char** argv) {
   if (getenv("KVQ_B")) B = atoll(getenv("KVQ_B"));
   if (getenv("KVQ_H")) H = atoll(getenv("KVQ_H"));
   if (getenv("KVQ_D")) D = atoll(getenv("KVQ_D"));  // multiple of 8
+  if (what == "bufcheck") {
+    uint8_t* buf;
+    uint32_t* out;
+    HIP_OK(hipMalloc(&buf, 4096));
+    HIP_OK(hipMalloc(&out, 64 * 3 * 4));
+    HIP_OK(hipMemset(buf, 0xAB, 4096));
+    bufcheck_k<<<1, 64>>>(buf, 512, out);
+    uint32_t h[64 * 3];
+    HIP_OK(hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int l = 0; l < 64; ++l) {
+      const bool in = l < 32;
+      const uint32_t e128 = in ? 0xABABABABu : 0u, e32 = in ? 0xABABABABu : 0u, e16 = in ? 0xABABu : 0u;
+      if (h[3 * l] != e128 || h[3 * l + 1] != e32 || h[3 * l + 2] != e16) {
+        ++bad;
+        printf("lane %d: got %08x %08x %04x expected %08x %08x %04x\n", l, h[3 * l], h[3 * l + 1], h[3 * l + 2], e128, e32, e16);
+      }
+    }
+    printf("bufcheck: %s (lanes 0..31 in range read the fill pattern, lanes 32..63 out of range read 0)\n", bad ? "FAILED" : "ok");
+    return bad ? 1 : 0;
+  }
   hipDeviceProp_t prop;
   HIP_OK(hipGetDeviceProperties(&prop, 0));
   printf("# device %s CUs=%d  shape G=%lld B=%lld H=%lld T=%lld D=%lld iters=%d\n", prop.gcnArchName,
