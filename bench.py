@@ -71,67 +71,99 @@ def parse():
                     help="independent quantised caches visited round-robin by consecutive steps, so that no "
                          "step re-reads lines the 256 MiB Infinity Cache may still hold (1 = the decode loop's "
                          "behaviour: the same cache every step; its 256 MiB INT4 store then stays cache-resident)")
-    ap.add_argument("--cpu-sample-layers", type=int, default=32)
+    ap.add_argument("--cpu-sample-layers", type=int, default=8)
     ap.add_argument("--tunable", action="append", default=[], metavar="KEY=VALUE",
                     help="A-B only: kvq_set_tunable(KEY, VALUE) before the run (include/kvq_hip.h lists the keys)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="allow more ranks than GPUs (rank r uses GPU r %% n_gpus): a rehearsal of the N > 1 code "
+                         "path on a small box, never a scaling number; RCCL refuses duplicate devices, so this "
+                         "also needs --allow-gloo-timing")
+    ap.add_argument("--allow-gloo-timing", action="store_true",
+                    help="if RCCL cannot be brought up on every rank, run the timing / counter reductions over gloo "
+                         "instead of failing (recorded as timing_reduction_backend)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-launcher waits for its ranks")
+    ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--fused-attention", action="store_true",
                     help="decode:* workloads with quant_* methods: attend straight over the quantised store "
                          "(kvq_decode_attn) instead of the staged fp16 copy")
     return ap.parse_args()
 
 
-def cpu_baseline(L, B, H, T, D, sample_layers):
-    """Time the scalar C port of the reference's INT4 dequantise on `sample_layers` layers of
-    the same V set (host buffers, one thread)."""
+def _median_time(fn, reps):
+    """median wall time of `reps` calls after one warm-up call"""
+    fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def cpu_baseline(L, B, H, T, D, sample_layers, reps=5):
+    """the reference's CPU algorithm for the INT4 dequantise (the roofline kernel's
+    op) and quantise of the same V set, on this box's host cores, three ways — each one warm-up +
+    `reps` timed repetitions, median reported, on a bounded sample (stated per entry):
+      port        scalar C restatement (oracle/kvq_oracle.c), 1 core
+      vectorised  whole-tensor torch-CPU ops (oracle/vectorised_torch.py), every host core
+      literal     the reference's own call structure: one op chain per [B,H,1,D] slice + a T-way
+                  cat (oracle/literal_loop.py), torch-CPU, every host core
+    The top-level value / cores / kind / sample are the port's dequantise figure."""
     import numpy as np
+    import torch as _t
     from oracle import c_oracle as C
-    n_layers = max(1, min(sample_layers, L))
+    from oracle import literal_loop as LL
+    from oracle import vectorised_torch as VT
+    cores = os.cpu_count() or 1
+    bpe = BYTES_PER_ELT["int4"]
     rng = np.random.default_rng(42)
+    gbps = lambda n, dt: round(n * bpe / dt / 1e9, 5)  # noqa: E731
+
+    # ---- port: scalar C, 1 core --------------------------------------------------------------
+    n_layers = max(1, min(sample_layers, L))
     q = rng.integers(0, 256, size=(n_layers, B, H, T, D // 2), dtype=np.uint8)
     sc = (rng.random((n_layers, T), dtype=np.float32) * 0.02 + 0.001).astype(np.float32)
-    C.dequantize_tokens(q[:1], sc[:1], "int4", D, "f16")  # warm (page in, load lib)
-    dt = float("inf")
-    for _ in range(3):  # best of three passes over the sample (~10 s of CPU work at the default)
-        t0 = time.perf_counter()
-        C.dequantize_tokens(q, sc, "int4", D, "f16")
-        dt = min(dt, time.perf_counter() - t0)
+    dt = _median_time(lambda: C.dequantize_tokens(q, sc, "int4", D, "f16"), reps)
     n = n_layers * B * H * T * D
-    # the quantise side of the same path (rows a1/a2): scalar C port, fp16 -> INT4, on 4 layers
     nq_layers = max(1, min(4, n_layers))
     xq = (rng.standard_normal((nq_layers, B, H, T, D), dtype=np.float32)).astype(np.float16)
-    C.quantize_tokens(xq[:1, :, :, :64], "int4")
-    tq0 = time.perf_counter()
-    C.quantize_tokens(xq, "int4")
-    dq_s = time.perf_counter() - tq0
+    dq_s = _median_time(lambda: C.quantize_tokens(xq, "int4"), reps)
     nq = nq_layers * B * H * T * D
-    # the reference's literal call structure (per-slice op chains + T-way cat) on a small sample
-    import torch as _t
-    from oracle import literal_loop as LL
-    Ts = min(T, 2048)
-    qs = [_t.from_numpy(q[0, :, :, t:t + 1, :].copy()) for t in range(Ts)]
-    ss = [_t.tensor(float(sc[0, t]), dtype=_t.float16) for t in range(Ts)]
-    _t.set_num_threads(os.cpu_count() or 1)
-    LL.dequantize_slices(qs[:64], ss[:64], "int4", D, _t.float16)
-    t1 = time.perf_counter()
-    LL.dequantize_slices(qs, ss, "int4", D, _t.float16)
-    dl = time.perf_counter() - t1
+    port = {"value": gbps(n, dt), "unit": "GB/s", "cores": 1, "reps": reps, "kind": "port",
+            "sample": f"INT4->fp16 dequantise of {n_layers}/{L} layers of the V set [{n_layers},{B},{H},{T},{D}] "
+                      f"({n} elements, median {dt:.3f} s), oracle/kvq_oracle.c scalar",
+            "quantise_value": gbps(nq, dq_s),
+            "quantise_sample": f"fp16->INT4 per-token quantise of {nq_layers}/{L} layers ({nq} elements, median {dq_s:.3f} s)"}
+
+    # ---- vectorised: whole-tensor torch-CPU, all cores ------------------------------------------
+    _t.set_num_threads(cores)
+    nv_layers = max(1, min(4, n_layers))
+    xv = _t.from_numpy(xq[:nv_layers])
+    qv, sv = VT.quantize_tokens(xv, "int4")
+    dv = _median_time(lambda: VT.dequantize_tokens(qv, sv, "int4", D, _t.float16), reps)
+    dvq = _median_time(lambda: VT.quantize_tokens(xv, "int4"), reps)
+    nvv = nv_layers * B * H * T * D
+    vect = {"value": gbps(nvv, dv), "unit": "GB/s", "cores": cores, "reps": reps, "kind": "port",
+            "sample": f"INT4->fp16 dequantise of {nv_layers}/{L} layers [{nv_layers},{B},{H},{T},{D}] as whole-tensor "
+                      f"torch-CPU ops ({nvv} elements, median {dv:.3f} s), oracle/vectorised_torch.py",
+            "quantise_value": gbps(nvv, dvq), "quantise_sample": f"same tensors, fp16->INT4 (median {dvq:.3f} s)",
+            "torch_threads": _t.get_num_threads()}
+
+    # ---- literal: the reference's per-slice loop, sub-sampled in T -------------------------------
+    Ts = min(T, 1024)
+    xl = _t.from_numpy(xq[0, :, :, :Ts].copy())
+    qs, ss = LL.quantize_slices(xl, "int4")
+    dl = _median_time(lambda: LL.dequantize_slices(qs, ss, "int4", D, _t.float16), reps)
+    dlq = _median_time(lambda: LL.quantize_slices(xl, "int4"), reps)
     n_lit = B * H * Ts * D
-    return {
-        "value": round(n * BYTES_PER_ELT["int4"] / dt / 1e9, 4),
-        "unit": "GB/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"INT4->fp16 dequantise of {n_layers}/{L} layers of the V set "
-                  f"[{n_layers},{B},{H},{T},{D}] ({n} elements, best of 3 passes: {dt:.2f} s), oracle/kvq_oracle.c scalar",
-        "host_cores_available": os.cpu_count(),
-        "quantise": {"value": round(nq * BYTES_PER_ELT["int4"] / dq_s / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
-                     "sample": f"fp16->INT4 per-token quantise of {nq_layers}/{L} layers [{nq_layers},{B},{H},{T},{D}] "
-                               f"({dq_s:.2f} s), oracle/kvq_oracle.c scalar"},
-        "literal_loop": {"value": round(n_lit * BYTES_PER_ELT["int4"] / dl / 1e9, 5), "unit": "GB/s",
-                         "sample": f"per-slice dequantise + {Ts}-way cat of one layer's V [{B},{H},{Ts},{D}] with torch-CPU ops "
-                                   f"({dl:.2f} s), the reference's own call structure (oracle/literal_loop.py)",
-                         "torch_threads": _t.get_num_threads()},
-    }
+    lit = {"value": gbps(n_lit, dl), "unit": "GB/s", "cores": cores, "reps": reps, "kind": "port",
+           "sample": f"per-slice dequantise + {Ts}-way cat of one layer's V [{B},{H},{Ts},{D}] (T sub-sampled {Ts}/{T}; the "
+                     f"loop is linear in T) with torch-CPU ops (median {dl:.3f} s), oracle/literal_loop.py",
+           "quantise_value": gbps(n_lit, dlq), "quantise_sample": f"same slices, per-slice fp16->INT4 (median {dlq:.3f} s)",
+           "torch_threads": _t.get_num_threads()}
+    return {"value": port["value"], "unit": "GB/s", "cores": 1, "kind": "port", "sample": port["sample"], "reps": reps,
+            "host_cores_available": cores, "port": port, "vectorised": vect, "literal": lit}
 
 
 def run_decode(args, rank, world, dev):
@@ -152,8 +184,7 @@ def run_decode(args, rank, world, dev):
     for _ in range(args.warmup):
         bm.benchmark_method([f"<{min(n_prompt, 64)}>"], method=method, max_new_tokens=8)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    sharding.barrier()
     res = sharding.benchmark_sharded(bm, prompts, method, max_new_tokens=n_new)
     base = sharding.benchmark_sharded(bm, prompts, "full_cache", max_new_tokens=n_new)
     if rank == 0:
@@ -170,7 +201,8 @@ def run_decode(args, rank, world, dev):
                        "heads": getattr(cfg, "num_attention_heads", None) or cfg.n_head,
                        "kv_heads": getattr(cfg, "num_key_value_heads", None) or getattr(cfg, "num_attention_heads", None) or cfg.n_head,
                        "head_dim": getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads,
-                       "parallelism": f"prompt-shard x{world}, one all_reduce of counters"},
+                       "parallelism": f"prompt-shard x{world}, one all_reduce of counters",
+                       "timing_reduction_backend": sharding.backend()},
             "est_kv_cache_mb": round(res["est_kv_cache_mb_avg"], 3),
             "full_cache_tokens_per_sec": round(base["tokens_per_sec"], 2),
             "vs_full_cache": round(res["tokens_per_sec"] / base["tokens_per_sec"], 3),
@@ -229,7 +261,8 @@ def run_evict(args, rank, world, dev):
             "data": "synthetic",
             "config": {"workload": args.workload, "shape_per_rank_L2BHTD": [L, 2, B, H, T, D], "window": W,
                        "chunk_size": chunk, "keep_last": keep, "global_batch": B * world,
-                       "parallelism": f"batch-shard x{world} (8 rows per GPU), no collective"},
+                       "parallelism": f"batch-shard x{world} (8 rows per GPU), no collective",
+                       "timing_reduction_backend": sharding.backend()},
             "roofline": {"kernel": "chunk_pool_vec_k<f16>", "bound": "hbm",
                          "achieved": round(bytes_pool / (p_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(bytes_pool / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
@@ -318,7 +351,8 @@ def run_attn(args, rank, world, dev):
             "dtype_detail": "int8 / packed-int4 store, fp16 query, fp32 accumulate, fp16 out", "data": "synthetic",
             "config": {"workload": args.workload, "shape_L_B_Hq_Hkv_T_D": [L, B, Hq, Hkv, T, D], "mode": mode,
                        "step": "one decode step: kvq_decode_attn per layer (2 launches each), host launch gaps included",
-                       "bytes_per_step": int(step_bytes), "parallelism": f"batch-shard x{world}, no collective"},
+                       "bytes_per_step": int(step_bytes), "parallelism": f"batch-shard x{world}, no collective",
+                       "timing_reduction_backend": sharding.backend()},
             "roofline": {"kernel": ("decode_attn_partial_mfma_k" if D in (64, 128) and 3 <= Hq // Hkv <= 16 else "decode_attn_partial_k (or _mfma_k under --tunable attn_mfma_min_nq)") + " + decode_attn_merge_k (per layer call)", "bound": "hbm",
                          "achieved": round(layer_bytes / (layer_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(layer_bytes / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": _traffic(args.workload, "decode_attn_per_layer_call"),
@@ -332,65 +366,142 @@ def run_attn(args, rank, world, dev):
         }), flush=True)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """``python bench.py --gpus N`` without a launcher: start N ranks of this script (one per GPU)
+    BEFORE anything in this process touches the GPU, relay rank 0's JSON line, exit non-zero if any
+    rank does. The parent never initialises HIP (``torch.cuda.device_count()`` does not on this
+    image) and never re-execs itself; the children are ordinary child processes."""
+    import subprocess
+    n = args.gpus
+    if not args.launcher_selftest:
+        n_dev = torch.cuda.device_count()
+        if n_dev == 0:
+            raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU path")
+        if n > n_dev and not args.share_gpu:
+            raise SystemExit(f"bench.py: --gpus {n} but only {n_dev} GPU(s) are visible; a rehearsal with several ranks "
+                             f"per GPU needs --share-gpu (and --allow-gloo-timing: RCCL refuses duplicate devices)")
+    env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv,
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    deadline = time.monotonic() + args.launch_timeout
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            rc = p.poll()
+            if rc not in (None, 0):
+                failed = (r, rc)
+        if time.monotonic() > deadline:
+            failed = (-1, 124)
+        time.sleep(0.05)
+    if failed is None:
+        failed = next(((r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0), None)
+    if failed is not None:  # the other ranks would wait in a collective for ever: stop exactly the processes we started
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        out0 = procs[0].stdout.read() if procs[0].stdout else ""
+        sys.stderr.write(out0)
+        who = "the launcher's timeout" if failed[0] < 0 else f"rank {failed[0]} (exit code {failed[1]})"
+        raise SystemExit(f"bench.py --gpus {n}: failed in {who}; no result line")
+    sys.stdout.write(procs[0].stdout.read())
+    sys.stdout.flush()
+
+
+def selftest_rank(args, rank, world):
+    """--launcher-selftest: what a rank does with no GPU at all (CPU test of the launcher): join the
+    gloo group, reduce the ranks, report."""
+    from efficient_llm_inference_amd import sharding
+    if os.environ.get("KVQ_SELFTEST_FAIL_RANK") == str(rank):  # test hook: a rank that dies before the rendezvous
+        raise SystemExit(3)
+    be = sharding.init_distributed(rank, world, None) if world > 1 else None
+    seen = sharding.max_over_ranks(float(rank))
+    t = torch.tensor([float(rank)])
+    if world > 1:
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "max_rank": seen, "rank_sum": float(t.item()),
+                          "timing_reduction_backend": be}), flush=True)
+    if world > 1:
+        sharding.shutdown()
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch as many ranks as --gpus says")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.launcher_selftest:
+        return selftest_rank(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
     n_dev = torch.cuda.device_count()
-    dev_index = local_rank % max(1, n_dev)  # ranks > GPUs (a rehearsal on a 1-GPU box) share the card
+    share = local_rank >= n_dev or int(os.environ.get("LOCAL_WORLD_SIZE", world)) > n_dev
+    if share and not args.share_gpu:
+        raise SystemExit(f"bench.py: rank {rank} has no GPU of its own ({n_dev} visible, {world} ranks); "
+                         f"pass --share-gpu for a rehearsal on a small box")
+    dev_index = local_rank % max(1, n_dev)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    backend = None
-    if world > 1:
-        # RCCL over xGMI for the one scalar reduction of a run; the data path itself needs no
-        # collective. If RCCL cannot come up (IPC / driver trouble) the same reduction runs over
-        # gloo so that the per-rank measurements are still reported.
-        try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-            backend = "nccl"
-            warm = torch.zeros(1, device=dev)
-            dist.all_reduce(warm)  # surfaces RCCL initialisation errors here, not inside the timed region
-            torch.cuda.synchronize()
-        except Exception as exc:  # noqa: BLE001
-            print(f"[bench] rank {rank}: RCCL unavailable ({exc!r}); using gloo for the timing reduction", file=sys.stderr)
-            if dist.is_initialized():
-                dist.destroy_process_group()
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            backend = "gloo"
 
-    import efficient_llm_inference_amd as E
+    import efficient_llm_inference_amd as E  # noqa: F401
     from efficient_llm_inference_amd import _lib, sharding
 
+    backend = None
+    if world > 1:
+        # RCCL over xGMI carries the reductions of a run (the data path itself needs no collective).
+        # RCCL not coming up on every rank is FATAL unless --allow-gloo-timing: a line that says
+        # n_gpus: 8 must not hide a broken xGMI / IPC setup.
+        try:
+            backend = sharding.init_distributed(rank, world, dev, allow_gloo=args.allow_gloo_timing, ranks_share_device=share)
+        except sharding.RcclUnavailable as exc:
+            raise SystemExit(f"bench.py: {exc}")
     _lib.load()
     for kv in args.tunable:
         key, _, val = kv.partition("=")
         _lib.set_tunable(key, int(val))
-    if args.workload.startswith("decode"):
-        run_decode(args, rank, world, dev)
+    try:
+        if args.workload.startswith("decode"):
+            run_decode(args, rank, world, dev)
+        elif args.workload in ATTN:
+            run_attn(args, rank, world, dev)
+        elif args.workload in EVICT:
+            run_evict(args, rank, world, dev)
+        elif args.workload in WORKLOADS:
+            run_dequant(args, rank, world, dev, backend)
+        else:
+            raise SystemExit(f"unknown workload {args.workload}")
+    finally:
         if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-    if args.workload in ATTN:
-        run_attn(args, rank, world, dev)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-    if args.workload in EVICT:
-        run_evict(args, rank, world, dev)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-    if args.workload not in WORKLOADS:
-        raise SystemExit(f"unknown workload {args.workload}")
+            sharding.shutdown()
+
+
+def run_dequant(args, rank, world, dev, backend):
+    """The headline workload (module docstring): one STEP = to_past_key_values() of the quantised cache."""
+    import efficient_llm_inference_amd as E
+    from efficient_llm_inference_amd import sharding
     L, B, H, T, D, mode = WORKLOADS[args.workload]
     kk, vk = {"int8": ("int8", "int8"), "int4": ("int4", "int4"), "mixed": ("int8", "int4")}[mode]
 
@@ -505,7 +616,9 @@ def main():
                 "kernel": f"dequant_tokens_fast_k<{vk}>", "what": target_name, "bound": "hbm",
                 "achieved": round(target_bytes / (target_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(target_bytes / (target_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                "traffic": traffic, "algorithmic_bytes_per_launch": int(target_bytes),
+                "traffic": traffic, "traffic_source": "profiles/traffic.json (rocprofv3 PMC passes of this command, committed; "
+                                                      "not re-measured in this run)" if traffic is not None else None,
+                "algorithmic_bytes_per_launch": int(target_bytes),
                 "avg_launch_ms": round(target_ms, 4), "timer": "HIP events on the launch stream, per launch, in the timed region",
             },
             "roofline_k": {
@@ -521,9 +634,6 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(L, B, H, T, D, args.cpu_sample_layers)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

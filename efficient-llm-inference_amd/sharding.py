@@ -2,17 +2,101 @@
 
 The path partitions by prompt / batch row: a prompt's KV cache, its scales and its eviction
 state never leave the GPU that owns the prompt, so quantise / dequantise / trim / pool run with NO
-data-path collective. What crosses xGMI is one ``all_reduce`` of a handful of run counters at the
-end of a benchmark (RCCL = backend "nccl" on ROCm; "gloo" in the CPU tests).
+data-path collective. What crosses xGMI is
 
-One process per GPU (``torch.distributed.run``), rank r owns prompts ``r, r+W, r+2W, ...``.
+* one ``all_reduce`` pair over a handful of run counters at the end of a benchmark, and
+* — only when ONE genuinely batched ``[B>1,H,1,D]`` slice is split by batch rows over ranks — one
+  ``all_reduce(MAX)`` of the ``[G,T]`` fp32 abs-max table between the abs-max and the quantise
+  phases (`quantize_tokens_batch_sharded`): the reference's scale spans the whole batch
+  (``abs().max()`` of the slice, reference src/quantization/ops.py:27,48), so every rank must
+  quantise with the same scale.
+
+One process per GPU, rank r owns prompts ``r, r+W, r+2W, ...``. RCCL = backend "nccl" on ROCm;
+"gloo" in the CPU tests. `init_distributed` brings both up: a gloo group as the control plane (it
+cannot fail on xGMI / IPC trouble) and an RCCL group for every reduction; whether RCCL came up is
+AGREED over gloo, so the ranks either all use it or all fail (or, with ``allow_gloo``, all fall
+back) — never a mix that would hang at the next collective.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence
+import datetime
+from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
+
+# the group + device every reduction of this module uses; None = torch's default group
+_STATE = {"group": None, "device": None, "backend": None}
+
+
+class RcclUnavailable(RuntimeError):
+    """RCCL could not be brought up on every rank and the caller did not allow the gloo fallback."""
+
+
+def init_distributed(rank: int, world_size: int, device: Optional[torch.device], *, allow_gloo: bool = False,
+                     ranks_share_device: bool = False, timeout_s: float = 300.0) -> str:
+    """Bring up the process groups of an N-rank run and return the backend the reductions use
+    ("nccl" = RCCL over xGMI, or "gloo").
+
+    MASTER_ADDR / MASTER_PORT come from the environment (127.0.0.1 on one node). ``device`` None
+    = a CPU-only run (tests, launcher self-test): gloo only. ``ranks_share_device``: more ranks
+    than GPUs (a rehearsal on a small box) — RCCL refuses duplicate devices, so it is not tried.
+    RCCL failing on ANY rank raises `RcclUnavailable` on EVERY rank unless ``allow_gloo``."""
+    timeout = datetime.timedelta(seconds=timeout_s)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size, timeout=timeout)
+    _STATE.update(group=None, device=None, backend="gloo")
+    if device is None or device.type != "cuda":
+        return "gloo"
+    ok, why, group = 1, "", None
+    if ranks_share_device:
+        ok, why = 0, "several ranks share one GPU (RCCL refuses duplicate devices)"
+    else:
+        try:
+            group = dist.new_group(backend="nccl", timeout=timeout, device_id=device)
+            warm = torch.zeros(1, device=device)
+            dist.all_reduce(warm, group=group)  # RCCL initialises lazily: surface its errors here
+            torch.cuda.synchronize(device)
+        except Exception as exc:  # noqa: BLE001 - any RCCL / IPC / driver failure
+            ok, why = 0, repr(exc)
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # over gloo: every rank learns the same answer
+    if int(flag.item()) == 1:
+        _STATE.update(group=group, device=device, backend="nccl")
+        return "nccl"
+    if group is not None and ok:
+        try:
+            dist.destroy_process_group(group)
+        except Exception:  # noqa: BLE001
+            pass
+    if not allow_gloo:
+        msg = (f"rank {rank}: RCCL is not usable on every rank"
+               + (f" (this rank: {why})" if why else " (it failed on another rank)")
+               + "; pass --allow-gloo-timing to run the timing reduction over gloo instead")
+        dist.destroy_process_group()
+        raise RcclUnavailable(msg)
+    return "gloo"
+
+
+def shutdown() -> None:
+    """Barrier + destroy every group this module created (idempotent)."""
+    if dist.is_available() and dist.is_initialized():
+        try:
+            dist.barrier()
+        finally:
+            if _STATE["group"] is not None:
+                try:
+                    dist.destroy_process_group(_STATE["group"])
+                except Exception:  # noqa: BLE001
+                    pass
+            _STATE.update(group=None, device=None, backend=None)
+            dist.destroy_process_group()
+
+
+def backend() -> Optional[str]:
+    """"nccl" | "gloo" | None (single process)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    return _STATE["backend"] or dist.get_backend()
 
 
 def world() -> tuple:
@@ -40,16 +124,27 @@ def shard_batch_rows(n_rows: int, rank: int = None, world_size: int = None) -> r
 
 def _reduce_device(device=None):
     """where the scalars of a reduction live: the GPU under RCCL, host memory under gloo"""
-    if dist.get_backend() != "nccl":
+    if backend() != "nccl":
         return torch.device("cpu")
+    if _STATE["device"] is not None:
+        return _STATE["device"]
     return device if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+
+def _all_reduce(t: torch.Tensor, op) -> None:
+    dist.all_reduce(t, op=op, group=_STATE["group"])
 
 
 def barrier() -> None:
     """Rendezvous of all ranks (no-op in a single process). bench.py brackets its timed region
     with barrier() + torch.cuda.synchronize() on both sides."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if _STATE["group"] is not None:  # RCCL: a 1-element all_reduce on the device, then drained
+            t = torch.zeros(1, device=_STATE["device"])
+            _all_reduce(t, dist.ReduceOp.SUM)
+            torch.cuda.synchronize(_STATE["device"])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value: float, device=None) -> float:
@@ -59,13 +154,16 @@ def max_over_ranks(value: float, device=None) -> float:
     if ws == 1:
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=_reduce_device(device))
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    _all_reduce(t, dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def aggregate_results(local: Dict[str, float], device=None) -> Dict[str, float]:
-    """Combine per-rank ``benchmark_method`` dicts: token counts and cache MB are summed, elapsed
-    time is the max over ranks (ranks run concurrently), tokens/sec = total tokens / max elapsed.
+    """Combine per-rank ``benchmark_method`` dicts: token and prompt counts are summed, elapsed time
+    is the max over ranks (ranks run concurrently), tokens/sec = total tokens / max elapsed, and
+    ``est_kv_cache_mb_avg`` stays what the single-process dict reports — the mean over PROMPTS
+    (reference benchmarker.py:804-809) — i.e. per-rank means weighted by their finite-estimate
+    counts (``n_est``; ``n_prompts`` when the caller does not supply it).
     ONE collective pair on two tiny tensors; identical result on every rank."""
     rank, ws = world()
     out = dict(local)
@@ -74,13 +172,13 @@ def aggregate_results(local: Dict[str, float], device=None) -> Dict[str, float]:
         return out
     device = _reduce_device(device)
     est = local.get("est_kv_cache_mb_avg", float("nan"))
-    has_est = 0.0 if est != est else 1.0
-    sums = torch.tensor([float(local.get("total_new_tokens", 0)), (est if has_est else 0.0), has_est,
+    n_est = float(local.get("n_est", local.get("n_prompts", 0))) if est == est else 0.0
+    sums = torch.tensor([float(local.get("total_new_tokens", 0)), (est * n_est if n_est else 0.0), n_est,
                          float(local.get("n_prompts", 0))], dtype=torch.float64, device=device)
     maxs = torch.tensor([float(local.get("elapsed_sec", 0.0)),
                          float(local.get("gpu_peak_mb") or 0.0)], dtype=torch.float64, device=device)
-    dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-    dist.all_reduce(maxs, op=dist.ReduceOp.MAX)
+    _all_reduce(sums, dist.ReduceOp.SUM)
+    _all_reduce(maxs, dist.ReduceOp.MAX)
     total_tokens, est_sum, est_n, n_prompts = sums.tolist()
     elapsed, peak = maxs.tolist()
     out.update({
@@ -103,3 +201,42 @@ def benchmark_sharded(benchmarker, prompts: Sequence[str], method: str, **kw) ->
         "est_kv_cache_mb_avg": float("nan"), "gpu_peak_mb": None}
     res["n_prompts"] = len(mine)
     return aggregate_results(res)
+
+
+# --------------------------------------------------------------------------- the one exchange step
+
+def all_reduce_absmax(table: torch.Tensor) -> torch.Tensor:
+    """``all_reduce(MAX)`` of the ``[G,T]`` fp32 abs-max table IN PLACE: the single data-path
+    collective of the path. RCCL reduces the device tensor directly over xGMI
+    (≤ 8 MiB at config 5; 256 B per decode step); under gloo (CPU tests, or a 1-GPU rehearsal)
+    the table makes a round trip through host memory. MAX of non-negative floats is exact and
+    order-independent, so every rank ends up with bit-identical scales."""
+    _, ws = world()
+    if ws == 1:
+        return table
+    if table.dtype != torch.float32:
+        raise TypeError("abs-max table must be fp32")
+    if table.is_cuda and backend() != "nccl":
+        host = table.detach().cpu()
+        _all_reduce(host, dist.ReduceOp.MAX)
+        table.copy_(host)
+    else:
+        _all_reduce(table, dist.ReduceOp.MAX)
+    return table
+
+
+def quantize_tokens_batch_sharded(x_local, kind: str, eps: float = 1e-8):
+    """Quantise this rank's batch rows ``x_local`` (``[G,B_local,H,T,D]`` on the GPU, or a list of G
+    ``[B_local,H,T,D]`` tensors) of a slice whose batch is split over the ranks, with the scale of
+    the WHOLE batch (reference ops.py:27,48: one ``abs().max()`` per ``[B,H,1,D]`` slice):
+
+        abs-max of the local rows (HIP) -> all_reduce(MAX) of the [G,T] table -> quantise with
+        those abs-max values (HIP)
+
+    Returns ``(q, scales)`` as `kernels.quant_tokens` does for the un-sharded batch: ``q`` holds
+    this rank's rows, ``scales`` ``[G,T]`` (stored scales widened to fp32) is identical on every
+    rank and bit-identical to the un-sharded result."""
+    from . import kernels as K
+    amax = K.absmax_tokens(x_local)
+    all_reduce_absmax(amax)
+    return K.quant_tokens_with_absmax(x_local, amax, kind, eps)

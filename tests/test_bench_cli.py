@@ -1,24 +1,59 @@
-"""bench.py pieces that run without a GPU: the cpu_baseline leg (C oracle on a bounded sample)
-and the refusal to run the hot path on a box without an MI355X."""
+"""bench.py pieces that run without a GPU: the cpu_baseline leg (CPU restatements on a bounded
+sample), the refusal to run the hot path on a box without an MI355X, and the ``--gpus N``
+self-launcher (children that only join the process group and report rank / world)."""
 import json
+import os
 import subprocess
 import sys
 
+import torch
+
 from tests.conftest import ROOT
+
+
+def _bench(*argv, env=None, timeout=300):
+    return subprocess.run([sys.executable, "bench.py", *argv], cwd=ROOT, capture_output=True, text=True, timeout=timeout,
+                          env=dict({k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")},
+                                   **(env or {})))
 
 
 def test_cpu_baseline_leg():
     sys.path.insert(0, ROOT)
     import bench
-    cb = bench.cpu_baseline(L=4, B=1, H=2, T=256, D=64, sample_layers=2)
+    cb = bench.cpu_baseline(L=4, B=1, H=2, T=256, D=64, sample_layers=2, reps=2)
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "GB/s" and cb["value"] > 0
     assert "2/4 layers" in cb["sample"]
+    for leg in ("port", "vectorised", "literal"):  # the three CPU figures, each with cores + reps
+        assert cb[leg]["value"] > 0 and cb[leg]["cores"] >= 1 and cb[leg]["reps"] >= 2, leg
+    assert cb["vectorised"]["cores"] == (os.cpu_count() or 1)
     json.dumps(cb)
 
 
 def test_bench_refuses_without_gpu():
-    import torch
     if torch.cuda.is_available():
         return
-    proc = subprocess.run([sys.executable, "bench.py", "--steps", "1"], cwd=ROOT, capture_output=True, text=True)
+    proc = _bench("--steps", "1")
     assert proc.returncode != 0 and "no CPU path" in (proc.stderr + proc.stdout)
+
+
+def test_gpus_flag_launches_ranks():
+    """--gpus 2 with no launcher around it: the script starts its own two ranks and relays rank 0's line"""
+    proc = _bench("--gpus", "2", "--launcher-selftest")
+    assert proc.returncode == 0, proc.stderr
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["max_rank"] == 1.0 and res["rank_sum"] == 1.0 and res["timing_reduction_backend"] == "gloo"
+
+
+def test_gpus_flag_fails_loudly():
+    if not torch.cuda.is_available():  # more ranks than GPUs without --share-gpu: refused before anything starts
+        proc = _bench("--gpus", "2")
+        assert proc.returncode != 0 and "GPU" in proc.stderr and not proc.stdout.strip()
+    # a rank that dies takes the job down with a non-zero exit code and no result line
+    proc = _bench("--gpus", "2", "--launcher-selftest", env={"KVQ_SELFTEST_FAIL_RANK": "1"})
+    assert proc.returncode != 0 and "rank 1" in proc.stderr and "{" not in proc.stdout
+    # a rank count that disagrees with the launcher's WORLD_SIZE is refused
+    proc = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--launcher-selftest"], cwd=ROOT, capture_output=True,
+                          text=True, env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert proc.returncode != 0 and "WORLD_SIZE" in proc.stderr

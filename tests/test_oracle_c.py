@@ -70,3 +70,19 @@ def test_literal_loop_equals_numpy_oracle(kind):
     assert np.array_equal(torch.cat(qs, dim=2).numpy(), q_ref[0])
     out = LL.dequantize_slices(qs, scales, kind, 16, torch.float16)
     assert np.array_equal(out.numpy().view(np.uint8), O.dequantize_tokens(q_ref, s32, kind, 16, "f16")[0].view(np.uint8))
+
+
+@pytest.mark.parametrize("kind", ["int8", "int4"])
+@pytest.mark.parametrize("shape,dtype", [((2, 2, 3, 9, 16), "f16"), ((1, 1, 8, 5, 128), "f32"), ((2, 2, 3, 7, 5), "f16")])
+def test_vectorised_torch_equals_numpy_oracle(kind, shape, dtype):
+    """The whole-tensor torch-CPU restatement (bench.py's 'vectorised' CPU leg) agrees with the oracle."""
+    import torch
+    from oracle import vectorised_torch as VT
+    x = seeded_kv(shape, dtype, 7, "heavy")
+    q_ref, st_ref, s32 = O.quantize_tokens(x, kind)
+    q, sc = VT.quantize_tokens(torch.from_numpy(x), kind)
+    assert np.array_equal(q.numpy().view(np.uint8), q_ref.view(np.uint8))
+    assert np.array_equal(sc.float().numpy().view(np.uint32), s32.view(np.uint32))
+    for od, td in (("f16", torch.float16), ("f32", torch.float32)):
+        out = VT.dequantize_tokens(q, sc, kind, shape[-1], td)
+        assert np.array_equal(out.numpy().view(np.uint8), O.dequantize_tokens(q_ref, s32, kind, shape[-1], od).view(np.uint8))
