@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--cpu-sample-layers", type=int, default=8)
     ap.add_argument("--tunable", action="append", default=[], metavar="KEY=VALUE",
                     help="A-B only: kvq_set_tunable(KEY, VALUE) before the run (include/kvq_hip.h lists the keys)")
+    ap.add_argument("--per-layer-calls", action="store_true",
+                    help="decode-attention workloads: one host call per layer (kvq_decode_attn) instead of one per step "
+                         "(kvq_decode_step_layers)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="allow more ranks than GPUs (rank r uses GPU r %% n_gpus): a rehearsal of the N > 1 code "
                          "path on a small box, never a scaling number; RCCL refuses duplicate devices, so this "
@@ -287,6 +290,7 @@ def run_attn(args, rank, world, dev):
     (kvq_decode_attn per layer: split-T partial kernel + merge), new token's exact K/V included.
     Side measurement: the same step as the staged path runs it (torch SDPA over the fp16 copy)."""
     import efficient_llm_inference_amd as E
+    from efficient_llm_inference_amd import _lib
     from efficient_llm_inference_amd import kernels as K
     from efficient_llm_inference_amd import sharding
     L, B, Hq, Hkv, T, D, mode = ATTN[args.workload]
@@ -307,10 +311,15 @@ def run_attn(args, rank, world, dev):
     layer_bytes = B * Hkv * T * (K.packed_dim(kk, D) + K.packed_dim(vk, D)) + 8 * T  # rows + two fp32 scales per token
     step_bytes = L * layer_bytes
 
+    plan = K.DecodeLayersPlan(q, kn, vn, out, qc._k.q, qc._k.scales, kk, qc._v.q, qc._v.scales, vk)
+
     def step():
-        for i in range(L):
-            K.decode_attn(q[i], qc._k.q[i], qc._k.scales[i], kk, qc._v.q[i], qc._v.scales[i], vk, T, out[i], ws, sm,
-                          kn[i], vn[i])
+        if args.per_layer_calls:  # one trip through the binding per layer (what an HF attention hook does)
+            for i in range(L):
+                K.decode_attn(q[i], qc._k.q[i], qc._k.scales[i], kk, qc._v.q[i], qc._v.scales[i], vk, T, out[i], ws, sm,
+                              kn[i], vn[i])
+        else:  # kvq_decode_step_layers: ONE host call enqueues every layer's launch
+            K.decode_step_layers(plan, T, ws, sm)
 
     for _ in range(args.warmup):
         step()
@@ -350,10 +359,15 @@ def run_attn(args, rank, world, dev):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "dtype_detail": "int8 / packed-int4 store, fp16 query, fp32 accumulate, fp16 out", "data": "synthetic",
             "config": {"workload": args.workload, "shape_L_B_Hq_Hkv_T_D": [L, B, Hq, Hkv, T, D], "mode": mode,
-                       "step": "one decode step: kvq_decode_attn per layer (2 launches each), host launch gaps included",
+                       "step": "one decode step = every layer's attention over the store: "
+                               + ("kvq_decode_attn per layer" if args.per_layer_calls else "ONE kvq_decode_step_layers call")
+                               + ", host launch gaps included",
+                       "launches_per_layer": 1 if (D in (64, 128) and 3 <= Hq // Hkv <= 16 and _lib.get_tunable("attn_fused")) else 2,
                        "bytes_per_step": int(step_bytes), "parallelism": f"batch-shard x{world}, no collective",
                        "timing_reduction_backend": sharding.backend()},
-            "roofline": {"kernel": ("decode_attn_partial_mfma_k" if D in (64, 128) and 3 <= Hq // Hkv <= 16 else "decode_attn_partial_k (or _mfma_k under --tunable attn_mfma_min_nq)") + " + decode_attn_merge_k (per layer call)", "bound": "hbm",
+            "roofline": {"kernel": ("decode_attn_fused_mfma_k (one launch per layer)" if _lib.get_tunable("attn_fused") and D in (64, 128) and 3 <= Hq // Hkv <= 16
+                                    else ("decode_attn_partial_mfma_k" if D in (64, 128) and 3 <= Hq // Hkv <= 16 else "decode_attn_partial_k")
+                                    + " + decode_attn_merge_k (per layer)"), "bound": "hbm",
                          "achieved": round(layer_bytes / (layer_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(layer_bytes / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": _traffic(args.workload, "decode_attn_per_layer_call"),
                          "algorithmic_bytes_per_launch": int(layer_bytes), "avg_launch_ms": round(layer_ms, 5),

@@ -40,6 +40,7 @@ EXPORTS = (
     "kvq_decode_attn_workspace_cap",
     "kvq_decode_attn",
     "kvq_decode_step",
+    "kvq_decode_step_layers",
     "kvq_set_tunable",
     "kvq_get_tunable",
 )
@@ -109,6 +110,11 @@ def _declare(lib):
     lib.kvq_decode_step.restype = c_int
     lib.kvq_decode_step.argtypes = [P, c_int64, c_int64, P, c_int64, c_int64, P, c_int64, c_int64, P, ST, P, c_int,
                                     P, ST, P, c_int, P, c_int64, c_int64, c_int, c_float, c_float, P, c_int64, AD, P]
+    PP = POINTER(c_void_p)
+    lib.kvq_decode_step_layers.restype = c_int
+    lib.kvq_decode_step_layers.argtypes = [c_int64, c_int, PP, c_int64, c_int64, PP, c_int64, c_int64, PP, c_int64, c_int64,
+                                           PP, ST, PP, c_int, PP, ST, PP, c_int, PP, c_int64, c_int64, c_int, c_float,
+                                           c_float, P, c_int64, AD, P]
     lib.kvq_chunk_summary_len.restype = c_int64
     lib.kvq_chunk_summary_len.argtypes = [c_int64, c_int64, c_int64]
     lib.kvq_set_tunable.restype = c_int

@@ -62,8 +62,10 @@ def trim_kv_sliding_window(past_key_values: tuple, window_size: int) -> tuple:
     out: List[torch.Tensor] = list(flat)
     for (shape, _strides, dtype, device), idx in _by_signature(flat).items():
         B, H, T, D = shape
-        if not T > window_size:
-            continue  # unchanged objects, as the reference
+        if not T > window_size or window_size == 0:
+            # unchanged objects, as the reference; window_size == 0 keeps everything there too
+            # (`k[:, :, -0:, :]` is the whole tensor, reference implementations.py:137-139)
+            continue
         W = int(window_size)
         for c0 in range(0, len(idx), 256):
             part = idx[c0:c0 + 256]
@@ -106,7 +108,7 @@ def _gather_policy(past_key_values: tuple, index_fn) -> tuple:
     out: List[torch.Tensor] = list(flat)
     for (shape, _strides, dtype, device), idx in _by_signature(flat).items():
         B, H, T, D = shape
-        keep = index_fn(T)
+        keep = index_fn(T, device)
         if keep is None:
             continue  # short sequence: unchanged objects, as the reference
         if keep and (min(keep) < 0 or max(keep) >= T):
@@ -124,10 +126,12 @@ def _gather_policy(past_key_values: tuple, index_fn) -> tuple:
 def trim_kv_prefix_window(past_key_values, prefix_len: int, window_size: int):
     """Keep the first ``prefix_len`` and the last ``window_size`` tokens (reference
     implementations.py:143-154)."""
-    def index_fn(T):
+    def index_fn(T, _device):
         if T <= prefix_len + window_size:
             return None
-        return list(range(prefix_len)) + list(range(T - window_size, T))
+        # window_size == 0: the reference's `k[:, :, -0:, :]` is the WHOLE tensor (:151-152), so the result is
+        # the prefix followed by every token
+        return list(range(prefix_len)) + (list(range(T)) if window_size == 0 else list(range(T - window_size, T)))
     return _gather_policy(past_key_values, index_fn)
 
 
@@ -136,7 +140,7 @@ def trim_kv_strided(past_key_values, window_size: int, stride: int, prefix_len: 
     implementations.py:157-190)."""
     assert stride >= 1
 
-    def index_fn(T):
+    def index_fn(T, _device):
         if T <= prefix_len + window_size:
             return None
         tail_start = max(prefix_len, T - window_size)
@@ -151,7 +155,7 @@ def trim_kv_block_old(past_key_values, window_size: int, block_size: int = 64, k
     assert block_size >= 1
     assert 1 <= keep_per_block <= block_size
 
-    def index_fn(T):
+    def index_fn(T, _device):
         if T <= prefix_len + window_size:
             return None
         tail_start = max(prefix_len, T - window_size)
@@ -170,7 +174,7 @@ def trim_kv_budget_old(past_key_values, window_size: int, old_budget: int = 64, 
     implementations.py:248-292)."""
     assert old_budget >= 0
 
-    def index_fn(T):
+    def index_fn(T, device):
         if T <= prefix_len + window_size:
             return None
         tail_start = max(prefix_len, T - window_size)
@@ -179,8 +183,11 @@ def trim_kv_budget_old(past_key_values, window_size: int, old_budget: int = 64, 
         if old_len > 0 and old_budget > 0:
             if old_len <= old_budget:
                 old = list(range(prefix_len, tail_start))
-            else:  # the reference's own expression (:279-282), evaluated on the host
-                sel = torch.linspace(prefix_len, tail_start - 1, steps=old_budget).long()
+            else:
+                # the reference's own expression (:279-282) evaluated where the reference evaluates it — on the
+                # tensors' device — so that the fp32 linspace truncation is the device kernel's; the <= old_budget
+                # indices come back to the host (unique_consecutive synchronises in the reference as well)
+                sel = torch.linspace(prefix_len, tail_start - 1, steps=old_budget, device=device).long()
                 old = torch.unique_consecutive(sel).tolist()
         return list(range(prefix_len)) + old + list(range(tail_start, T))
     return _gather_policy(past_key_values, index_fn)

@@ -27,8 +27,49 @@ int check_launch(const char* what) {
 }
 
 Tunables& tunables() {
-  static Tunables t = {-1, 0, 0, 0, 0, 64, 64, 8, 0, 0, 0, 3, 128, 1};
+  static Tunables t = [] {
+    Tunables d = {};  // every knob 0 unless named here
+    d.dequant_variant = -1;
+    d.pool_block = 64;
+    d.quant_block = 64;
+    d.quant_nv = 8;
+    d.attn_mfma_min_nq = 3;
+    d.attn_mfma_tc = 128;
+    d.nt_loads = 1;
+    return d;
+  }();
   return t;
+}
+
+// name -> field, one table for kvq_set_tunable and kvq_get_tunable
+struct TunableKey {
+  const char* name;
+  int64_t Tunables::*field;
+};
+static const TunableKey kTunableKeys[] = {
+    {"dequant_variant", &Tunables::dequant_variant},
+    {"dequant_grid", &Tunables::dequant_grid},
+    {"quant_force_two_pass", &Tunables::quant_force_two_pass},
+    {"quant_direct_stores", &Tunables::quant_direct_stores},
+    {"pool_grid", &Tunables::pool_grid},
+    {"nt_loads", &Tunables::nt_loads},
+    {"quant_block", &Tunables::quant_block},
+    {"pool_block", &Tunables::pool_block},
+    {"quant_no_regmax", &Tunables::quant_no_regmax},
+    {"quant_nv", &Tunables::quant_nv},
+    {"quant_lds_pad", &Tunables::quant_lds_pad},
+    {"quant_tpw", &Tunables::quant_tpw},
+    {"attn_force_valu", &Tunables::attn_force_valu},
+    {"attn_mfma_min_nq", &Tunables::attn_mfma_min_nq},
+    {"attn_mfma_tc", &Tunables::attn_mfma_tc},
+    {"attn_fused", &Tunables::attn_fused},
+    {"attn_fused_tc", &Tunables::attn_fused_tc},
+    {"attn_fused_nw", &Tunables::attn_fused_nw},
+};
+static int64_t* tunable_slot(const char* key) {
+  for (const TunableKey& k : kTunableKeys)
+    if (!strcmp(key, k.name)) return &(tunables().*(k.field));
+  return nullptr;
 }
 
 }  // namespace kvq
@@ -41,46 +82,19 @@ const char* kvq_last_error_string(void) { return kvq::g_err; }
 
 int kvq_set_tunable(const char* key, int64_t value) {
   if (!key) return KVQ_E_NULL;
-  kvq::Tunables& t = kvq::tunables();
-  if (!strcmp(key, "dequant_variant")) t.dequant_variant = value;
-  else if (!strcmp(key, "dequant_grid")) t.dequant_grid = value;
-  else if (!strcmp(key, "quant_force_two_pass")) t.quant_force_two_pass = value;
-  else if (!strcmp(key, "quant_direct_stores")) t.quant_direct_stores = value;
-  else if (!strcmp(key, "pool_grid")) t.pool_grid = value;
-  else if (!strcmp(key, "nt_loads")) t.nt_loads = value;
-  else if (!strcmp(key, "quant_block")) t.quant_block = value;
-  else if (!strcmp(key, "pool_block")) t.pool_block = value;
-  else if (!strcmp(key, "quant_no_regmax")) t.quant_no_regmax = value;
-  else if (!strcmp(key, "quant_nv")) t.quant_nv = value;
-  else if (!strcmp(key, "quant_lds_pad")) t.quant_lds_pad = value;
-  else if (!strcmp(key, "attn_force_valu")) t.attn_force_valu = value;
-  else if (!strcmp(key, "attn_mfma_min_nq")) t.attn_mfma_min_nq = value;
-  else if (!strcmp(key, "attn_mfma_tc")) t.attn_mfma_tc = value;
-  else {
+  int64_t* slot = kvq::tunable_slot(key);
+  if (!slot) {
     kvq::set_error("kvq_set_tunable: unknown key '%s'", key);
     return KVQ_E_DIMS;
   }
+  *slot = value;
   return 0;
 }
 
 int64_t kvq_get_tunable(const char* key) {
   if (!key) return 0;
-  kvq::Tunables& t = kvq::tunables();
-  if (!strcmp(key, "dequant_variant")) return t.dequant_variant;
-  if (!strcmp(key, "dequant_grid")) return t.dequant_grid;
-  if (!strcmp(key, "quant_force_two_pass")) return t.quant_force_two_pass;
-  if (!strcmp(key, "quant_direct_stores")) return t.quant_direct_stores;
-  if (!strcmp(key, "pool_grid")) return t.pool_grid;
-  if (!strcmp(key, "nt_loads")) return t.nt_loads;
-  if (!strcmp(key, "quant_block")) return t.quant_block;
-  if (!strcmp(key, "pool_block")) return t.pool_block;
-  if (!strcmp(key, "quant_no_regmax")) return t.quant_no_regmax;
-  if (!strcmp(key, "quant_nv")) return t.quant_nv;
-  if (!strcmp(key, "quant_lds_pad")) return t.quant_lds_pad;
-  if (!strcmp(key, "attn_force_valu")) return t.attn_force_valu;
-  if (!strcmp(key, "attn_mfma_min_nq")) return t.attn_mfma_min_nq;
-  if (!strcmp(key, "attn_mfma_tc")) return t.attn_mfma_tc;
-  return 0;
+  const int64_t* slot = kvq::tunable_slot(key);
+  return slot ? *slot : 0;
 }
 
 int64_t kvq_chunk_summary_len(int64_t T, int64_t chunk_size, int64_t keep_last) {

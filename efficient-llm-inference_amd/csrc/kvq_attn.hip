@@ -23,6 +23,7 @@
 //   both write (m, l) and acc[D] per (batch, query head, split) to the caller's workspace
 //   decode_attn_merge_k         grid (query head, batch): log-sum-exp merge of the splits and of the
 //                               exact new token
+#include <atomic>
 #include <type_traits>
 
 #include "kvq_common.h"
@@ -448,27 +449,31 @@ __device__ inline void transpose4x4(uint32_t a0, uint32_t a1, uint32_t a2, uint3
   c[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
 }
 
+// One wave's tile of TC tokens starting at t0 (nt valid ones, 1 <= nt <= TC) of kv head hk, batch row b:
+// on return lane (x, g) holds m (log2 domain) and l of head x, and acc[c][r] = head 4 g + r, element
+// d = DVN x + e(c) (see attn_tile_store) of sum_t p[t] sv[t] v_int[t, d] / svmax. s_ks / s_vs: TC floats of
+// LDS each, private to this wave.
 template <int KBITS, int VBITS, int TC, int HD>
-__global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnArgs a) {
+struct AttnTile {
   static_assert(HD == 64 || HD == 128, "head_dim of the MFMA kernel");
-  constexpr int NT = TC / 16;   // 16-token score tiles
-  constexpr int NS = TC / 32;   // 32-token P V steps
-  constexpr int KS = HD / 32;   // k-steps of the score product
-  constexpr int DVN = HD / 16;  // MFMAs (d values per lane) of a P V step
+  static constexpr int NT = TC / 16;   // 16-token score tiles
+  static constexpr int NS = TC / 32;   // 32-token P V steps
+  static constexpr int KS = HD / 32;   // k-steps of the score product
+  static constexpr int DVN = HD / 16;  // MFMAs (d values per lane) of a P V step
   // K row bytes per lane group and load: 16 (8 for INT4 at head_dim 64); loads per row and lane
-  constexpr int CBK = (HD * KBITS / 8) / 4 < 16 ? 8 : 16;
-  constexpr int NL = (HD * KBITS / 8) / (4 * CBK);
-  constexpr int EPC = CBK * 8 / KBITS;  // elements per chunk
-  constexpr int SPL = EPC / 8;          // k-steps per load
+  static constexpr int CBK = (HD * KBITS / 8) / 4 < 16 ? 8 : 16;
+  static constexpr int NL = (HD * KBITS / 8) / (4 * CBK);
+  static constexpr int EPC = CBK * 8 / KBITS;  // elements per chunk
+  static constexpr int SPL = EPC / 8;          // k-steps per load
   static_assert(NL * SPL == KS, "k-step bookkeeping");
-  constexpr int VB = DVN * VBITS / 8;   // V bytes per lane and row: 8, 4 or 2
-  __shared__ __attribute__((aligned(16))) float s_ks[TC];
-  __shared__ __attribute__((aligned(16))) float s_vs[TC];
-  const uint32_t lane = threadIdx.x;
+  static constexpr int VB = DVN * VBITS / 8;   // V bytes per lane and row: 8, 4 or 2
+  float m, l, svmax;
+  f32x4 acc[DVN];
+
+  __device__ __forceinline__ void run(const AttnArgs& a, const uint32_t b, const uint32_t hk, const uint32_t t0, const uint32_t nt,
+                                      float* s_ks, float* s_vs) {
+  const uint32_t lane = threadIdx.x & 63u;
   const uint32_t x = lane & 15u, g = lane >> 4;
-  const uint32_t split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
-  const uint32_t t0 = split * TC;
-  const uint32_t nt = a.T - t0 < (uint32_t)TC ? a.T - t0 : (uint32_t)TC;
 
   // K / V rows are read with BUFFER loads: descriptor (uniform base of this split's rows, size =
   // the split's valid bytes) + a 32-bit offset (constant lane part + uniform row part: one v_add per
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
   // ---- S = K Q^T: tile i, token row x -----------------------------------------------------------
   f32x4 sc[NT];
   f16x8 qb[KS];
-  float svmax = 0.0f;
+  svmax = 0.0f;
   {
     const uint8_t* kb = a.k + (int64_t)b * a.k_sb + (int64_t)hk * a.k_sh + (int64_t)t0 * a.k_st;
     uint32_t raw[NT][NL][CBK / 4];
@@ -549,9 +554,10 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
           for (int j = 0; j < 4; ++j) w[4 * (c * SPL + wi) + j] = v[j];
         }
     }
-    float ksv[TC / kWave], vsv[TC / kWave];
+    constexpr int SR = (TC + kWave - 1) / kWave;  // TC = 32: the upper half of the wave idles here
+    float ksv[SR], vsv[SR];
 #pragma unroll
-    for (int r = 0; r < TC / kWave; ++r) {
+    for (int r = 0; r < SR; ++r) {
       const uint32_t i = r * kWave + lane;
       const uint32_t ic = i < nt ? i : nt - 1u;
       ksv[r] = a.k_scale[t0 + ic];
@@ -560,7 +566,7 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
     // scores are kept in the log2 domain (one v_exp_f32 per probability); V scales are staged
     // already divided by the split's largest one (the f16 pack of P needs the range, see header)
 #pragma unroll
-    for (int r = 0; r < TC / kWave; ++r) {
+    for (int r = 0; r < SR; ++r) {
       const uint32_t i = r * kWave + lane;
       if (i >= nt) vsv[r] = 0.0f;
       svmax = fmaxf(svmax, vsv[r]);
@@ -568,10 +574,12 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
     svmax = wave_fmax(svmax);
     const float svn = svmax > 0.0f ? 1.0f / svmax : 0.0f;
 #pragma unroll
-    for (int r = 0; r < TC / kWave; ++r) {
+    for (int r = 0; r < SR; ++r) {
       const uint32_t i = r * kWave + lane;
-      s_ks[i] = ksv[r] * (a.sm_scale * 1.44269504088896341f);
-      s_vs[i] = vsv[r] * svn;
+      if (TC >= kWave || i < (uint32_t)TC) {
+        s_ks[i] = ksv[r] * (a.sm_scale * 1.44269504088896341f);
+        s_vs[i] = vsv[r] * svn;
+      }
     }
     // ---- Q^T operands: head x, the 8 d's of this lane group per k-step (zeros for padded heads) ----
     {
@@ -630,10 +638,14 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
       for (int s = 1; s < NS; ++s) load_v_step(s, vr[s]);
     }
   }
-  __syncthreads();  // one wave: publishes s_ks / s_vs
+  // this wave's own LDS writes above are read below by other lanes of the SAME wave: the LDS queue of a
+  // wave is in order, so only the compiler has to be kept from moving the reads up
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   // ---- softmax over this split for head x (log2 domain); P scaled by sv / max sv ------------------
-  float m = -INFINITY;
+  m = -INFINITY;
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const f32x4 ks = *reinterpret_cast<const f32x4*>(&s_ks[16 * i + 4 * g]);
@@ -646,7 +658,7 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
   }
   m = fmaxf(m, __shfl_xor(m, 16));
   m = fmaxf(m, __shfl_xor(m, 32));
-  float l = 0.0f;
+  l = 0.0f;
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const f32x4 sv = *reinterpret_cast<const f32x4*>(&s_vs[16 * i + 4 * g]);
@@ -661,7 +673,6 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
   l += __shfl_xor(l, 32);
 
   // ---- O = P V: column x <-> d = DVN x + e(c) for MFMA c ---------------------------------------------
-  f32x4 acc[DVN];
 #pragma unroll
   for (int n = 0; n < DVN; ++n) acc[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   {
@@ -710,28 +721,323 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
     }
   }
 
+  }
+
+  // acc values of row r (head 4 g + r) in element order: o8[e] for d = DVN x + e
+  __device__ __forceinline__ void ordered(const int r, const float scale, float (&o8)[DVN]) const {
+#pragma unroll
+    for (int c = 0; c < DVN; ++c) {
+      int e = c;
+      if constexpr (VBITS == 4 && HD == 128) e = c < 4 ? 2 * c : 2 * (c - 4) + 1;
+      if constexpr (VBITS == 4 && HD == 64) e = c == 1 ? 2 : (c == 2 ? 1 : c);
+      o8[e] = acc[c][r] * scale;
+    }
+  }
+};
+
+template <int KBITS, int VBITS, int TC, int HD>
+__global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnArgs a) {
+  typedef AttnTile<KBITS, VBITS, TC, HD> Tile;
+  constexpr int DVN = Tile::DVN;
+  __shared__ __attribute__((aligned(16))) float s_ks[TC];
+  __shared__ __attribute__((aligned(16))) float s_vs[TC];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t x = lane & 15u, g = lane >> 4;
+  const uint32_t split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  const uint32_t t0 = split * TC;
+  const uint32_t nt = a.T - t0 < (uint32_t)TC ? a.T - t0 : (uint32_t)TC;
+  Tile tile;
+  tile.run(a, b, hk, t0, nt, s_ks, s_vs);
   // ---- workspace: (m, l) per head, acc[heads][D] --------------------------------------------------
   if (g == 0u && x < a.nq) {
     float* o = a.ws + (((int64_t)b * a.Hq + hk * a.nq + x) * a.nsplit + split) * 2;
-    o[0] = m * 0.693147180559945309f;  // back to the natural-log domain the merge kernel works in
-    o[1] = l;
+    o[0] = tile.m * 0.693147180559945309f;  // back to the natural-log domain the merge kernel works in
+    o[1] = tile.l;
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const uint32_t h = 4 * g + r;
     if (h < a.nq) {
-      // element e of MFMA c. head_dim 128: INT8 c; INT4 c < 4 ? 2c : 2(c-4)+1. head_dim 64: INT8 c; INT4 0,2,1,3
       float o8[DVN];
-#pragma unroll
-      for (int c = 0; c < DVN; ++c) {
-        int e = c;
-        if constexpr (VBITS == 4 && HD == 128) e = c < 4 ? 2 * c : 2 * (c - 4) + 1;
-        if constexpr (VBITS == 4 && HD == 64) e = c == 1 ? 2 : (c == 2 ? 1 : c);
-        o8[e] = acc[c][r] * svmax;
-      }
+      tile.ordered(r, tile.svmax, o8);
       float* dst = a.ws + a.acc_off + (((int64_t)b * a.Hq + hk * a.nq + h) * a.nsplit + split) * a.D + DVN * x;
 #pragma unroll
       for (int c = 0; c < DVN; c += 4) *reinterpret_cast<f32x4*>(dst + c) = f32x4{o8[c], o8[c + 1], o8[c + 2], o8[c + 3]};
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- fused single launch
+// One launch per layer call: NW waves per workgroup, one TC-token tile per wave, then
+//   1. the NW waves' (m, l, acc) are merged through LDS -> ONE partial per workgroup and head
+//      (a quarter / an eighth of the two-launch path's split partials, written once, read once);
+//   2. the partial goes to the workspace with write-through (sc1) stores; every storing wave drains
+//      (s_waitcnt vmcnt(0)), the workgroup's barrier, then ONE lane takes a ticket on the (batch row,
+//      kv head)'s arrival word with an agent-scope fetch_add;
+//   3. the workgroup that draws the last ticket reads every partial back with sc1 loads (they bypass
+//      this CU's L1; no other kind of load touches those bytes), does the log-sum-exp merge with the
+//      exact new token and writes the output rows. No fence, no spin, no residency requirement: a
+//      workgroup never waits for another one, so any grid size and any dispatch order is fine.
+// Arrival word = (epoch << 20) | arrivals, epoch = a process-wide monotone call number. The caller's
+// workspace is never zeroed: at kernel entry one lane reads the word (sc1) and, if it carries another
+// epoch (garbage, or an earlier call), tries ONE compare-and-swap to (epoch << 20). If that CAS fails
+// the word was changed by this launch (an earlier call on the stream has finished), and the first
+// change of a launch can only be a successful CAS of this kind, so the word carries the epoch either
+// way before any workgroup's fetch_add (issued after its own CAS has returned: vmcnt(0) in between).
+// Two extra workgroup columns (blockIdx.x = nwg, nwg + 1; kv head 0 of batch row 0 only) quantise the new
+// token's K / V into slot T of the stores: nothing in this launch reads slot T (the tiles' buffer
+// descriptors end at row T and the scale loads are clamped below T).
+struct FusedArgs {
+  unsigned long long* cnt;  // [B * Hkv] arrival words
+  float* part_ml;           // [B * Hkv][nwg][16][2]: m (log2 domain), l per head
+  float* part_acc;          // [B * Hkv][nwg][nq][D]
+  unsigned long long epoch;
+  uint32_t nwg;             // workgroup splits per (batch row, kv head)
+  int32_t fuse_quant;
+};
+
+__device__ inline float f32_lo(unsigned long long v) { return __uint_as_float((uint32_t)v); }
+__device__ inline float f32_hi(unsigned long long v) { return __uint_as_float((uint32_t)(v >> 32)); }
+
+// quant_new_token_block for a workgroup of `nthreads` threads (kvq_common.h's version is 256-wide)
+template <int IDT>
+__device__ inline void quant_new_token_block_n(const NewTokenArgs& a, uint32_t w, float* s_red, const uint32_t nthreads) {
+  const uint32_t tid = threadIdx.x;
+  const void* x = a.x[w];
+  const uint32_t n = a.B * a.H * a.D;
+  float m = 0.0f;
+  for (uint32_t i = tid; i < n; i += nthreads) {
+    const uint32_t d = i % a.D, r = i / a.D;
+    m = fmaxf(m, fabsf(load1<IDT>(x, (int64_t)(r / a.H) * a.xs_b[w] + (int64_t)(r % a.H) * a.xs_h[w] + d)));
+  }
+  m = wave_fmax(m);
+  if ((tid & 63u) == 0u) s_red[tid >> 6] = m;
+  __syncthreads();
+  m = s_red[0];
+  for (uint32_t i = 1; i < nthreads / kWave; ++i) m = fmaxf(m, s_red[i]);
+  if (a.bits[w] == 8) {
+    const float s32 = fmaxf(m / QRange<8>::qmax, a.eps);
+    if (tid == 0) *a.scale[w] = Elem<IDT>::round_trip(s32);
+    for (uint32_t i = tid; i < n; i += nthreads) {
+      const uint32_t d = i % a.D, r = i / a.D;
+      const float v = load1<IDT>(x, (int64_t)(r / a.H) * a.xs_b[w] + (int64_t)(r % a.H) * a.xs_h[w] + d);
+      a.q[w][(int64_t)(r / a.H) * a.qs_b[w] + (int64_t)(r % a.H) * a.qs_h[w] + d] = (uint8_t)(int8_t)quant1<8>(v, s32);
+    }
+  } else {
+    const float s32 = fmaxf(m / QRange<4>::qmax, a.eps);
+    if (tid == 0) *a.scale[w] = Elem<IDT>::round_trip(s32);
+    const uint32_t Dq = (a.D + 1) / 2;
+    for (uint32_t i = tid; i < a.B * a.H * Dq; i += nthreads) {
+      const uint32_t j = i % Dq, r = i / Dq;
+      const int64_t xo = (int64_t)(r / a.H) * a.xs_b[w] + (int64_t)(r % a.H) * a.xs_h[w];
+      const int hi = quant1<4>(load1<IDT>(x, xo + 2 * j), s32) + 8;
+      const int lo = 2 * j + 1 < a.D ? quant1<4>(load1<IDT>(x, xo + 2 * j + 1), s32) + 8 : 8;
+      a.q[w][(int64_t)(r / a.H) * a.qs_b[w] + (int64_t)(r % a.H) * a.qs_h[w] + j] = (uint8_t)(((hi & 0xF) << 4) | (lo & 0xF));
+    }
+  }
+}
+
+// floats of dynamic LDS the fused kernel needs (host + device agree through this one function)
+__host__ __device__ inline uint32_t fused_lds_floats(uint32_t tc, uint32_t nw, uint32_t hd, uint32_t nq, uint32_t nwg) {
+  const uint32_t tile_phase = nw * 2u * tc + 32u * nw + nw * nq * hd;
+  const uint32_t nthreads = nw * 64u, nvec = nq * hd / 4u;
+  const uint32_t cw = nvec < nthreads ? nvec : nthreads;
+  const uint32_t groups = nthreads / cw;
+  const uint32_t final_phase = 2u * nq * nwg + 68u + groups * nvec * 4u;  // + 4: s_red is aligned up to 16 bytes
+  return tile_phase > final_phase ? tile_phase : final_phase;
+}
+
+template <int KBITS, int VBITS, int TC, int HD, int NW>
+__global__ __launch_bounds__(NW* kWave) void decode_attn_fused_mfma_k(const AttnArgs a, const FusedArgs f, const NewTokenArgs ntok) {
+  typedef AttnTile<KBITS, VBITS, TC, HD> Tile;
+  constexpr int DVN = Tile::DVN;
+  constexpr uint32_t NTH = NW * kWave;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+  const uint32_t x = lane & 15u, g = lane >> 4;
+  if (blockIdx.x >= f.nwg) {  // the new token's K (column nwg) / V (column nwg + 1)
+    if (f.fuse_quant && blockIdx.y == 0u && blockIdx.z == 0u) {
+      if (a.dtype == KVQ_F16) quant_new_token_block_n<KVQ_F16>(ntok, blockIdx.x - f.nwg, smem, NTH);
+      else quant_new_token_block_n<KVQ_BF16>(ntok, blockIdx.x - f.nwg, smem, NTH);
+    }
+    return;
+  }
+  const uint32_t split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  const uint32_t bh = b * a.Hkv + hk;
+  const uint32_t nq = a.nq;
+  unsigned long long old = 0ull;
+  if (tid == 0u) old = __hip_atomic_load(&f.cnt[bh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  // ---- this wave's tile -----------------------------------------------------------------------------
+  const uint32_t t0 = (split * NW + wave) * (uint32_t)TC;
+  const uint32_t nt = t0 < a.T ? (a.T - t0 < (uint32_t)TC ? a.T - t0 : (uint32_t)TC) : 0u;  // wave-uniform
+  Tile tile;
+  if (nt > 0u) {
+    tile.run(a, b, hk, t0, nt, smem + wave * 2 * TC, smem + wave * 2 * TC + TC);
+  } else {  // past the end of the context (last workgroup only): contributes nothing
+    tile.m = -INFINITY;
+    tile.l = 0.0f;
+    tile.svmax = 0.0f;
+#pragma unroll
+    for (int n = 0; n < DVN; ++n) tile.acc[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+  unsigned long long seen = old;
+  if (tid == 0u && (old >> 20) != f.epoch)
+    __hip_atomic_compare_exchange_strong(&f.cnt[bh], &seen, f.epoch << 20, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+
+  // ---- 1. merge the NW waves through LDS ----------------------------------------------------------------
+  float* s_m = smem + NW * 2 * TC;  // [NW][16]
+  float* s_l = s_m + NW * 16;       // [NW][16]
+  float* s_acc = s_l + NW * 16;     // [NW][nq][HD]
+  if (g == 0u) s_m[wave * 16 + x] = tile.m;
+  __syncthreads();
+  {
+    float Mx = s_m[x];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) Mx = fmaxf(Mx, s_m[w * 16 + x]);  // wave 0 always holds >= 1 token: finite
+    if (g == 0u) s_l[wave * 16 + x] = tile.l * __builtin_amdgcn_exp2f(tile.m - Mx);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t h = 4 * g + r;
+      if (h < nq) {
+        float Mh = s_m[h];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) Mh = fmaxf(Mh, s_m[w * 16 + h]);
+        float o8[DVN];
+        tile.ordered(r, __builtin_amdgcn_exp2f(s_m[wave * 16 + h] - Mh) * tile.svmax, o8);
+        float* dst = s_acc + (wave * nq + h) * HD + DVN * x;
+#pragma unroll
+        for (int c = 0; c < DVN; c += 4) *reinterpret_cast<f32x4*>(dst + c) = f32x4{o8[c], o8[c + 1], o8[c + 2], o8[c + 3]};
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. the workgroup's partial -> workspace, write-through ---------------------------------------------
+  const uint32_t nvec = nq * HD / 4u;
+  float* my_ml = f.part_ml + ((int64_t)bh * f.nwg + split) * 32;
+  float* my_acc = f.part_acc + ((int64_t)bh * f.nwg + split) * (int64_t)(nq * HD);
+  {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(my_acc, 0, (int)(nq * HD * 4u), 0x00020000);
+    for (uint32_t v = tid; v < nvec; v += NTH) {
+      f32x4 sum = *reinterpret_cast<const f32x4*>(s_acc + v * 4u);
+#pragma unroll
+      for (int w = 1; w < NW; ++w) sum += *reinterpret_cast<const f32x4*>(s_acc + (uint32_t)w * nq * HD + v * 4u);
+      u32x4 bits;
+      __builtin_memcpy(&bits, &sum, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(bits, rs, v * 16u, 0, 16);  // aux 16 = sc1
+    }
+    if (tid < 16u) {  // head tid: (M, L) as ONE 8-byte sc1 store
+      float M = s_m[tid], L = s_l[tid];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) {
+        M = fmaxf(M, s_m[w * 16 + tid]);
+        L += s_l[w * 16 + tid];
+      }
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(my_ml) + tid,
+                         ((unsigned long long)__float_as_uint(L) << 32) | __float_as_uint(M), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains (also covers lane 0's CAS)
+  __syncthreads();
+  uint32_t* s_flag = reinterpret_cast<uint32_t*>(smem);  // the scale area is free by now
+  if (tid == 0u) {
+    asm volatile("" ::"v"((uint32_t)seen));  // the CAS above is the returning form and has returned
+    const unsigned long long r = __hip_atomic_fetch_add(&f.cnt[bh], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_flag = (r - (f.epoch << 20)) == (unsigned long long)(f.nwg - 1u) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (*s_flag == 0u) return;
+  __syncthreads();  // everyone has read the flag before the area is reused
+
+  // ---- 3. last arriver: log-sum-exp merge of the nwg partials + the exact new token ------------------------
+  const uint32_t nwg = f.nwg;
+  float* s_w = smem;                // [nq][nwg]: m, then the split weights
+  float* s_pl = s_w + nq * nwg;     // [nq][nwg]: l
+  float* s_hL = s_pl + nq * nwg;    // [16] 1 / L
+  float* s_hw = s_hL + 16;          // [16] weight of the new token
+  float* s_red = s_hw + 48;         // [groups][nvec] f32x4 (16-byte aligned: 2 nq nwg + 64 floats; nq nwg even or padded below)
+  s_red = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(s_red) + 15u) & ~(uintptr_t)15u);
+  const bool has_new = a.kn != nullptr;
+  const unsigned long long* all_ml = reinterpret_cast<const unsigned long long*>(f.part_ml + (int64_t)bh * nwg * 32);
+  for (uint32_t i = tid; i < nq * nwg; i += NTH) {
+    const uint32_t sp = i / nq, h = i - sp * nq;
+    const unsigned long long v = __hip_atomic_load(all_ml + sp * 16u + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_w[h * nwg + sp] = f32_lo(v);
+    s_pl[h * nwg + sp] = f32_hi(v);
+  }
+  __syncthreads();
+  for (uint32_t h = wave; h < nq; h += NW) {  // one wave per head
+    float s_tok = -INFINITY;
+    if (has_new) {
+      float part = 0.0f;
+      for (uint32_t d = lane; d < (uint32_t)HD; d += kWave)
+        part += load_elem(a.q, (int64_t)b * a.q_sb + (int64_t)(hk * nq + h) * a.q_sh + d, a.dtype) *
+                load_elem(a.kn, (int64_t)b * a.kn_sb + (int64_t)hk * a.kn_sh + d, a.dtype);
+      s_tok = wave_fsum(part) * (a.sm_scale * 1.44269504088896341f);
+    }
+    float mx = s_tok;
+    for (uint32_t sp = lane; sp < nwg; sp += kWave) mx = fmaxf(mx, s_w[h * nwg + sp]);
+    const float M = wave_fmax(mx);
+    float lsum = 0.0f;
+    for (uint32_t sp = lane; sp < nwg; sp += kWave) {
+      const float wgt = __builtin_amdgcn_exp2f(s_w[h * nwg + sp] - M);
+      s_w[h * nwg + sp] = wgt;
+      lsum += s_pl[h * nwg + sp] * wgt;
+    }
+    const float w_new = has_new ? __builtin_amdgcn_exp2f(s_tok - M) : 0.0f;
+    const float L = wave_fsum(lsum) + w_new;
+    if (lane == 0u) {
+      s_hL[h] = 1.0f / L;
+      s_hw[h] = w_new;
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t cw = nvec < NTH ? nvec : NTH;  // columns (16-byte vectors of the [nq][HD] row) handled side by side
+    const uint32_t groups = NTH / cw;
+    const uint32_t grp = tid / cw, c0 = tid - grp * cw;
+    const float* all_acc = f.part_acc + (int64_t)bh * nwg * (int64_t)(nq * HD);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(all_acc), 0, (int)(nwg * nq * HD * 4u), 0x00020000);
+    if (grp < groups) {
+      for (uint32_t col = c0; col < nvec; col += cw) {
+        const uint32_t h = col / (HD / 4u);
+        const float* wrow = s_w + h * nwg;
+        f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+        uint32_t sp = grp;
+        for (; sp + 3u * groups < nwg; sp += 4u * groups) {  // 4 independent sc1 loads in flight
+          u32x4 r0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (sp * nvec + col) * 16u, 0, 16);
+          u32x4 r1 = __builtin_amdgcn_raw_buffer_load_b128(rs, ((sp + groups) * nvec + col) * 16u, 0, 16);
+          u32x4 r2 = __builtin_amdgcn_raw_buffer_load_b128(rs, ((sp + 2u * groups) * nvec + col) * 16u, 0, 16);
+          u32x4 r3 = __builtin_amdgcn_raw_buffer_load_b128(rs, ((sp + 3u * groups) * nvec + col) * 16u, 0, 16);
+          f32x4 x0, x1, x2, x3;
+          __builtin_memcpy(&x0, &r0, 16);
+          __builtin_memcpy(&x1, &r1, 16);
+          __builtin_memcpy(&x2, &r2, 16);
+          __builtin_memcpy(&x3, &r3, 16);
+          o += x0 * wrow[sp] + x1 * wrow[sp + groups] + x2 * wrow[sp + 2u * groups] + x3 * wrow[sp + 3u * groups];
+        }
+        for (; sp < nwg; sp += groups) {
+          u32x4 r0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (sp * nvec + col) * 16u, 0, 16);
+          f32x4 x0;
+          __builtin_memcpy(&x0, &r0, 16);
+          o += x0 * wrow[sp];
+        }
+        *reinterpret_cast<f32x4*>(s_red + (grp * nvec + col) * 4u) = o;
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nq * (uint32_t)HD; i += NTH) {
+      const uint32_t h = i / (uint32_t)HD, d = i - h * (uint32_t)HD;
+      float t = 0.0f;
+      for (uint32_t k = 0; k < groups; ++k) t += s_red[k * nvec * 4u + i];
+      if (has_new) t = fmaf(s_hw[h], load_elem(a.vn, (int64_t)b * a.vn_sb + (int64_t)hk * a.vn_sh + d, a.dtype), t);
+      t *= s_hL[h];
+      const int64_t oi = (int64_t)b * a.o_sb + (int64_t)(hk * nq + h) * a.o_sh + d;
+      if (a.dtype == KVQ_F16) reinterpret_cast<f16*>(a.out)[oi] = (f16)t;
+      else reinterpret_cast<__bf16*>(a.out)[oi] = (__bf16)t;
     }
   }
 }
@@ -854,6 +1160,74 @@ static bool plan(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit) {
   return *nsplit <= (uint32_t)kAttnMaxSplit;
 }
 
+// ---- fused single launch: which (tokens per wave, waves per workgroup) and how many workgroup splits
+struct FusedPlan {
+  uint32_t tc, nw, nwg, lds_bytes;
+};
+constexpr uint32_t kFusedMaxWg = 256;  // workgroup splits per (batch row, kv head): LDS weights of the final merge
+static bool plan_fused(const kvq_attn_dims_t* d, FusedPlan* p) {
+  if (!use_mfma(d) || d->T <= 0 || !tunables().attn_fused) return false;  // opt-in: measured slower than partial + merge (see header)
+  const int64_t nq = d->Hq / d->Hkv;
+  int64_t tc = 128, nw = 4;
+  if (d->D == 128) {
+    const int64_t waves128 = d->B * d->Hkv * ((d->T + 127) / 128);
+    if (waves128 < 2048) {  // small batches: more, shorter waves (2+ per SIMD) and still >= 1 workgroup per CU
+      tc = 64;
+      nw = 8;
+    }
+    const int64_t ttc = tunables().attn_fused_tc, tnw = tunables().attn_fused_nw;
+    if ((ttc == 128 && tnw == 4) || (ttc == 64 && tnw == 8) || (ttc == 32 && tnw == 16) || (ttc == 128 && tnw == 8)) {
+      tc = ttc;
+      nw = tnw;
+    }
+  }
+  int64_t nwg = (d->T + tc * nw - 1) / (tc * nw);
+  uint32_t lds = 4u * fused_lds_floats((uint32_t)tc, (uint32_t)nw, (uint32_t)d->D, (uint32_t)nq, (uint32_t)nwg);
+  if (lds > 60u * 1024u && !(tc == 128 && nw == 4)) {  // many query heads per kv head: the 4-wave shape needs the least LDS
+    tc = 128;
+    nw = 4;
+    nwg = (d->T + 511) / 512;
+    lds = 4u * fused_lds_floats(128u, 4u, (uint32_t)d->D, (uint32_t)nq, (uint32_t)nwg);
+  }
+  if (nwg > (int64_t)kFusedMaxWg || lds > 60u * 1024u) return false;
+  // partial rows are addressed with 32-bit buffer offsets
+  if (nwg * nq * d->D * 4 >= (int64_t(1) << 31)) return false;
+  p->tc = (uint32_t)tc;
+  p->nw = (uint32_t)nw;
+  p->nwg = (uint32_t)nwg;
+  p->lds_bytes = lds;
+  return true;
+}
+// workspace floats of the fused path for `nwg` workgroup splits: arrival words, (m, l) rows, acc rows
+static int64_t fused_ws_floats(const kvq_attn_dims_t* d, int64_t nwg) {
+  const int64_t bh = d->B * d->Hkv, nq = d->Hq / d->Hkv;
+  return (2 * bh + 3) / 4 * 4 + bh * nwg * (32 + nq * d->D);
+}
+static std::atomic<unsigned long long> g_attn_epoch{1};
+
+template <int KBITS, int VBITS>
+static void launch_fused(const AttnArgs& a, const FusedPlan& p, const NewTokenArgs* nt, hipStream_t st) {
+  FusedArgs f;
+  const int64_t bh = (int64_t)a.B * a.Hkv;
+  f.cnt = reinterpret_cast<unsigned long long*>(a.ws);
+  f.part_ml = a.ws + (2 * bh + 3) / 4 * 4;
+  f.part_acc = f.part_ml + bh * p.nwg * 32;
+  f.epoch = g_attn_epoch.fetch_add(1, std::memory_order_relaxed) & ((1ull << 44) - 1ull);
+  f.nwg = p.nwg;
+  f.fuse_quant = nt ? 1 : 0;
+  NewTokenArgs none = {};
+  const NewTokenArgs& nta = nt ? *nt : none;
+  const dim3 grid(p.nwg + (nt ? 2u : 0u), a.Hkv, a.B);
+#define KVQ_FUSED(TC_, HD_, NW_) \
+  hipLaunchKernelGGL((decode_attn_fused_mfma_k<KBITS, VBITS, TC_, HD_, NW_>), grid, dim3(NW_ * kWave), p.lds_bytes, st, a, f, nta)
+  if (a.D == 64u) KVQ_FUSED(128, 64, 4);
+  else if (p.tc == 128u && p.nw == 4u) KVQ_FUSED(128, 128, 4);
+  else if (p.tc == 128u) KVQ_FUSED(128, 128, 8);
+  else if (p.tc == 64u) KVQ_FUSED(64, 128, 8);
+  else KVQ_FUSED(32, 128, 16);
+#undef KVQ_FUSED
+}
+
 template <int KBITS, int VBITS>
 static void launch_partial(const AttnArgs& a, hipStream_t st) {
   const dim3 grid(a.nsplit, a.Hkv, a.B);
@@ -881,7 +1255,10 @@ int64_t kvq_decode_attn_workspace(const kvq_attn_dims_t* d) {
   uint32_t ts, ns;
   if (!plan(d, &ts, &ns)) return -1;
   const int64_t rows = d->B * d->Hq * (int64_t)(ns > 0 ? ns : 1);
-  return (rows * 2 + 3) / 4 * 4 + rows * d->D;
+  const int64_t legacy = (rows * 2 + 3) / 4 * 4 + rows * d->D;
+  // the fused single-launch path (whatever shape the tunables pick: at most one split per 512 tokens)
+  const int64_t fused = use_mfma(d) ? fused_ws_floats(d, (d->T + 511) / 512 > 0 ? (d->T + 511) / 512 : 1) : 0;
+  return legacy > fused ? legacy : fused;
 }
 
 }  // extern "C"
@@ -976,6 +1353,14 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
     return KVQ_E_DIMS;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  FusedPlan fp;
+  if (plan_fused(d, &fp)) {  // ONE launch: tiles, in-workgroup merge, ticketed final merge, new-token quantise
+    if (k_bits == 8 && v_bits == 8) launch_fused<8, 8>(a, fp, nt, st);
+    else if (k_bits == 8) launch_fused<8, 4>(a, fp, nt, st);
+    else if (v_bits == 8) launch_fused<4, 8>(a, fp, nt, st);
+    else launch_fused<4, 4>(a, fp, nt, st);
+    return check_launch(name);
+  }
   if (a.nsplit > 0) {
     if (k_bits == 8 && v_bits == 8) launch_partial<8, 8>(a, st);
     else if (k_bits == 8) launch_partial<8, 4>(a, st);
@@ -1006,7 +1391,9 @@ int64_t kvq_decode_attn_workspace_cap(const kvq_attn_dims_t* d) {
     if (plan(&t, &ts, &ns) && ns > ns_max) ns_max = ns;
   }
   const int64_t rows = d->B * d->Hq * (int64_t)(ns_max + 1);
-  return (rows * 2 + 3) / 4 * 4 + rows * d->D;
+  const int64_t legacy = (rows * 2 + 3) / 4 * 4 + rows * d->D;
+  const int64_t fused = use_mfma(d) ? fused_ws_floats(d, (d->T + 511) / 512 + 1) : 0;  // monotone in T
+  return legacy > fused ? legacy : fused;
 }
 
 int kvq_decode_attn(const void* q, int64_t q_sb, int64_t q_sh, const uint8_t* k_store, const kvq_strides_t* k_st,
@@ -1065,6 +1452,33 @@ int kvq_decode_step(const void* q, int64_t q_sb, int64_t q_sh, const void* k_new
                                    v_scales + d->T, 0, absmax_ws, eps, &qd, stream)
              : kvq_quant_i4_tokens(v_new, nullptr, &vin, dtype, v_store + d->T * v_st->t, v_st, v_scales + d->T, 0,
                                    absmax_ws, eps, &qd, stream);
+}
+
+int kvq_decode_step_layers(int64_t n_layers, int append, const void* const* q, int64_t q_sb, int64_t q_sh,
+                           const void* const* k_new, int64_t kn_sb, int64_t kn_sh, const void* const* v_new,
+                           int64_t vn_sb, int64_t vn_sh, uint8_t* const* k_store, const kvq_strides_t* k_st,
+                           float* const* k_scales, int k_bits, uint8_t* const* v_store, const kvq_strides_t* v_st,
+                           float* const* v_scales, int v_bits, void* const* out, int64_t o_sb, int64_t o_sh, int dtype,
+                           float sm_scale, float eps, float* workspace, int64_t workspace_floats,
+                           const kvq_attn_dims_t* d, void* stream) {
+  const char* name = "kvq_decode_step_layers";
+  if (n_layers < 0 || !q || !out || !k_store || !v_store || !k_scales || !v_scales || (append && (!k_new || !v_new)) ||
+      ((k_new == nullptr) != (v_new == nullptr))) {
+    set_error("%s: NULL pointer table (or n_layers < 0)", name);
+    return KVQ_E_NULL;
+  }
+  for (int64_t i = 0; i < n_layers; ++i) {
+    const void* kn = k_new ? k_new[i] : nullptr;
+    const void* vn = v_new ? v_new[i] : nullptr;
+    const int rc = append ? kvq_decode_step(q[i], q_sb, q_sh, kn, kn_sb, kn_sh, vn, vn_sb, vn_sh, k_store[i], k_st, k_scales[i], k_bits,
+                                            v_store[i], v_st, v_scales[i], v_bits, out[i], o_sb, o_sh, dtype, sm_scale, eps,
+                                            workspace, workspace_floats, d, stream)
+                          : kvq_decode_attn(q[i], q_sb, q_sh, k_store[i], k_st, k_scales[i], k_bits, v_store[i], v_st,
+                                            v_scales[i], v_bits, kn, kn_sb, kn_sh, vn, vn_sb, vn_sh, out[i], o_sb, o_sh, dtype,
+                                            sm_scale, workspace, workspace_floats, d, stream);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 }  // extern "C"

@@ -43,10 +43,14 @@ struct Tunables {
   int64_t quant_block;           // fused quantise kernel workgroup: 64 (default, one wave per tile), 128 or 256 (measured: 241 / 261 / 270 us)
   int64_t quant_nv;              // 4 = 2048-element one-wave tiles (A-B), else 8
   int64_t quant_no_regmax;       // 1 = keep the LDS abs-max in one-wave tiles (A-B)
+  int64_t quant_tpw;             // tiles per wave of the pipelined one-wave quantise kernel (2 | 4 | 8); 0 = one tile per wave
   int64_t quant_lds_pad;         // A-B: bytes of unused dynamic LDS on the one-wave quantise launch (caps waves per CU)
   int64_t attn_force_valu;       // 1 = decode attention never takes the MFMA kernel (tests / A-B)
   int64_t attn_mfma_min_nq;      // fewest query heads per kv head that take the MFMA kernel at head_dim 128 (default 3)
   int64_t attn_mfma_tc;          // tokens per one-wave split of the MFMA kernel: 128 (default) or 64
+  int64_t attn_fused;            // 1 = decode attention as ONE launch (decode_attn_fused_mfma_k) where it applies; default 0: partial + merge measured faster
+  int64_t attn_fused_tc;         // fused launch, head_dim 128: tokens per wave 128 | 64 | 32 (with attn_fused_nw 4 or 8 | 8 | 16); 0 = by batch size
+  int64_t attn_fused_nw;
   int64_t nt_loads;              // non-temporal input loads in the quantise / pool kernels (default 1: +2-3 % on quantise)
 };
 Tunables& tunables();

@@ -70,23 +70,35 @@ struct GatherArgs {
   Strides osb;  // bytes
   const int32_t* idx;
   uint32_t H, n_idx;
+  uint32_t T;          // source tokens: idx values outside [0, T) never become an address
   uint32_t row_bytes;  // D * elem_size
   uint32_t vecs;       // 16-byte vectors per token row (VEC) or 2-byte units (scalar)
 };
 
 // One lane = one 16-byte piece of one output token row; the lanes of a row read one contiguous
-// source row (HBM-bound row gather: 2 * elem_size bytes per kept element).
+// source row (HBM-bound row gather: 2 * elem_size bytes per kept element). The index table is the
+// caller's DEVICE memory: an index outside [0, T) (torch's index_select raises there) writes a
+// row of zeros instead of reading out of bounds — one compare per row piece.
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void gather_tokens_k(const GatherArgs a, uint32_t items_per_g) {
   const uint32_t g = blockIdx.y;
   constexpr uint32_t kUnit = VEC ? 16u : 2u;
-  for (uint32_t item = blockIdx.x * kBlock + threadIdx.x; item < items_per_g; item += gridDim.x * kBlock) {
+  // 64-bit counter: items_per_g may sit within one grid stride of 2^32
+  for (uint64_t it = (uint64_t)blockIdx.x * kBlock + threadIdx.x; it < items_per_g; it += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t item = (uint32_t)it;
     const uint32_t v = item % a.vecs;
     uint32_t r = item / a.vecs;
     const uint32_t j = r % a.n_idx;
     r /= a.n_idx;
     const uint32_t h = r % a.H, b = r / a.H;
     const int64_t t = a.idx[j];
+    if ((uint64_t)t >= (uint64_t)a.T) {  // also catches negative indices
+      char* bad = a.out + (int64_t)g * a.osb.g + (int64_t)b * a.osb.b + (int64_t)h * a.osb.h + (int64_t)j * a.osb.t +
+                  (int64_t)v * kUnit;
+      if constexpr (VEC) *reinterpret_cast<u32x4*>(bad) = u32x4{0u, 0u, 0u, 0u};
+      else *reinterpret_cast<uint16_t*>(bad) = 0;
+      continue;
+    }
     const char* src = reinterpret_cast<const char*>(a.in.p[g]) + (int64_t)b * a.isb.b + (int64_t)h * a.isb.h +
                       t * a.isb.t + (int64_t)v * kUnit;
     char* dst = a.out + (int64_t)g * a.osb.g + (int64_t)b * a.osb.b + (int64_t)h * a.osb.h + (int64_t)j * a.osb.t +
@@ -318,6 +330,7 @@ int kvq_gather_tokens(const void* in_base, const void* const* in_ptrs, const kvq
   a.idx = idx;
   a.H = (uint32_t)d->H;
   a.n_idx = (uint32_t)n_idx;
+  a.T = (uint32_t)d->T;
   a.row_bytes = (uint32_t)(d->D * elem_size);
   for (int64_t g0 = 0; g0 < d->G; g0 += kPtrsPerLaunch) {
     const int64_t gn = d->G - g0 < kPtrsPerLaunch ? d->G - g0 : kPtrsPerLaunch;

@@ -311,6 +311,90 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------- pipelined one-wave tiles
+// The shipped prefill shape (R rows x 64 vectors per tile, one wave per tile: REGMAX above) as a
+// software pipeline: ONE wave walks TPW consecutive tiles and requests tile n + 1's R non-temporal
+// loads BEFORE it quantises and stores tile n, so that inside a wave reads are in flight while the
+// writes of the previous tile drain (the load-all -> store-all schedule of a single-tile wave alternates
+// the two), and the per-wave start-up (kernel-argument loads, address set-up) is paid once per TPW
+// tiles. Same arithmetic, same bytes, same order of operations per element as quant_tokens_fused_k.
+//   lane = vector `lane` of every row's 64-vector run: token lane >> dvshift, 8 elements at d = 8 (lane & (DV-1))
+//   abs-max across the R rows in registers, across the D/8 lanes of a token by DPP; scale per lane
+//   packed bytes staged in LDS in output order, stored 16 B per lane (R * 64 * BITS / 128 lanes active)
+template <int IDT, int BITS, int R, int TPW>
+__global__ __launch_bounds__(kWave) void quant_tokens_pipe_k(const QuantArgs a) {
+  static_assert(IDT != KVQ_F32, "two-byte inputs only (the fp32 tile does not fit twice)");
+  constexpr int QV = BITS;                       // bytes stored per 8-element vector
+  constexpr uint32_t kRowBytes = 64u * QV;       // one row's run of a tile in the store
+  __shared__ __attribute__((aligned(16))) uint32_t s_out[R * 64 * QV / 4];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t g = blockIdx.y;
+  const uint32_t DV = a.D >> 3;
+  const uint32_t tile0 = blockIdx.x * TPW;
+  const char* in_g = reinterpret_cast<const char*>(a.in.p[g]);
+  uint8_t* q_g = a.q + (int64_t)g * a.qs.g;
+  float* sc_g = a.scales + (int64_t)g * a.ssg;
+
+  auto load_tile = [&](uint32_t tile, Vec8<IDT> (&x)[R]) {
+    const char* src = in_g + ((int64_t)(a.t_begin + tile * a.TT) * a.is.t + (int64_t)lane * 8) * Elem<IDT>::size;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (a.nt_loads) x[r].load_nt(src + (int64_t)r * a.is.h * Elem<IDT>::size);
+      else x[r].load(src + (int64_t)r * a.is.h * Elem<IDT>::size);
+    }
+  };
+  auto process_tile = [&](uint32_t tile, const Vec8<IDT> (&x)[R]) {
+    const uint32_t t0 = a.t_begin + tile * a.TT;
+    uint32_t m = 0u;
+#pragma unroll
+    for (int r = 0; r < R; ++r) m = max(m, x[r].absmax_bits());  // across the tile's rows
+    m = group_umax(m, a.dvshift);                                // across the D/8 lanes of the token
+    const float s32 = fmaxf(Vec8<IDT>::bits_to_f32(m) / QRange<BITS>::qmax, a.eps);
+    const float rcp = 1.0f / s32;
+    if ((lane & (DV - 1u)) == 0u) sc_g[t0 + (lane >> a.dvshift)] = Elem<IDT>::round_trip(s32);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      uint32_t qb[8];
+      quotient_bits8<BITS>(x[r], s32, rcp, qb);
+      const uint32_t widx = ((uint32_t)r * 64u + lane) * (QV / 4);
+      if constexpr (BITS == 8) {
+        const u32x2 w = pack_i8(qb);
+        s_out[widx] = w[0];
+        s_out[widx + 1] = w[1];
+      } else {
+        s_out[widx] = pack_i4(qb);
+      }
+    }
+    // one wave: its LDS queue is in order; only the compiler must not move the reads above the writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint8_t* qbase = q_g + (int64_t)t0 * a.qs.t;
+#pragma unroll
+    for (uint32_t k = lane * 16u; k < (uint32_t)R * kRowBytes; k += 64u * 16u) {
+      const uint32_t r = k / kRowBytes, off = k % kRowBytes;
+      const u32x4 w = *reinterpret_cast<const u32x4*>(&s_out[k >> 2]);
+      if (a.nt_loads) __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off));
+      else *reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off) = w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next tile's staging writes stay below these reads
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  Vec8<IDT> xa[R], xb[R];
+  load_tile(tile0, xa);
+#pragma unroll
+  for (int k = 0; k < TPW; k += 2) {
+    if (k + 1 < TPW) load_tile(tile0 + k + 1, xb);
+    process_tile(tile0 + k, xa);
+    if (k + 1 < TPW) {
+      if (k + 2 < TPW) load_tile(tile0 + k + 2, xa);
+      process_tile(tile0 + k + 1, xb);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------- swept tile (any R)
 // Batched slices whose B*H*D exceeds the register tile (e.g. B = 64): the workgroup still owns
 // TT tokens x all R rows of one group, but sweeps the rows twice in steps of `rpc` rows — once for
@@ -522,11 +606,25 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
       return;
     }
     if (a.blk == 64 || a.blk == 128) {  // small workgroups (host guarantees ROWU + LDS_OUT eligibility)
-      const unsigned n_small = a.nvec == (uint32_t)(a.blk * kNVMax) ? a.T / a.TT : 0u;
+      unsigned n_small = a.nvec == (uint32_t)(a.blk * kNVMax) ? a.T / a.TT : 0u;
       const bool regmax = (1 << a.vshift) == a.blk && !tunables().quant_no_regmax;  // one round == one row
+      unsigned piped = 0;  // tiles taken by the pipelined kernel (multiples of its tiles-per-wave)
+      if constexpr (IDT != KVQ_F32) {
+        const int64_t tpw = tunables().quant_tpw;
+        if (a.blk == 64 && regmax && a.R == 8u && (tpw == 2 || tpw == 4 || tpw == 8) && n_small >= (unsigned)tpw && a.bh_contig) {
+          piped = n_small / (unsigned)tpw * (unsigned)tpw;
+          QuantArgs f = a;
+          f.t_begin = 0;
+          const dim3 grid(piped / (unsigned)tpw, a.G);
+          if (tpw == 2) hipLaunchKernelGGL((quant_tokens_pipe_k<IDT, BITS, 8, 2>), grid, dim3(64), 0, st, f);
+          else if (tpw == 4) hipLaunchKernelGGL((quant_tokens_pipe_k<IDT, BITS, 8, 4>), grid, dim3(64), 0, st, f);
+          else hipLaunchKernelGGL((quant_tokens_pipe_k<IDT, BITS, 8, 8>), grid, dim3(64), 0, st, f);
+        }
+      }
+      n_small -= piped;
       if (n_small) {
         QuantArgs f = a;
-        f.t_begin = 0;
+        f.t_begin = piped * a.TT;
         const dim3 grid(n_small, a.G);
         if (a.blk == 64 && regmax)  // quant_lds_pad: occupancy A-B only (dynamic LDS the kernel never touches)
           hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, true>), grid, dim3(64),
@@ -538,10 +636,10 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
         else
           hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 128>), grid, dim3(128), 0, st, f);
       }
-      if (tiles - n_small) {
+      if (tiles - n_small - piped) {
         QuantArgs t = a;
-        t.t_begin = n_small * a.TT;
-        const dim3 grid(tiles - n_small, a.G);
+        t.t_begin = (n_small + piped) * a.TT;
+        const dim3 grid(tiles - n_small - piped, a.G);
         if (a.blk == 64)
           hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, false, 64>), grid, dim3(64), 0, st, t);
         else

@@ -3,8 +3,9 @@
 Same names and return values as the reference's ``src/evaluation/quality.py`` (:11-150):
 ``compute_perplexity``, ``compute_sliding_window_nll``, ``text_similarity``,
 ``token_agreement_rate``. No kernel content of their own: the sliding-window NLL trims its cache
-through ``trim_kv_sliding_window`` (the HIP path on a GPU) and bridges the transformers cache
-formats with the benchmarker's shim.
+through ``trim_kv_sliding_window`` (the HIP path; GPU models only) and bridges the transformers cache
+formats with the benchmarker's shim. ``text_similarity`` / ``token_agreement_rate`` are pinned to the
+reference's outputs by ``tests/golden/g8_round2.npz``.
 """
 from __future__ import annotations
 
@@ -48,12 +49,9 @@ def compute_sliding_window_nll(model, tokenizer, text: str, window_size: int = 2
         for i in range(1, ids.size(1)):
             out = model(input_ids=prev, use_cache=True, past_key_values=past)
             logits = out.logits[:, -1, :]
-            kv = to_legacy_tuple(out.past_key_values)
-            if kv[0][0].is_cuda:
-                kv = trim_kv_sliding_window(kv, window_size)
-            else:  # host tensors: plain views, there is no CPU kernel path
-                kv = tuple((k[:, :, -window_size:, :], v[:, :, -window_size:, :]) if k.size(2) > window_size else (k, v)
-                           for k, v in kv)
+            # the trim IS the hot path (kvq_window_compact): like every other entry of the package it runs on
+            # the MI355X only and raises KvqError for host tensors — there is no CPU branch
+            kv = trim_kv_sliding_window(to_legacy_tuple(out.past_key_values), window_size)
             past = from_legacy_tuple(kv)
             target = ids[:, i]
             nll_sum += -torch.log_softmax(logits.float(), dim=-1).gather(1, target.unsqueeze(1)).item()

@@ -360,3 +360,81 @@ def decode_step(plan: DecodeStepPlan, q: torch.Tensor, k_new: torch.Tensor, v_ne
         plan.k_ptr, byref(plan.kst), plan.ks_ptr, plan.kbits, plan.v_ptr, byref(plan.vst), plan.vs_ptr, plan.vbits,
         c_void_p(out.data_ptr()), out.stride(0), out.stride(1), plan.dtype_code, float(sm_scale), plan.eps,
         c_void_p(workspace.data_ptr()), workspace.numel(), byref(dims), _lib.current_stream(q.device)), "decode_step")
+
+
+class DecodeLayersPlan:
+    """Pointer tables of :func:`decode_step_layers`: one decode step's attention for ALL layers of a
+    store behind one host call (kvq_decode_step_layers). Built once per (store allocation, query /
+    output buffers); the per-step cost is one ctypes call that enqueues one launch per layer.
+
+    q / out ``[L,B,Hq,D]``, k_new / v_new ``[L,B,Hkv,D]`` (fp16 / bf16; every layer the same strides),
+    k_store / v_store ``[L,B,Hkv,Tcap,Dq]``, k_scales / v_scales ``[L,Tcap]`` fp32."""
+
+    __slots__ = ("L", "B", "Hq", "Hkv", "D", "cap", "tabs", "q_st", "kn_st", "vn_st", "o_st", "kst", "vst", "kbits", "vbits",
+                 "dtype_code", "eps", "has_new", "keep", "device")
+
+    def __init__(self, q: torch.Tensor, k_new, v_new, out: torch.Tensor, k_store: torch.Tensor, k_scales: torch.Tensor,
+                 k_kind: str, v_store: torch.Tensor, v_scales: torch.Tensor, v_kind: str, eps: float = 1e-8):
+        for name, t in (("q", q), ("out", out), ("k_store", k_store), ("v_store", v_store), ("k_scales", k_scales),
+                        ("v_scales", v_scales)):
+            require_gpu(t, name)
+        if q.dim() != 4 or out.shape != q.shape or out.dtype != q.dtype or q.dtype not in (torch.float16, torch.bfloat16):
+            raise _lib.KvqError(f"kvq: decode_step_layers q / out must be matching [L,B,Hq,D] fp16 / bf16 tensors, got {tuple(q.shape)}")
+        L, B, Hq, D = q.shape
+        if k_store.dim() != 5 or v_store.dim() != 5 or k_store.shape[:4] != v_store.shape[:4] or k_store.shape[:2] != (L, B):
+            raise _lib.KvqError("kvq: decode_step_layers stores must be [L,B,Hkv,Tcap,Dq]")
+        Hkv = k_store.size(2)
+        if k_store.dtype != QDTYPE[k_kind] or v_store.dtype != QDTYPE[v_kind] or k_store.size(4) != packed_dim(k_kind, D) \
+                or v_store.size(4) != packed_dim(v_kind, D) or k_store.stride(4) != 1 or v_store.stride(4) != 1:
+            raise _lib.KvqError("kvq: decode_step_layers store dtype / last dim does not match its kind and head_dim")
+        for name, t in (("k_scales", k_scales), ("v_scales", v_scales)):
+            if t.dtype != torch.float32 or t.dim() != 2 or t.size(0) != L or t.stride(1) != 1:
+                raise _lib.KvqError(f"kvq: decode_step_layers {name} must be fp32 [L,Tcap] rows")
+        if q.stride(3) != 1 or out.stride(3) != 1:
+            raise _lib.KvqError("kvq: decode_step_layers q / out last dim must be contiguous")
+        self.has_new = k_new is not None
+        if (k_new is None) != (v_new is None):
+            raise _lib.KvqError("kvq: decode_step_layers k_new and v_new go together")
+        if self.has_new:
+            for name, t in (("k_new", k_new), ("v_new", v_new)):
+                require_gpu(t, name)
+                if tuple(t.shape) != (L, B, Hkv, D) or t.dtype != q.dtype or t.stride(3) != 1:
+                    raise _lib.KvqError(f"kvq: decode_step_layers {name} must be [L,B,Hkv,D] of the query dtype")
+        self.L, self.B, self.Hq, self.Hkv, self.D = L, B, Hq, Hkv, D
+        self.cap = min(k_store.size(3), v_store.size(3), k_scales.size(1), v_scales.size(1))
+
+        def table(t):
+            return _lib.ptr_array([t[i].data_ptr() for i in range(L)])
+
+        self.tabs = {"q": table(q), "out": table(out), "k": table(k_store), "v": table(v_store), "ks": table(k_scales),
+                     "vs": table(v_scales), "kn": table(k_new) if self.has_new else None,
+                     "vn": table(v_new) if self.has_new else None}
+        self.q_st, self.o_st = (q.stride(1), q.stride(2)), (out.stride(1), out.stride(2))
+        self.kn_st = (k_new.stride(1), k_new.stride(2)) if self.has_new else (0, 0)
+        self.vn_st = (v_new.stride(1), v_new.stride(2)) if self.has_new else (0, 0)
+        self.kst = KvqStrides(0, k_store.stride(1), k_store.stride(2), k_store.stride(3))
+        self.vst = KvqStrides(0, v_store.stride(1), v_store.stride(2), v_store.stride(3))
+        self.kbits, self.vbits = KIND_BITS[k_kind], KIND_BITS[v_kind]
+        self.dtype_code = dtype_code(q.dtype)
+        self.eps = float(eps)
+        self.device = q.device
+        self.keep = (q, k_new, v_new, out, k_store, k_scales, v_store, v_scales)
+
+
+def decode_step_layers(plan: DecodeLayersPlan, T: int, workspace: torch.Tensor, sm_scale: float, append: bool = False) -> None:
+    """Every layer's decode attention over its first ``T`` stored tokens (+ the plan's new token) in ONE
+    host call; ``append`` also quantises the new token into slot ``T`` of every layer's store
+    (kvq_decode_step per layer) — the caller bumps its token count afterwards."""
+    T = int(T)
+    if T < 0 or T > plan.cap or (append and (T >= plan.cap or not plan.has_new)):
+        raise _lib.KvqError(f"kvq: decode_step_layers T={T} does not fit the store (capacity {plan.cap}) or append without a new token")
+    require_gpu(workspace, "workspace")
+    if workspace.dtype != torch.float32 or not workspace.is_contiguous():
+        raise _lib.KvqError("kvq: decode_step_layers workspace must be contiguous float32")
+    t = plan.tabs
+    dims = _lib.KvqAttnDims(plan.B, plan.Hq, plan.Hkv, T, plan.D)
+    check(_lib.load().kvq_decode_step_layers(
+        plan.L, 1 if append else 0, t["q"], plan.q_st[0], plan.q_st[1], t["kn"], plan.kn_st[0], plan.kn_st[1],
+        t["vn"], plan.vn_st[0], plan.vn_st[1], t["k"], byref(plan.kst), t["ks"], plan.kbits, t["v"], byref(plan.vst), t["vs"],
+        plan.vbits, t["out"], plan.o_st[0], plan.o_st[1], plan.dtype_code, float(sm_scale), plan.eps,
+        c_void_p(workspace.data_ptr()), workspace.numel(), byref(dims), _lib.current_stream(plan.device)), "decode_step_layers")

@@ -13,7 +13,8 @@ Plumbing (transformers >= 4.54 / 5.x):
   * :class:`FusedQuantizedCache` owns a :class:`QuantizedKVCache` and hands the model a
     ``DynamicCache`` whose layers quantise the prompt's K/V into the store (2 launches per layer) and
     pass the new tokens' exact K/V on to the attention function; a decode token is quantised by the
-    same host call that attends (``kvq_decode_step``: one ctypes call, two launches per layer and step);
+    same host call that attends (``kvq_decode_step``: one ctypes call and, for grouped-query shapes,
+    one launch per layer and step);
   * ``kvq_fused`` is registered with transformers' ``AttentionInterface``; inside
     :func:`fused_attention` the model's ``_attn_implementation`` points at it. A single-token
     query runs ``kernels.decode_attn`` on the layer's store; a prompt (empty cache) runs exact
@@ -23,7 +24,8 @@ Numerics: fp32 accumulation over exact integer x fp16 products; the rounding of 
 value to fp16 that the reference's tuple path performs is skipped, so logits agree within fp16
 tolerance, not bit-for-bit (tests/test_gpu_attn.py, tests/test_gpu_benchmarker.py).
 Limits (fail loudly): fp16 / bf16 models, head_dim in {32, 64, 128, 256}, at most 8 query heads
-per kv head (16 at head_dim 64 / 128), no padding mask during decode, no chunked prefill into a non-empty cache.
+per kv head (16 at head_dim 64 / 128), no padding mask during decode, no chunked prefill into a non-empty cache,
+no sliding-window / soft-capped / attention-sink layers (``_reject_unsupported_variants``).
 """
 from __future__ import annotations
 
@@ -118,6 +120,26 @@ class FusedQuantizedCache:
         return self.qcache.estimated_bytes()
 
 
+# what transformers passes for attention variants this kernel does not implement: plain softmax over
+# EVERY stored token is all it computes, so any of these must stop the run instead of being ignored
+_UNSUPPORTED_KWARGS = ("sliding_window", "softcap", "s_aux", "sinks")
+_UNSUPPORTED_MODULE_ATTRS = ("sliding_window", "sinks", "attn_logit_softcapping")
+
+
+def _reject_unsupported_variants(module, kwargs) -> None:
+    """Sliding-window (Mistral / Qwen2 / Gemma), logit soft-capping (Gemma 2) and attention sinks reach an
+    attention-interface function as keyword arguments or module attributes. Raise on any of them."""
+    for name in _UNSUPPORTED_KWARGS:
+        if kwargs.get(name) is not None:
+            raise RuntimeError(f"kvq: fused attention over the quantised store does not implement '{name}' "
+                               f"(got {kwargs[name]!r}); use the staged path (fused_attention=False) for this model")
+    for name in _UNSUPPORTED_MODULE_ATTRS:
+        if getattr(module, name, None) is not None:
+            raise RuntimeError(f"kvq: fused attention over the quantised store does not implement the attention "
+                               f"variant this layer is configured with ({type(module).__name__}.{name} = "
+                               f"{getattr(module, name)!r}); use the staged path (fused_attention=False)")
+
+
 def _fused_attention_forward(module, query, key, value, attention_mask=None, dropout: float = 0.0,
                              scaling: Optional[float] = None, **kwargs):
     """transformers attention-interface function: ``(attn_output [B, n, Hq, D], None)``."""
@@ -126,6 +148,7 @@ def _fused_attention_forward(module, query, key, value, attention_mask=None, dro
         raise RuntimeError("kvq: the 'kvq_fused' attention runs only inside fused_attention(model, cache)")
     if dropout:
         raise RuntimeError("kvq: fused decode attention is inference-only (dropout must be 0)")
+    _reject_unsupported_variants(module, kwargs)
     B, Hq, n, D = query.shape
     Hkv = key.shape[1]
     scale = float(scaling) if scaling is not None else D ** -0.5

@@ -378,15 +378,17 @@ class QuantizedKVCache:
         self._v.append([v for _, v in past_key_values])
 
     @torch.no_grad()
-    def to_past_key_values(self) -> tuple:
+    def to_past_key_values(self, copy: bool = False) -> tuple:
         """Dequantise to the legacy tuple ``tuple_L[(K, V)]``, each ``[B,H,T,D]`` in compute_dtype
         (reference ops.py:345-355): two launches. With ``incremental=True`` (default) the tuple
-        holds views of two persistent staging buffers and only tokens appended since the previous
-        call are dequantised; ``incremental=False`` re-dequantises everything into fresh buffers,
-        as the reference does. Same values either way."""
+        holds VIEWS of two persistent staging buffers and only tokens appended since the previous
+        call are dequantised — read-only by contract: writing into them corrupts every later step,
+        which the reference's fresh tensors (ops.py:267-269) would not. ``copy=True`` (or
+        ``incremental=False`` on the cache) re-dequantises everything into fresh buffers the caller
+        owns, as the reference does. Same values either way."""
         if not self.layers:
             return tuple()
-        if self.incremental and len(set(self._k.lens)) == 1 and len(set(self._v.lens)) == 1:
+        if not copy and self.incremental and len(set(self._k.lens)) == 1 and len(set(self._v.lens)) == 1:
             # persistent staging: dequantise only what was appended since the last call
             k = self._k.dequant_staged(self.compute_dtype)
             v = self._v.dequant_staged(self.compute_dtype)
@@ -412,16 +414,35 @@ class QuantizedKVCache:
             raise ValueError("Empty cache")
         if append and (k_new is None or v_new is None):
             raise ValueError("kvq: append=True needs k_new and v_new")
+        if q.dim() != 3:
+            raise ValueError(f"kvq: attend takes a [B, Hq, D] query, got {tuple(q.shape)}")
         B, Hq, D = q.shape
-        scale = float(sm_scale) if sm_scale is not None else D ** -0.5
-        out = torch.empty_like(q)
-        need = kernels.decode_attn_workspace_cap(B, Hq, k.H, max(k.cap, T + 1), D)
-        if getattr(self, "_attn_ws", None) is None or self._attn_ws.numel() < need:
-            self._attn_ws = torch.empty(need, dtype=torch.float32, device=q.device)
         if append:
+            # an appended token must be what append_from_past would have been given: the store's own
+            # input dtype (the scale is rounded to it, estimated_bytes counts its itemsize) and shape
+            for name, t in (("k_new", k_new), ("v_new", v_new)):
+                if t.dtype != k.in_dtype or tuple(t.shape) != (k.B, k.H, k.D):
+                    raise ValueError(f"kvq: attend(append=True) {name} {tuple(t.shape)} {t.dtype} does not match the cache "
+                                     f"[B={k.B},H={k.H},D={k.D}] {k.in_dtype}")
             k.reserve(T + 1)
             v.reserve(T + 1)
-            plan = kernels.DecodeStepPlan(q, k.q[layer], k.scales[layer], k.kind, v.q[layer], v.scales[layer], v.kind, k.eps)
+        scale = float(sm_scale) if sm_scale is not None else D ** -0.5
+        out = torch.empty_like(q)
+        # the workspace size (a host loop over the capacity) and the per-layer plans are looked up only when
+        # the shape, the capacity or the store allocation changes — not once per call
+        ws_key = (B, Hq, D, q.dtype, k.cap, q.device)
+        if getattr(self, "_attn_ws_key", None) != ws_key:
+            need = kernels.decode_attn_workspace_cap(B, Hq, k.H, max(k.cap, T + 1), D)
+            if getattr(self, "_attn_ws", None) is None or self._attn_ws.numel() < need or self._attn_ws.device != q.device:
+                self._attn_ws = torch.empty(need, dtype=torch.float32, device=q.device)
+            self._attn_ws_key = ws_key
+            self._attn_plans = {}
+        if append:
+            pkey = (k.q.data_ptr(), v.q.data_ptr(), q.dtype, B, Hq, D)
+            plan = self._attn_plans.get(layer)
+            if plan is None or plan.key[:2] != (k.q[layer].data_ptr(), v.q[layer].data_ptr()) or plan.key[2:] != pkey[2:]:
+                plan = self._attn_plans[layer] = kernels.DecodeStepPlan(q, k.q[layer], k.scales[layer], k.kind, v.q[layer],
+                                                                        v.scales[layer], v.kind, k.eps)
             kernels.decode_step(plan, q, k_new, v_new, T, out, self._attn_ws, scale)
             k.lens[layer] = v.lens[layer] = T + 1
         else:

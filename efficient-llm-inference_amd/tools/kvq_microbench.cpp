@@ -1,6 +1,6 @@
 // kvq_microbench — standalone HIP-event micro-benchmark of libkvq_hip.so on the GPU box.
 //
-//   kvq_microbench [dequant4|dequant8|quant4|quant8|pool|window|copy|all] [iters]
+//   kvq_microbench [dequant4|dequant8|quant4|quant8|pool|window|copy|qtpw|qnv|qocc|qblock|regmax|ntload|pblock|mixed|bufcheck|all] [iters]
 //
 // Sweeps the dequantise tuning variants / grid sizes at the Llama-3-8B seq-16K KV shape
 // (BASELINE config 4: G=32, B=1, H=8, T=16384, D=128) and prints algorithmic GB/s
@@ -346,7 +346,7 @@ int main(int argc, char** argv) {
 
   auto run_quant = [&](int bits) {
     const double bytes = bits == 4 ? N * 2.5 : N * 3.0;
-    for (int two_pass = 0; two_pass < ((what == "ntload" || what == "qblock" || what == "regmax" || what == "qnv" || what == "qocc") ? 1 : 2); ++two_pass) {
+    for (int two_pass = 0; two_pass < ((what == "ntload" || what == "qblock" || what == "regmax" || what == "qnv" || what == "qocc" || what == "qtpw") ? 1 : 2); ++two_pass) {
       KVQ_OK(kvq_set_tunable("quant_force_two_pass", two_pass));
       double ms = tm.ms_per(
           [&] {
@@ -382,6 +382,16 @@ int main(int argc, char** argv) {
         run_quant(8);
       }
     KVQ_OK(kvq_set_tunable("quant_nv", 8));
+  }
+  if (what == "qtpw") {  // tiles per wave of the pipelined one-wave quantise kernel, interleaved rounds (0 = one tile per wave)
+    for (int rep = 0; rep < 4; ++rep)
+      for (int tpw : {0, 2, 4, 8}) {
+        KVQ_OK(kvq_set_tunable("quant_tpw", tpw));
+        printf("quant_tpw=%d\n", tpw);
+        run_quant(4);
+        run_quant(8);
+      }
+    KVQ_OK(kvq_set_tunable("quant_tpw", 0));
   }
   if (what == "qocc") {  // waves per CU of the one-wave quantise kernel, capped through unused dynamic LDS
     for (int rep = 0; rep < 2; ++rep)

@@ -150,7 +150,9 @@ int64_t kvq_chunk_summary_len(int64_t T, int64_t chunk_size, int64_t keep_last);
  * trim_kv_strided, trim_kv_block_old, trim_kv_budget_old (src/cache/implementations.py:143-292):
  *   out[g,b,h,j,:] = in[g,b,h,idx[j],:]   j < n_idx
  * idx is a DEVICE array of n_idx int32 token indices in [0, dims->T) (built by the host from the
- * policy; the library does not validate its contents). elem_size is 2 or 4 bytes. */
+ * policy). The kernel compares every index with dims->T: an index outside the range yields a row of
+ * zeros, never an out-of-bounds read (torch's index_select raises there; the Python wrappers validate
+ * host-built index lists before the call). elem_size is 2 or 4 bytes. */
 int kvq_gather_tokens(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st,
                       void* out, const kvq_strides_t* out_st, int elem_size, const int32_t* idx,
                       int64_t n_idx, const kvq_dims_t* dims, void* stream);
@@ -195,7 +197,10 @@ int kvq_decode_attn(const void* q, int64_t q_stride_b, int64_t q_stride_h,
  * (append_from_past ops.py:323-330, to_past_key_values :345-355, attention) behind one call.
  * The caller guarantees capacity for slot T (k_st / v_st describe the whole [B,Hkv,Tcap,Dq] store)
  * and counts the token as stored afterwards. workspace as for kvq_decode_attn (>= 1 float).
- * Two launches: the new token is quantised by two extra workgroups of the merge launch. */
+ * Two launches: the new token is quantised by two extra workgroups of the merge launch. (Under
+ * kvq_set_tunable("attn_fused", 1) grouped-query shapes take ONE launch — tiles, in-workgroup merge,
+ * ticketed final merge, new-token quantise; csrc/kvq_attn.hip, decode_attn_fused_mfma_k — which
+ * measured slower on MI355X and is therefore opt-in.) The workspace needs no initialisation either way. */
 int kvq_decode_step(const void* q, int64_t q_stride_b, int64_t q_stride_h,
                     const void* k_new, int64_t kn_stride_b, int64_t kn_stride_h,
                     const void* v_new, int64_t vn_stride_b, int64_t vn_stride_h,
@@ -204,10 +209,26 @@ int kvq_decode_step(const void* q, int64_t q_stride_b, int64_t q_stride_h,
                     void* out, int64_t out_stride_b, int64_t out_stride_h, int dtype, float sm_scale, float eps,
                     float* workspace, int64_t workspace_floats, const kvq_attn_dims_t* dims, void* stream);
 
+/* kvq_decode_step (append != 0) or kvq_decode_attn with the new token given (append == 0) for n_layers
+ * layers behind ONE host call: the per-layer launches are enqueued back to back on `stream` (each layer
+ * one launch on the fused path), so a decode step costs one trip through the binding instead of one per
+ * layer — the reference pays 2*T Python-level calls per layer and step here (ops.py:345-355). Every
+ * pointer argument is a HOST array of n_layers device pointers; dims, strides, kinds and dtype are
+ * shared by all layers; `workspace` is reused by consecutive launches (stream order makes that safe).
+ * k_new / v_new may be NULL when append == 0 (attention over the stored tokens only). */
+int kvq_decode_step_layers(int64_t n_layers, int append, const void* const* q, int64_t q_stride_b, int64_t q_stride_h,
+                           const void* const* k_new, int64_t kn_stride_b, int64_t kn_stride_h,
+                           const void* const* v_new, int64_t vn_stride_b, int64_t vn_stride_h,
+                           uint8_t* const* k_store, const kvq_strides_t* k_st, float* const* k_scales, int k_bits,
+                           uint8_t* const* v_store, const kvq_strides_t* v_st, float* const* v_scales, int v_bits,
+                           void* const* out, int64_t out_stride_b, int64_t out_stride_h, int dtype, float sm_scale,
+                           float eps, float* workspace, int64_t workspace_floats, const kvq_attn_dims_t* dims,
+                           void* stream);
+
 /* ---- tuning knobs (benchmarks only; defaults are what ships) ----------------------------- */
 
 /* key: "dequant_variant" (0..30, -1 = shipped default), "dequant_grid" (workgroups, 0 = one chunk
- * each), "quant_force_two_pass" (0/1), "quant_direct_stores" (0/1), "pool_grid" (workgroup cap, 0 = none), "nt_loads" (0/1), "quant_block" (64|128|256), "quant_nv" (8|4|16), "quant_lds_pad" (bytes of unused dynamic LDS, occupancy A-B), "quant_no_regmax" (0/1), "pool_block" (64|128|256), "attn_force_valu" (0/1), "attn_mfma_min_nq" (default 3), "attn_mfma_tc" (128|64).
+ * each), "quant_force_two_pass" (0/1), "quant_direct_stores" (0/1), "pool_grid" (workgroup cap, 0 = none), "nt_loads" (0/1), "quant_block" (64|128|256), "quant_nv" (8|4|16), "quant_lds_pad" (bytes of unused dynamic LDS, occupancy A-B), "quant_no_regmax" (0/1), "pool_block" (64|128|256), "attn_force_valu" (0/1), "attn_mfma_min_nq" (default 3), "attn_mfma_tc" (128|64), "attn_fused" (0/1: decode attention as one launch where it applies; default 0 = partial + merge launches, measured faster), "attn_fused_tc" / "attn_fused_nw" (tokens per wave / waves per workgroup of the fused launch: 128/4, 128/8, 64/8 or 32/16; 0 = by batch size).
  * Returns 0, or KVQ_E_DIMS for an unknown key. Process-global. */
 int kvq_set_tunable(const char* key, int64_t value);
 int64_t kvq_get_tunable(const char* key);

@@ -209,7 +209,7 @@ def trim_kv_sliding_window(x: np.ndarray, window_size: int) -> np.ndarray:
     """Reference ``trim_kv_sliding_window`` (src/cache/implementations.py:124-140) on one
     [..., T, D] tensor: last ``window_size`` tokens if T > window, else unchanged."""
     T = x.shape[-2]
-    if T > window_size:
+    if T > window_size and window_size != 0:  # window_size == 0: the reference's `-0:` slice is the whole tensor (:137-139)
         return x[..., T - window_size :, :]
     return x
 
@@ -269,7 +269,8 @@ def keep_indices_prefix_window(T: int, prefix_len: int, window_size: int):
     window_size tokens; None = unchanged (T <= prefix_len + window_size)."""
     if T <= prefix_len + window_size:
         return None
-    return list(range(prefix_len)) + list(range(T - window_size, T))
+    # window_size == 0: `k[:, :, -0:, :]` is the WHOLE tensor (:151-152): prefix followed by every token
+    return list(range(prefix_len)) + (list(range(T)) if window_size == 0 else list(range(T - window_size, T)))
 
 
 def keep_indices_strided(T: int, window_size: int, stride: int, prefix_len: int = 0):

@@ -18,6 +18,9 @@ Groups:
          to_past_key_values, estimated_bytes) for int8 / int4 / mixed
   G6     trim_kv_sliding_window  (T<W, T==W, T>W)
   G7     chunk_summarize_kv      (old%chunk==0, !=0, T<=keep_last, keep_last=0, re-application)
+  G8     round-2 additions: window_size == 0 edge of the trims (the reference's ``-0:`` slice keeps
+         everything), budget-policy index lists at more lengths, and known-answer tests of the
+         quality helpers text_similarity / token_agreement_rate (src/evaluation/quality.py:124-150)
 """
 import os
 import sys
@@ -248,6 +251,51 @@ def gen_sparse():
     print("g7_sparse:", len(out), "arrays")
 
 
+def gen_round2():
+    """G8 (g8_round2.npz). Strings travel as fixed-width unicode arrays (plain data, no pickle)."""
+    from src.evaluation.quality import text_similarity, token_agreement_rate
+    out = {}
+    # window_size == 0: `k[:, :, -0:, :]` is the whole tensor (implementations.py:137-139, :151-152)
+    for T in (1, 7):
+        x = (torch.arange(T, dtype=torch.float32)[None, None, :, None] + torch.arange(8)[None, None, None, :] / 16.0)
+        x = x.expand(1, 2, T, 8).contiguous().half()
+        (k, _), = trim_kv_sliding_window(((x, x),), 0)
+        out[f"win0.T{T}"] = to_np(k[0, 0, :, 0].float().round().long())
+        for P in (0, 3):
+            (k, _), = trim_kv_prefix_window(((x, x),), prefix_len=P, window_size=0)
+            out[f"prefix0.T{T}.P{P}"] = to_np(k[0, 0, :, 0].float().round().long())
+    # budget policy (fp32 linspace truncated to integers, :279-282) at lengths where the spacing is not integral
+    for T in (97, 513, 2049, 4096, 16385, 32768):
+        x = (torch.arange(T, dtype=torch.float32)[None, None, :, None]).expand(1, 1, T, 2).contiguous()
+        for (W, P, n) in ((8, 0, 7), (256, 32, 64), (33, 5, 100), (1, 1, 3)):
+            (k, _), = trim_kv_budget_old(((x, x),), window_size=W, old_budget=n, prefix_len=P)
+            out[f"budget.T{T}.W{W}.P{P}.n{n}"] = to_np(k[0, 0, :, 0].round().long())
+    # quality helpers
+    pairs = [("", ""), ("abc", "abc"), ("abc", "xyz"), ("the quick brown fox", "the quick brown dog"),
+             ("KV cache quantisation", "KV-cache quantization"), ("aaaa", "aa"), ("hello world", "world hello"),
+             ("a", ""), ("Once upon a time, there was a model.", "Once upon a time there was a small model"),
+             ("0123456789" * 5, "0123456789" * 4 + "abcdefghij")]
+    out["textsim.a"] = np.array([a for a, _ in pairs])
+    out["textsim.b"] = np.array([b for _, b in pairs])
+    out["textsim.ratio"] = np.array([text_similarity(a, b) for a, b in pairs], dtype=np.float64)
+    g = torch.Generator().manual_seed(8000)
+    toks = []
+    for i, (la, lb) in enumerate(((0, 0), (0, 5), (5, 0), (1, 1), (8, 8), (8, 5), (5, 8), (64, 64), (64, 100), (3, 3))):
+        a = torch.randint(0, 4, (la,), generator=g).tolist()
+        b = torch.randint(0, 4, (lb,), generator=g).tolist()
+        if i == 9:
+            b = list(a)
+        toks.append((a, b))
+    width = max(max(len(a), len(b)) for a, b in toks)
+    pad = lambda t: t + [-1] * (width - len(t))  # noqa: E731
+    out["tokagree.a"] = np.array([pad(a) for a, _ in toks], dtype=np.int64)
+    out["tokagree.b"] = np.array([pad(b) for _, b in toks], dtype=np.int64)
+    out["tokagree.len"] = np.array([[len(a), len(b)] for a, b in toks], dtype=np.int64)
+    out["tokagree.rate"] = np.array([token_agreement_rate(a, b) for a, b in toks], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "g8_round2.npz"), **out)
+    print("g8_round2:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     torch.manual_seed(42)
     gen_slices()
@@ -256,3 +304,4 @@ if __name__ == "__main__":
     gen_cache_bf16()
     gen_evict()
     gen_sparse()
+    gen_round2()

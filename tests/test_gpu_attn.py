@@ -283,3 +283,134 @@ def test_decode_attn_rejects_bad_arguments(K):
         K.decode_attn(q.cpu(), ks, sc, "int8", ks, sc, "int8", 8, torch.empty_like(q), ws, 1.0)
     with pytest.raises(KvqError):  # workspace too small
         K.decode_attn(q, ks, sc, "int8", ks, sc, "int8", 8, torch.empty_like(q), ws[:4], 1.0)
+
+
+# ---------------------------------------------------------------------------- fused single launch
+
+FUSED_SHAPES = [(128, 4), (128, 8), (64, 8), (32, 16)]  # (tokens per wave, waves per workgroup)
+
+
+@pytest.fixture
+def tunable():
+    from efficient_llm_inference_amd import _lib
+    touched = []
+
+    def set_(key, value):
+        touched.append(key)
+        _lib.set_tunable(key, value)
+    yield set_
+    for key in touched:
+        _lib.set_tunable(key, 0)
+
+
+@pytest.mark.parametrize("shape", FUSED_SHAPES)
+@pytest.mark.parametrize("kinds", [("int8", "int4"), ("int4", "int8"), ("int8", "int8"), ("int4", "int4")])
+def test_decode_attn_fused_shapes_match_oracle(K, tunable, shape, kinds):
+    """Every (tokens per wave, waves per workgroup) shape of the fused single launch at head_dim 128:
+    one workgroup, a ragged last workgroup, idle waves in the last workgroup, several batch rows."""
+    tunable("attn_fused", 1)
+    tunable("attn_fused_tc", shape[0])
+    tunable("attn_fused_nw", shape[1])
+    for case in [(1, 32, 8, 1000, 128), (2, 6, 2, 200, 128), (1, 16, 1, 300, 128), (1, 32, 8, 5000, 128), (3, 8, 2, 1, 128),
+                 (1, 8, 2, 513, 128), (2, 32, 8, 2048, 128)]:
+        for dtype, with_new in (("f16", True), ("f16", False), ("bf16", True)):
+            _run_case(K, *case, kinds[0], kinds[1], dtype, with_new)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[4] in (64, 128) and 3 <= c[1] // c[2] <= 16])
+def test_decode_attn_fused_default_shape_matches(K, tunable, case):
+    """attn_fused = 1 with the shape picked by batch size (head_dim 64 included): same answers as the
+    default partial + merge pair, which every other test of this file exercises."""
+    tunable("attn_fused", 1)
+    for kinds in (("int8", "int4"), ("int4", "int8")):
+        _run_case(K, *case, kinds[0], kinds[1], "f16", True)
+
+
+@pytest.mark.parametrize("shape", FUSED_SHAPES)
+def test_decode_attn_fused_workspace_reuse(K, tunable, shape):
+    """The arrival words of the fused launch are never zeroed by anyone: a workspace full of garbage
+    (all-ones, then whatever earlier calls left) must work, back-to-back launches on one stream with
+    DIFFERENT inputs and context lengths must each merge their own partials (a stale partial or a
+    miscounted ticket shows up as another call's output), and every (batch row, kv head) must be
+    written exactly once per call."""
+    tunable("attn_fused", 1)
+    tunable("attn_fused_tc", shape[0])
+    tunable("attn_fused_nw", shape[1])
+    B, Hq, Hkv, D = 2, 8, 2, 128
+    Tmax = 6000
+    rng = np.random.default_rng(shape[0] + shape[1])
+    sets = []
+    for i in range(3):
+        k = rng.standard_normal((1, B, Hkv, Tmax, D)).astype(np.float16)
+        v = (rng.standard_normal((1, B, Hkv, Tmax, D)) * (1.0 + i)).astype(np.float16)
+        kq, _, ks = O.quantize_tokens(k, "int8")
+        vq, _, vs = O.quantize_tokens(v, "int4")
+        q = rng.standard_normal((B, Hq, D)).astype(np.float16)
+        sets.append(dict(kq=kq[0], ks=ks[0], vq=vq[0], vs=vs[0], q=q, kq_t=to_torch(kq[0]), ks_t=to_torch(ks[0]),
+                         vq_t=to_torch(vq[0]), vs_t=to_torch(vs[0]), q_t=to_torch(q)))
+    lengths = [6000, 700, 3000, 513, 5999, 1]
+    sm = D ** -0.5
+    ws = torch.empty(K.decode_attn_workspace(B, Hq, Hkv, Tmax, D), dtype=torch.float32, device="cuda")
+    ws.view(torch.int32).fill_(-1)  # all-ones bit patterns in every arrival word and partial
+    calls, outs = [], []
+    for it in range(36):
+        s, T = sets[it % 3], lengths[it % len(lengths)]
+        out = torch.full((B, Hq, D), float("nan"), dtype=torch.float16, device="cuda")
+        K.decode_attn(s["q_t"], s["kq_t"], s["ks_t"], "int8", s["vq_t"], s["vs_t"], "int4", T, out, ws, sm)
+        calls.append((it % 3, T))
+        outs.append(out)
+    torch.cuda.synchronize()
+    refs = {}
+    for (si, T), out in zip(calls, outs):
+        if (si, T) not in refs:
+            s = sets[si]
+            refs[(si, T)] = O.decode_attention(s["q"], s["kq"][:, :, :T], s["ks"][:T], "int8", s["vq"][:, :, :T], s["vs"][:T],
+                                               "int4", D, sm)
+        ref = refs[(si, T)]
+        got = to_numpy(out).astype(np.float64)
+        assert np.isfinite(got).all(), (si, T)
+        assert (np.abs(got - ref) <= TOL["f16"] * (np.abs(ref) + np.abs(ref).max())).all(), (si, T)
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+@pytest.mark.parametrize("append", [False, True])
+def test_decode_step_layers_equals_per_layer_calls(K, tunable, append, fused):
+    """kvq_decode_step_layers: L launches behind one host call == L separate kvq_decode_attn /
+    kvq_decode_step calls, bit for bit (same kernels, same workspace), incl. the appended slot."""
+    tunable("attn_fused", fused)
+    L, B, Hq, Hkv, T, D = 3, 2, 16, 4, 777, 128
+    g = torch.Generator(device="cuda").manual_seed(5)
+    cap = T + 2
+
+    def stores():
+        ks = torch.randint(-127, 128, (L, B, Hkv, cap, D), device="cuda", dtype=torch.int8, generator=torch.Generator(device="cuda").manual_seed(1))
+        vs = torch.randint(0, 256, (L, B, Hkv, cap, D // 2), device="cuda", dtype=torch.uint8, generator=torch.Generator(device="cuda").manual_seed(2))
+        ksc = torch.rand(L, cap, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) * 0.02 + 0.002
+        vsc = torch.rand(L, cap, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4)) * 0.3 + 0.01
+        return ks, vs, ksc, vsc
+    q = torch.randn(L, B, Hq, D, device="cuda", dtype=torch.float16, generator=g)
+    kn = torch.randn(L, B, Hkv, D, device="cuda", dtype=torch.float16, generator=g)
+    vn = torch.randn(L, B, Hkv, D, device="cuda", dtype=torch.float16, generator=g)
+    ws = torch.empty(K.decode_attn_workspace_cap(B, Hq, Hkv, cap, D), dtype=torch.float32, device="cuda")
+    sm = D ** -0.5
+    k1, v1, ks1, vs1 = stores()
+    out1 = torch.empty_like(q)
+    for i in range(L):
+        if append:
+            plan = K.DecodeStepPlan(q[i], k1[i], ks1[i], "int8", v1[i], vs1[i], "int4", 1e-8)
+            K.decode_step(plan, q[i], kn[i], vn[i], T, out1[i], ws, sm)
+        else:
+            K.decode_attn(q[i], k1[i], ks1[i], "int8", v1[i], vs1[i], "int4", T, out1[i], ws, sm, kn[i], vn[i])
+    k2, v2, ks2, vs2 = stores()
+    out2 = torch.empty_like(q)
+    plan = K.DecodeLayersPlan(q, kn, vn, out2, k2, ks2, "int8", v2, vs2, "int4")
+    K.decode_step_layers(plan, T, ws, sm, append=append)
+    torch.cuda.synchronize()
+    assert torch.equal(out1.view(torch.int16), out2.view(torch.int16))
+    assert torch.equal(k1, k2) and torch.equal(v1, v2) and torch.equal(ks1, ks2) and torch.equal(vs1, vs2)
+    if append:  # slot T now holds the quantised new token, bit-exact with the oracle's quantiser
+        kq, _, ksc = O.quantize_tokens(to_numpy(kn)[:, :, :, None, :], "int8")
+        assert np.array_equal(to_numpy(k2[:, :, :, T]), kq[:, :, :, 0]) and np.array_equal(to_numpy(ks2[:, T]), ksc[:, 0])
+    from efficient_llm_inference_amd._lib import KvqError
+    with pytest.raises(KvqError):
+        K.decode_step_layers(plan, cap + 1, ws, sm)

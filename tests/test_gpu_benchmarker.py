@@ -297,3 +297,32 @@ def test_fused_attention_rejects_unsupported_head_dim(rig):
     finally:
         bench.fused_attention = False
     assert bench.model.config._attn_implementation != "kvq_fused"
+
+
+def test_sliding_window_nll_through_hip_equals_plain_slicing(rig):
+    """N4: compute_sliding_window_nll trims its cache through kvq_window_compact; the trim is an exact
+    copy, so the NLL equals the reference's loop (src/evaluation/quality.py:60-121) with plain slicing
+    on the same model — bit for bit. A window longer than the text equals no trimming at all."""
+    import math
+
+    from efficient_llm_inference_amd.evaluation import compute_sliding_window_nll
+    _, model, tok, from_legacy, to_legacy = rig
+    text, W = "<40>", 7
+    got = compute_sliding_window_nll(model, tok, text, window_size=W, device="cuda")
+    ids = tok(text, return_tensors="pt").input_ids.cuda()
+    nll_sum, n_tok, past, prev = 0.0, 0, None, ids[:, :1]
+    with torch.no_grad():
+        for i in range(1, ids.size(1)):
+            out = model(input_ids=prev, use_cache=True, past_key_values=past)
+            logits = out.logits[:, -1, :]
+            kv = tuple((k[:, :, -W:, :].contiguous(), v[:, :, -W:, :].contiguous()) if k.size(2) > W else (k, v)
+                       for k, v in to_legacy(out.past_key_values))
+            past = from_legacy(kv)
+            target = ids[:, i]
+            nll_sum += -torch.log_softmax(logits.float(), dim=-1).gather(1, target.unsqueeze(1)).item()
+            n_tok += 1
+            prev = target.unsqueeze(1)
+    want = nll_sum / n_tok
+    assert got == (want, math.exp(want))
+    wide = compute_sliding_window_nll(model, tok, text, window_size=4096, device="cuda")
+    assert wide[0] > 0 and wide != got

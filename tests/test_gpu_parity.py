@@ -136,8 +136,14 @@ CASES = [  # (G, B, H, T, D)
 ]
 
 
-def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3, direct_stores=False, block=256, nv=8):
+DEFAULT_TPW = None  # the library's shipped tiles-per-wave, read once (tests restore it after A-B settings)
+
+
+def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3, direct_stores=False, block=256, nv=8, tpw=0):
     from efficient_llm_inference_amd import _lib, kernels
+    global DEFAULT_TPW
+    if DEFAULT_TPW is None:
+        DEFAULT_TPW = _lib.get_tunable("quant_tpw")
     G, B, H, T, D = x_np.shape
     x = to_torch(x_np, dtype)
     Dq = kernels.packed_dim(kind, D)
@@ -148,6 +154,7 @@ def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3
     _lib.set_tunable("quant_direct_stores", int(direct_stores))
     _lib.set_tunable("quant_block", int(block))
     _lib.set_tunable("quant_nv", int(nv))
+    _lib.set_tunable("quant_tpw", int(tpw))
     try:
         src = [x[g] for g in range(G)] if as_list else x
         kernels.quant_tokens(src, store[:, :, :, 1:T + 1], scales[:, 1:T + 1], ws, kind)
@@ -156,11 +163,29 @@ def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3
         _lib.set_tunable("quant_direct_stores", 0)
         _lib.set_tunable("quant_block", 64)
         _lib.set_tunable("quant_nv", 8)
+        _lib.set_tunable("quant_tpw", DEFAULT_TPW)
     torch.cuda.synchronize()
     # the window [1, T+1) was written; the guard tokens around it must be untouched
     assert int(store[:, :, :, 0].to(torch.int32).abs().sum()) == 0 and int(store[:, :, :, T + 1:].to(torch.int32).abs().sum()) == 0
     assert float(scales[:, 0].abs().sum()) == 0.0 and float(scales[:, T + 1:].abs().sum()) == 0.0
     return store, scales
+
+
+@pytest.mark.parametrize("case", [(4, 1, 8, 300, 128), (2, 1, 8, 64, 128), (1, 1, 8, 1031, 128), (3, 2, 4, 37, 128), (2, 1, 8, 40, 64)])
+@pytest.mark.parametrize("tpw", [0, 2, 4, 8])
+@pytest.mark.parametrize("kind", ["int8", "int4"])
+def test_quant_pipelined_one_wave_tiles(E, case, tpw, kind):
+    """quant_tokens_pipe_k (a wave walks `tpw` tiles, next tile's loads ahead of this tile's stores): bit-exact
+    q and stored scales for every tiles-per-wave setting, with tile counts that leave a remainder for the
+    one-tile kernel and a ragged last tile, list and single-buffer inputs, fp16 and bf16, all three
+    distributions (\"tiny\" drives the exact-division fallback and zero stored scales)."""
+    G, B, H, T, D = case
+    for dtype, dist, as_list in (("f16", "normal", False), ("f16", "heavy", True), ("bf16", "heavy", False), ("f16", "tiny", True)):
+        x_np = seeded_kv(case, dtype, seed=zlib.crc32(repr((case, dtype, kind, dist, "pipe")).encode()), dist=dist)
+        q_ref, _, s32_ref = O.quantize_tokens(x_np, kind, dtype=odt(dtype))
+        store, scales = _quant_via_kernels(E, x_np, dtype, kind, False, as_list, block=64, tpw=tpw)
+        assert np.array_equal(to_numpy(store[:, :, :, 1:T + 1]), q_ref), (dtype, dist, tpw)
+        assert np.array_equal(bits(scales[:, 1:T + 1]), bits(s32_ref)), (dtype, dist, tpw)
 
 
 @pytest.mark.parametrize("case", CASES)

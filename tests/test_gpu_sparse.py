@@ -129,3 +129,46 @@ def test_all_twelve_methods_on_gpu(E):
     t_full, _ = b.generate_with_cache("<40>", 8)
     t_paged, n, alloc_mb, used_mb, nb = b.generate_with_paged_attention("<40>", 8, block_size=16)
     assert t_paged == t_full and n == 8 and nb == 2 * 3 and alloc_mb >= used_mb > 0
+
+
+def test_gather_out_of_range_index_is_not_dereferenced(E):
+    """kvq_gather_tokens takes a DEVICE index table; an index outside [0, T) (stale table,
+    negative value) must not become an address. The kernel writes a row of zeros there; in-range
+    rows are the exact gather."""
+    from efficient_llm_inference_amd import kernels as K
+    G, B, H, T, D = 2, 1, 3, 10, 64
+    x = torch.randn(G, B, H, T, D, device="cuda", dtype=torch.float16)
+    idx = torch.tensor([0, 9, 10, -1, 2**31 - 1, 4], dtype=torch.int32, device="cuda")
+    out = torch.full((G, B, H, idx.numel(), D), 7.0, device="cuda", dtype=torch.float16)
+    K.gather_tokens(x, out, idx)
+    torch.cuda.synchronize()
+    good = torch.tensor([0, 9, 4], device="cuda")
+    assert torch.equal(out[:, :, :, [0, 1, 5]], x[:, :, :, good])
+    assert float(out[:, :, :, 2:5].abs().max()) == 0.0
+    # the 2-byte-granular path (rows that are not 16-byte multiples)
+    x2 = torch.randn(1, 1, 2, 5, 3, device="cuda", dtype=torch.float16)
+    idx2 = torch.tensor([4, 5, 1], dtype=torch.int32, device="cuda")
+    out2 = torch.full((1, 1, 2, 3, 3), 7.0, device="cuda", dtype=torch.float16)
+    K.gather_tokens(x2, out2, idx2)
+    torch.cuda.synchronize()
+    assert torch.equal(out2[:, :, :, 0], x2[:, :, :, 4]) and torch.equal(out2[:, :, :, 2], x2[:, :, :, 1])
+    assert float(out2[:, :, :, 1].abs().max()) == 0.0
+
+
+def test_round2_edges_on_gpu(E):
+    """g8_round2.npz through the HIP path: window_size == 0 keeps everything (sliding) / repeats the
+    prefix (prefix+window), and the budget policy's device-evaluated fp32 linspace gives the index lists
+    the reference's CPU run produced."""
+    g8 = load_golden("g8_round2.npz")
+    for T in (1, 7):
+        x = _ident(T)
+        (k, v), = E.trim_kv_sliding_window(((x, x),), 0)
+        assert k is x and v is x and _kept(k) == g8[f"win0.T{T}"].tolist()
+        for P in (0, 3):
+            (k, _), = E.trim_kv_prefix_window(((x, x),), prefix_len=P, window_size=0)
+            assert _kept(k) == g8[f"prefix0.T{T}.P{P}"].tolist(), (T, P)
+    for T in (97, 513, 2049, 4096, 16385, 32768):
+        x = torch.arange(T, dtype=torch.float32, device="cuda")[None, None, :, None].expand(1, 1, T, 2).contiguous()
+        for (W, P, n) in ((8, 0, 7), (256, 32, 64), (33, 5, 100), (1, 1, 3)):
+            (k, _), = E.trim_kv_budget_old(((x, x),), window_size=W, old_budget=n, prefix_len=P)
+            assert k[0, 0, :, 0].round().long().cpu().tolist() == g8[f"budget.T{T}.W{W}.P{P}.n{n}"].tolist(), (T, W, P, n)

@@ -35,3 +35,18 @@ def test_paged_golden_is_identity(g7):
     kv = g7["paged.kv"]
     assert np.array_equal(g7["paged.k"], kv[0]) and np.array_equal(g7["paged.v"], kv[1])
     assert g7["paged.meta"].tolist() == [3, 2 * 3 * 2 * 3 * 8 * 8 * 2, 21 * 2 * 3 * 8 * 2 * 2]
+
+
+def test_round2_edges_match_reference():
+    """tests/golden/g8_round2.npz: window_size == 0 (the reference's `-0:` slice keeps the whole tensor,
+    prefix+window then repeats the prefix) and budget index lists at lengths with non-integral spacing."""
+    from tests.conftest import load_golden
+    g8 = load_golden("g8_round2.npz")
+    for T in (1, 7):
+        x = np.arange(T, dtype=np.float32)[:, None] * np.ones((1, 2), np.float32)
+        assert O.trim_kv_sliding_window(x, 0)[:, 0].astype(np.int64).tolist() == g8[f"win0.T{T}"].tolist() == list(range(T))
+        for P in (0, 3):
+            assert _expect(O.keep_indices_prefix_window(T, P, 0), T) == g8[f"prefix0.T{T}.P{P}"].tolist()
+    for T in (97, 513, 2049, 4096, 16385, 32768):
+        for (W, P, n) in ((8, 0, 7), (256, 32, 64), (33, 5, 100), (1, 1, 3)):
+            assert _expect(O.keep_indices_budget_old(T, W, n, P), T) == g8[f"budget.T{T}.W{W}.P{P}.n{n}"].tolist(), (T, W, P, n)
