@@ -63,6 +63,9 @@ static const TunableKey kTunableKeys[] = {
     {"attn_mfma_min_nq", &Tunables::attn_mfma_min_nq},
     {"attn_mfma_tc", &Tunables::attn_mfma_tc},
     {"attn_fused", &Tunables::attn_fused},
+    {"attn_stream_tpw", &Tunables::attn_stream_tpw},
+    {"attn_stream_slots", &Tunables::attn_stream_slots},
+    {"attn_stream_tc", &Tunables::attn_stream_tc},
     {"attn_fused_tc", &Tunables::attn_fused_tc},
     {"attn_fused_nw", &Tunables::attn_fused_nw},
 };

@@ -56,6 +56,7 @@ struct AttnArgs {
   int32_t lpt_shift;  // log2(D / 16): lanes per token
   int32_t dtype;      // KVQ_F16 | KVQ_BF16 (q, k_new, v_new, out)
   int32_t mfma;       // host: the MFMA partial kernel serves this call
+  uint32_t stream_tpw;  // host: > 0 = the streaming MFMA kernel, that many 64-token tiles per wave
 };
 
 __device__ inline f16x2 bits_h2(uint32_t u) {
@@ -767,6 +768,303 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
   }
 }
 
+// ---------------------------------------------------------------------------- streaming variant
+// Larger batches (more tiles than wave slots): ONE wave walks `tpw` consecutive TC-token tiles of its
+// (batch row, kv head) with the NEXT tile's K / V rows and scales requested before the current tile is
+// reduced (two register sets, ping-pong), carries the softmax online across its tiles
+//   m' = max(m, m_tile), alpha = 2^(m - m'), l = l alpha + sum p, acc = acc alpha (svref / svref') + P~ V
+// and writes ONE partial at the end: a wave's loads and arithmetic overlap, the per-wave start-up (query
+// operands, descriptors) is paid once per tpw tiles, and the split partials shrink by tpw.
+// Same operand layouts as AttnTile (see its header). P is scaled by sv[t] / svref with svref the largest
+// V scale seen so far (non-decreasing), the accumulator carries the matching 1 / svref.
+template <int KBITS, int VBITS, int TC, int HD>
+struct AttnStream {
+  typedef AttnTile<KBITS, VBITS, TC, HD> TL;
+  static constexpr int NT = TL::NT, NS = TL::NS, KS = TL::KS, DVN = TL::DVN, CBK = TL::CBK, NL = TL::NL, SPL = TL::SPL, VB = TL::VB;
+  static constexpr int SR = (TC + kWave - 1) / kWave;
+  struct Raw {  // one tile in flight: K rows, V rows, scales — as loaded
+    uint32_t k[NT][NL][CBK / 4];
+    uint32_t v[NS][8][VB == 8 ? 2 : 1];
+    float ks[SR], vs[SR];
+  };
+  f16x8 qb[KS];
+  float m, l, svref;
+  f32x4 acc[DVN];
+
+  __device__ __forceinline__ void init(const AttnArgs& a, const uint32_t b, const uint32_t hk) {
+    const uint32_t lane = threadIdx.x & 63u, x = lane & 15u, g = lane >> 4;
+    uint32_t w[4 * KS];
+    const uint32_t hx = x < a.nq ? x : 0u;  // padded heads read head 0 and are zeroed below
+    const char* qp = reinterpret_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)(hk * a.nq + hx) * a.q_sh) * 2;
+#pragma unroll
+    for (int c = 0; c < NL; ++c)
+#pragma unroll
+      for (int wi = 0; wi < SPL; ++wi) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(qp + (TL::EPC * (4 * c + g) + 8 * wi) * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[4 * (c * SPL + wi) + j] = v[j];
+      }
+    if (a.dtype == KVQ_BF16) {
+#pragma unroll
+      for (int j = 0; j < 4 * KS; ++j) {
+        const f16x2 h = {(f16)__uint_as_float(w[j] << 16), (f16)__uint_as_float(w[j] & 0xFFFF0000u)};
+        w[j] = h2_bits(h);
+      }
+    }
+    if constexpr (KBITS == 4) {
+#pragma unroll
+      for (int c = 0; c < KS; ++c) {
+        const uint32_t w0 = w[4 * c], w1 = w[4 * c + 1], w2 = w[4 * c + 2], w3 = w[4 * c + 3];
+        w[4 * c + 0] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);  // (q0, q2)
+        w[4 * c + 1] = __builtin_amdgcn_perm(w3, w2, 0x05040100u);  // (q4, q6)
+        w[4 * c + 2] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);  // (q1, q3)
+        w[4 * c + 3] = __builtin_amdgcn_perm(w3, w2, 0x07060302u);  // (q5, q7)
+      }
+    }
+    if (x >= a.nq) {
+#pragma unroll
+      for (int j = 0; j < 4 * KS; ++j) w[j] = 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < KS; ++c) qb[c] = pack_h8(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
+    m = -INFINITY;
+    l = 0.0f;
+    svref = 0.0f;
+#pragma unroll
+    for (int n = 0; n < DVN; ++n) acc[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+
+  // request every byte of the tile [t0, t0 + nt): nothing waits here
+  __device__ __forceinline__ void issue(const AttnArgs& a, const uint32_t b, const uint32_t hk, const uint32_t t0, const uint32_t nt, Raw& r) const {
+    const uint32_t lane = threadIdx.x & 63u, x = lane & 15u, g = lane >> 4;
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(a.k + (int64_t)b * a.k_sb + (int64_t)hk * a.k_sh + (int64_t)t0 * a.k_st), 0, (int)(nt * (uint32_t)a.k_st), 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(a.v + (int64_t)b * a.v_sb + (int64_t)hk * a.v_sh + (int64_t)t0 * a.v_st), 0, (int)(nt * (uint32_t)a.v_st), 0x00020000);
+    const uint32_t k_lane = x * (uint32_t)a.k_st + (uint32_t)CBK * g;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int c = 0; c < NL; ++c) {
+        const uint32_t off = k_lane + 16 * i * (uint32_t)a.k_st + 4 * CBK * c;
+        if constexpr (CBK == 16) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, off, 0, 2);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) r.k[i][c][j] = v[j];
+        } else {
+          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(k_rsrc, off, 0, 2);
+          r.k[i][c][0] = v[0];
+          r.k[i][c][1] = v[1];
+        }
+      }
+    const uint32_t v_lane = 4u * g * (uint32_t)a.v_st + (uint32_t)VB * x;
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t row = 32 * sidx + 16 * (j >> 2) + (j & 3);  // + 4 g from the lane offset
+        const uint32_t off = v_lane + row * (uint32_t)a.v_st;
+        if constexpr (VB == 8) {
+          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(v_rsrc, off, 0, 2);
+          r.v[sidx][j][0] = v[0];
+          r.v[sidx][j][1] = v[1];
+        } else if constexpr (VB == 4) {
+          r.v[sidx][j][0] = __builtin_amdgcn_raw_buffer_load_b32(v_rsrc, off, 0, 2);
+        } else {
+          r.v[sidx][j][0] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(v_rsrc, off, 0, 2);
+        }
+      }
+#pragma unroll
+    for (int q = 0; q < SR; ++q) {
+      const uint32_t i = q * kWave + lane;
+      const uint32_t ic = i < nt ? i : nt - 1u;
+      r.ks[q] = a.k_scale[t0 + ic];
+      r.vs[q] = i < nt ? a.v_scale[t0 + ic] : 0.0f;
+    }
+  }
+
+  // fold one loaded tile into the running (m, l, acc); s_ks / s_vs: TC floats each, s_al: 16 floats (this wave's)
+  __device__ __forceinline__ void consume(const AttnArgs& a, const uint32_t nt, const Raw& r, float* s_ks, float* s_vs, float* s_al) {
+    const uint32_t lane = threadIdx.x & 63u, x = lane & 15u, g = lane >> 4;
+    const bool full = nt == (uint32_t)TC;  // uniform
+    // ---- scales: K side with sm_scale log2(e) folded in, V side relative to the running reference ----------
+    float svmax = 0.0f;
+#pragma unroll
+    for (int q = 0; q < SR; ++q) svmax = fmaxf(svmax, r.vs[q]);
+    svmax = wave_fmax(svmax);
+    const float svnew = fmaxf(svref, svmax);
+    const float svn = svnew > 0.0f ? 1.0f / svnew : 0.0f;
+    const float ratio = svnew > 0.0f ? svref * svn : 1.0f;  // <= 1; the first tile's accumulator is 0 anyway
+    svref = svnew;
+#pragma unroll
+    for (int q = 0; q < SR; ++q) {
+      const uint32_t i = q * kWave + lane;
+      if (TC >= kWave || i < (uint32_t)TC) {
+        s_ks[i] = r.ks[q] * (a.sm_scale * 1.44269504088896341f);
+        s_vs[i] = r.vs[q] * svn;
+      }
+    }
+    // ---- S = K Q^T ------------------------------------------------------------------------------------------
+    f32x4 sc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      f32x4 c4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int c = 0; c < NL; ++c) {
+#pragma unroll
+        for (int wi = 0; wi < SPL; ++wi) {
+          uint32_t h[4];
+          if constexpr (KBITS == 8) {
+            bytes_to_h4<128>(r.k[i][c][2 * wi] ^ 0x80808080u, h[0], h[1]);
+            bytes_to_h4<128>(r.k[i][c][2 * wi + 1] ^ 0x80808080u, h[2], h[3]);
+          } else {
+            bytes_to_h4<8>((r.k[i][c][wi] >> 4) & 0x0F0F0F0Fu, h[0], h[1]);  // (e0,e2) (e4,e6)
+            bytes_to_h4<8>(r.k[i][c][wi] & 0x0F0F0F0Fu, h[2], h[3]);         // (e1,e3) (e5,e7)
+          }
+          c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack_h8(h[0], h[1], h[2], h[3]), qb[c * SPL + wi], c4, 0, 0, 0);
+        }
+      }
+      sc[i] = c4;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // s_ks / s_vs written above by this wave's lanes
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- online softmax (log2 domain) -------------------------------------------------------------------------
+    float mt = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const f32x4 ks = *reinterpret_cast<const f32x4*>(&s_ks[16 * i + 4 * g]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        sc[i][q] *= ks[q];
+        if (!full && (uint32_t)(16 * i + 4 * g + q) >= nt) sc[i][q] = -INFINITY;
+        mt = fmaxf(mt, sc[i][q]);
+      }
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 16));
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    const float mnew = fmaxf(m, mt);                          // finite: every tile holds >= 1 token
+    const float alpha = __builtin_amdgcn_exp2f(m - mnew);     // first tile: 2^(-inf) = 0
+    float lt = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(&s_vs[16 * i + 4 * g]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float p = __builtin_amdgcn_exp2f(sc[i][q] - mnew);  // tokens past nt: 2^(-inf) = 0
+        lt += p;
+        sc[i][q] = p * sv[q];
+      }
+    }
+    lt += __shfl_xor(lt, 16);
+    lt += __shfl_xor(lt, 32);
+    l = l * alpha + lt;
+    m = mnew;
+    // the accumulator rows of this lane are heads 4 g + q: their alpha lives in lanes x = 4 g + q
+    if (g == 0u) s_al[x] = alpha * ratio;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const f32x4 al = *reinterpret_cast<const f32x4*>(&s_al[4 * g]);
+#pragma unroll
+    for (int n = 0; n < DVN; ++n) acc[n] *= al;
+    // ---- O += P V ---------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      uint32_t img[DVN / 4][8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t w0 = r.v[sidx][j][0];
+        if constexpr (HD == 128 && VBITS == 8) {
+          img[0][j] = w0 ^ 0x80808080u;
+          img[1][j] = r.v[sidx][j][VB == 8 ? 1 : 0] ^ 0x80808080u;
+        } else if constexpr (HD == 128) {
+          img[0][j] = (w0 >> 4) & 0x0F0F0F0Fu;
+          img[1][j] = w0 & 0x0F0F0F0Fu;
+        } else if constexpr (VBITS == 8) {
+          img[0][j] = w0 ^ 0x80808080u;
+        } else {
+          img[0][j] = ((w0 >> 4) & 0x0F0Fu) | ((w0 & 0x0F0Fu) << 16);
+        }
+      }
+      const f16x8 pa = pack_h8(Elem<KVQ_F16>::pack2(sc[2 * sidx][0], sc[2 * sidx][1]), Elem<KVQ_F16>::pack2(sc[2 * sidx][2], sc[2 * sidx][3]),
+                               Elem<KVQ_F16>::pack2(sc[2 * sidx + 1][0], sc[2 * sidx + 1][1]),
+                               Elem<KVQ_F16>::pack2(sc[2 * sidx + 1][2], sc[2 * sidx + 1][3]));
+      constexpr int BIAS = VBITS == 8 ? 128 : 8;
+#pragma unroll
+      for (int half = 0; half < DVN / 4; ++half) {
+        uint32_t ca[4], cb[4];
+        transpose4x4(img[half][0], img[half][1], img[half][2], img[half][3], ca);  // tokens j = 0..3
+        transpose4x4(img[half][4], img[half][5], img[half][6], img[half][7], cb);  // tokens j = 4..7
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          uint32_t h[4];
+          bytes_to_h4<BIAS>(ca[n], h[0], h[1]);
+          bytes_to_h4<BIAS>(cb[n], h[2], h[3]);
+          acc[4 * half + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, pack_h8(h[0], h[1], h[2], h[3]), acc[4 * half + n], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next tile's staging writes stay below this tile's LDS reads
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+};
+
+// Two tiles' worth of raw rows live in registers: 64-token tiles fit 2 waves per SIMD (<= 256 VGPRs),
+// 32-token tiles 3 (<= 168); the second launch-bounds argument is waves per SIMD for one-wave workgroups.
+template <int KBITS, int VBITS, int TC, int HD>
+__global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_stream_mfma_k(const AttnArgs a, const uint32_t tpw) {
+  typedef AttnStream<KBITS, VBITS, TC, HD> ST;
+  constexpr int DVN = ST::DVN;
+  __shared__ __attribute__((aligned(16))) float s_ks[TC];
+  __shared__ __attribute__((aligned(16))) float s_vs[TC];
+  __shared__ __attribute__((aligned(16))) float s_al[16];
+  const uint32_t lane = threadIdx.x, x = lane & 15u, g = lane >> 4;
+  const uint32_t split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  const uint32_t ntiles = (a.T + (uint32_t)TC - 1u) / (uint32_t)TC;
+  const uint32_t first = split * tpw;
+  const uint32_t last = first + tpw < ntiles ? first + tpw : ntiles;  // host: first < ntiles for every split
+  auto tok0 = [&](uint32_t t) { return t * (uint32_t)TC; };
+  auto ntok = [&](uint32_t t) { return a.T - t * (uint32_t)TC < (uint32_t)TC ? a.T - t * (uint32_t)TC : (uint32_t)TC; };
+  ST st;
+  typename ST::Raw ra, rb;
+  st.issue(a, b, hk, tok0(first), ntok(first), ra);
+  st.init(a, b, hk);
+  for (uint32_t t = first; t < last; t += 2u) {
+    const bool two = t + 1u < last;  // uniform
+    if (two) st.issue(a, b, hk, tok0(t + 1u), ntok(t + 1u), rb);
+    st.consume(a, ntok(t), ra, s_ks, s_vs, s_al);
+    if (two) {
+      if (t + 2u < last) st.issue(a, b, hk, tok0(t + 2u), ntok(t + 2u), ra);
+      st.consume(a, ntok(t + 1u), rb, s_ks, s_vs, s_al);
+    }
+  }
+  // ---- workspace: (m, l) per head, acc[heads][D] — the layout decode_attn_merge_k reads ---------------------
+  if (g == 0u && x < a.nq) {
+    float* o = a.ws + (((int64_t)b * a.Hq + hk * a.nq + x) * a.nsplit + split) * 2;
+    o[0] = st.m * 0.693147180559945309f;
+    o[1] = st.l;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t h = 4 * g + q;
+    if (h < a.nq) {
+      float o8[DVN];
+#pragma unroll
+      for (int c = 0; c < DVN; ++c) {
+        int e = c;
+        if constexpr (VBITS == 4 && HD == 128) e = c < 4 ? 2 * c : 2 * (c - 4) + 1;
+        if constexpr (VBITS == 4 && HD == 64) e = c == 1 ? 2 : (c == 2 ? 1 : c);
+        o8[e] = st.acc[c][q] * st.svref;
+      }
+      float* dst = a.ws + a.acc_off + (((int64_t)b * a.Hq + hk * a.nq + h) * a.nsplit + split) * a.D + DVN * x;
+#pragma unroll
+      for (int c = 0; c < DVN; c += 4) *reinterpret_cast<f32x4*>(dst + c) = f32x4{o8[c], o8[c + 1], o8[c + 2], o8[c + 3]};
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------- fused single launch
 // One launch per layer call: NW waves per workgroup, one TC-token tile per wave, then
 //   1. the NW waves' (m, l, acc) are merged through LDS -> ONE partial per workgroup and head
@@ -1140,7 +1438,29 @@ static bool use_mfma(const kvq_attn_dims_t* d) {
   const int64_t min_nq = tunables().attn_mfma_min_nq > 0 ? tunables().attn_mfma_min_nq : 3;
   return (d->D == 128 || d->D == 64) && nq >= min_nq && nq <= 16 && !tunables().attn_force_valu;
 }
+// streaming kernel: tiles per wave (0 = one-tile kernel). Chosen so that every wave of the launch is resident
+// at once (one round) when the batch offers more 64-token tiles than the chip has wave slots.
+static int stream_tc() { return tunables().attn_stream_tc == 32 ? 32 : 64; }
+static uint32_t stream_tpw(const kvq_attn_dims_t* d) {
+  if (!use_mfma(d) || d->D != 128 || d->T <= 0) return 0;
+  const int64_t forced = tunables().attn_stream_tpw;  // -1 = never, 0 = by size, > 0 = that many
+  if (forced < 0) return 0;
+  const int kStreamTC = stream_tc();
+  const int64_t ntiles = (d->T + kStreamTC - 1) / kStreamTC;
+  // wave slots of one round: 2 waves per SIMD at 64-token tiles, 3 at 32-token tiles
+  const int64_t slots = tunables().attn_stream_slots > 0 ? tunables().attn_stream_slots : 256 * 4 * (kStreamTC == 64 ? 2 : 3);
+  int64_t tpw = forced > 0 ? forced : (ntiles * d->B * d->Hkv + slots - 1) / slots;
+  if (tpw < 2 && forced <= 0) return 0;
+  if (tpw > ntiles) tpw = ntiles;
+  return (uint32_t)tpw;
+}
 static bool plan(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit) {
+  if (const uint32_t tpw = stream_tpw(d)) {  // one wave per tpw tiles of 64 (32) tokens
+    const int64_t per = (int64_t)tpw * stream_tc();
+    *ts = (uint32_t)per;
+    *nsplit = (uint32_t)((d->T + per - 1) / per);
+    if (*nsplit <= (uint32_t)kAttnMaxSplit) return true;
+  }
   if (use_mfma(d)) {  // one wave per split of TC tokens
     int64_t tc = tunables().attn_mfma_tc == 64 && d->D == 128 ? 64 : kAttnMfmaTC;
     if ((d->T + tc - 1) / tc > kAttnMaxSplit) tc = kAttnMfmaTC;
@@ -1231,6 +1551,11 @@ static void launch_fused(const AttnArgs& a, const FusedPlan& p, const NewTokenAr
 template <int KBITS, int VBITS>
 static void launch_partial(const AttnArgs& a, hipStream_t st) {
   const dim3 grid(a.nsplit, a.Hkv, a.B);
+  if (a.mfma && a.stream_tpw) {
+    if (stream_tc() == 64) hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
+    else hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 32, 128>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
+    return;
+  }
   if (a.mfma) {
     if (a.D == 64u) hipLaunchKernelGGL((decode_attn_partial_mfma_k<KBITS, VBITS, kAttnMfmaTC, 64>), grid, dim3(kWave), 0, st, a);
     else if (a.TS == 64u) hipLaunchKernelGGL((decode_attn_partial_mfma_k<KBITS, VBITS, 64, 128>), grid, dim3(kWave), 0, st, a);
@@ -1343,6 +1668,7 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
   a.lpt_shift = ilog2_exact(d->D / 16);
   a.dtype = dtype;
   a.mfma = use_mfma(d) ? 1 : 0;
+  a.stream_tpw = stream_tpw(d);
   if (!plan(d, &a.TS, &a.nsplit)) {
     set_error("%s: T=%lld needs more than %d splits of %d tokens", name, (long long)d->T, kAttnMaxSplit, kAttnMaxTS);
     return KVQ_E_DIMS;

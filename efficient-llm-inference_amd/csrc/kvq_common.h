@@ -48,6 +48,9 @@ struct Tunables {
   int64_t attn_force_valu;       // 1 = decode attention never takes the MFMA kernel (tests / A-B)
   int64_t attn_mfma_min_nq;      // fewest query heads per kv head that take the MFMA kernel at head_dim 128 (default 3)
   int64_t attn_mfma_tc;          // tokens per one-wave split of the MFMA kernel: 128 (default) or 64
+  int64_t attn_stream_tpw;       // streaming MFMA kernel: 64-token tiles per wave; 0 = by size (only when tiles exceed wave slots), -1 = never
+  int64_t attn_stream_tc;        // tokens per tile of the streaming kernel: 64 (default) or 32
+  int64_t attn_stream_slots;     // wave slots the streaming plan fills in one round (default 3072 = 3 per SIMD)
   int64_t attn_fused;            // 1 = decode attention as ONE launch (decode_attn_fused_mfma_k) where it applies; default 0: partial + merge measured faster
   int64_t attn_fused_tc;         // fused launch, head_dim 128: tokens per wave 128 | 64 | 32 (with attn_fused_nw 4 or 8 | 8 | 16); 0 = by batch size
   int64_t attn_fused_nw;

@@ -549,6 +549,61 @@ __global__ __launch_bounds__(kBlock) void quant_tokens_generic_k(const QuantArgs
   }
 }
 
+// ---------------------------------------------------------------------------- split phases (sharded batch)
+// A [B>1,H,1,D] slice whose batch rows are split over ranks still has ONE scale per token (ops.py:27,48:
+// abs().max() of the whole slice), so the fused kernels above cannot be used: the abs-max table must
+// cross ranks between the reduction and the quantisation (one all_reduce(MAX) of [G,T] fp32).
+//   absmax_tokens_vec_k   local rows -> absmax[g,t] (atomic max on the bit pattern of a non-negative float;
+//                         the table is zeroed by the launch function)
+//   quant_tokens_scaled_vec_k   quantise with the GIVEN abs-max values; same quotient / pack / scale code as
+//                         the fused kernels, so a 1-rank run is bit-identical with them
+// 16-byte vectors; shapes that do not qualify take the generic pair (same arithmetic, scalar accesses).
+template <int IDT>
+__global__ __launch_bounds__(kBlock) void absmax_tokens_vec_k(const QuantArgs a, uint32_t vecs_per_g) {
+  const uint32_t g = blockIdx.y;
+  const uint32_t DV = a.D >> 3;
+  const char* in = reinterpret_cast<const char*>(a.in.p[g]);
+  uint32_t* amax = reinterpret_cast<uint32_t*>(a.absmax_ws) + (int64_t)g * a.T;
+  for (uint64_t it = (uint64_t)blockIdx.x * kBlock + threadIdx.x; it < vecs_per_g; it += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t v = (uint32_t)it;
+    const uint32_t dv = v % DV;
+    uint32_t r = v / DV;
+    const uint32_t t = r % a.T;
+    r /= a.T;
+    const uint32_t h = r % a.H, b = r / a.H;
+    Vec8<IDT> x;
+    x.load(in + ((int64_t)b * a.is.b + (int64_t)h * a.is.h + (int64_t)t * a.is.t + (int64_t)dv * 8) * Elem<IDT>::size);
+    atomicMax(amax + t, __float_as_uint(Vec8<IDT>::bits_to_f32(x.absmax_bits())));
+  }
+}
+
+template <int IDT, int BITS>
+__global__ __launch_bounds__(kBlock) void quant_tokens_scaled_vec_k(const QuantArgs a, uint32_t vecs_per_g) {
+  const uint32_t g = blockIdx.y;
+  const uint32_t DV = a.D >> 3;
+  const char* in = reinterpret_cast<const char*>(a.in.p[g]);
+  uint8_t* qg = a.q + (int64_t)g * a.qs.g;
+  const float* amax = a.absmax_ws + (int64_t)g * a.T;
+  constexpr int QV = BITS;
+  for (uint64_t it = (uint64_t)blockIdx.x * kBlock + threadIdx.x; it < vecs_per_g; it += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t v = (uint32_t)it;
+    const uint32_t dv = v % DV;
+    uint32_t r = v / DV;
+    const uint32_t t = r % a.T;
+    r /= a.T;
+    const uint32_t h = r % a.H, b = r / a.H;
+    Vec8<IDT> x;
+    x.load(in + ((int64_t)b * a.is.b + (int64_t)h * a.is.h + (int64_t)t * a.is.t + (int64_t)dv * 8) * Elem<IDT>::size);
+    const float s32 = fmaxf(amax[t] / QRange<BITS>::qmax, a.eps);
+    uint32_t qb[8];
+    quotient_bits8<BITS>(x, s32, 1.0f / s32, qb);
+    uint8_t* qp = qg + (int64_t)b * a.qs.b + (int64_t)h * a.qs.h + (int64_t)t * a.qs.t + (int64_t)dv * QV;
+    if constexpr (BITS == 8) *reinterpret_cast<u32x2*>(qp) = pack_i8(qb);
+    else *reinterpret_cast<uint32_t*>(qp) = pack_i4(qb);
+    if (b == 0u && h == 0u && dv == 0u) a.scales[(int64_t)g * a.ssg + t] = Elem<IDT>::round_trip(s32);
+  }
+}
+
 // ---------------------------------------------------------------------------- host side
 
 static uint32_t pow2_floor(uint64_t v) {
@@ -845,6 +900,119 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
   return 0;
 }
 
+// shared argument checks + QuantArgs of the split-phase entry points; phase 1: q == nullptr
+template <int PHASE>
+static int split_phase(const char* name, int bits, const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st,
+                       int in_dtype, uint8_t* q, const kvq_strides_t* q_st, float* scales, int64_t ssg, float* absmax,
+                       float eps, const kvq_dims_t* d, void* stream) {
+  if (!in_st || !d || !absmax || (!in_base && !in_ptrs) || (PHASE == 2 && (!q || !q_st || !scales))) {
+    set_error("%s: NULL argument", name);
+    return KVQ_E_NULL;
+  }
+  if (in_base && in_ptrs) {
+    set_error("%s: pass in_base or in_ptrs, not both", name);
+    return KVQ_E_DIMS;
+  }
+  if (d->G < 0 || d->B < 0 || d->H < 0 || d->T < 0 || d->D < 0 || d->B >= (int64_t(1) << 31) || d->H >= (int64_t(1) << 31) ||
+      d->T >= (int64_t(1) << 31) || d->D >= (int64_t(1) << 31) || d->B * d->H >= (int64_t(1) << 31)) {
+    set_error("%s: bad dims", name);
+    return KVQ_E_DIMS;
+  }
+  if (in_dtype != KVQ_F16 && in_dtype != KVQ_BF16 && in_dtype != KVQ_F32) {
+    set_error("%s: unknown in_dtype %d", name, in_dtype);
+    return KVQ_E_DTYPE;
+  }
+  if (PHASE == 2 && bits != 8 && bits != 4) {
+    set_error("%s: bits must be 8 or 4", name);
+    return KVQ_E_DIMS;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (PHASE == 1 && d->G * d->T > 0 &&
+      hipMemsetAsync(absmax, 0, sizeof(float) * (size_t)(d->G * d->T), st) != hipSuccess)  // +0.0f: the identity of max over |x|
+    return check_launch(name);
+  if (d->G * d->B * d->H * d->T * d->D == 0) return 0;
+  const int esz = in_dtype == KVQ_F32 ? 4 : 2;
+  QuantArgs a = {};
+  a.is = to_strides(in_st);
+  if (PHASE == 2) a.qs = to_strides(q_st);
+  a.ssg = ssg;
+  a.eps = eps;
+  a.B = (uint32_t)d->B; a.H = (uint32_t)d->H; a.T = (uint32_t)d->T; a.D = (uint32_t)d->D;
+  a.R = (uint32_t)(d->B * d->H);
+  const int64_t qvec = bits == 8 ? 8 : 4;
+  const int64_t vecs = d->B * d->H * d->T * (d->D / 8);
+  bool vec = d->D % 8 == 0 && vecs < (int64_t(1) << 32) && (a.is.b * esz) % 16 == 0 && (a.is.h * esz) % 16 == 0 &&
+             (a.is.t * esz) % 16 == 0;
+  if (PHASE == 2)
+    vec = vec && a.qs.g % qvec == 0 && a.qs.b % qvec == 0 && a.qs.h % qvec == 0 && a.qs.t % qvec == 0 && aligned(q, qvec);
+  for (int64_t g0 = 0; g0 < d->G; g0 += kPtrsPerLaunch) {
+    const int64_t gn = d->G - g0 < kPtrsPerLaunch ? d->G - g0 : kPtrsPerLaunch;
+    bool vec_here = vec;
+    for (int64_t i = 0; i < gn; ++i) {
+      const void* p = in_ptrs ? in_ptrs[g0 + i] : static_cast<const char*>(in_base) + (g0 + i) * a.is.g * (int64_t)esz;
+      if (!p) {
+        set_error("%s: in_ptrs[%lld] is NULL", name, (long long)(g0 + i));
+        return KVQ_E_NULL;
+      }
+      if (!aligned(p, 16)) vec_here = false;
+      a.in.p[i] = p;
+    }
+    a.G = (uint32_t)gn;
+    a.absmax_ws = absmax + g0 * d->T;
+    if (PHASE == 2) {
+      a.q = q + g0 * a.qs.g;
+      a.scales = scales + g0 * ssg;
+    }
+    int64_t blocks = vec_here ? (vecs + kBlock - 1) / kBlock : 0;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    const dim3 grid((unsigned)blocks, (unsigned)gn);
+#define KVQ_BY_DTYPE(EXPR_F16, EXPR_BF16, EXPR_F32) \
+  switch (in_dtype) { case KVQ_F16: EXPR_F16; break; case KVQ_BF16: EXPR_BF16; break; default: EXPR_F32; break; }
+    if (PHASE == 1) {
+      if (vec_here) {
+        KVQ_BY_DTYPE(hipLaunchKernelGGL((absmax_tokens_vec_k<KVQ_F16>), grid, dim3(kBlock), 0, st, a, (uint32_t)vecs),
+                     hipLaunchKernelGGL((absmax_tokens_vec_k<KVQ_BF16>), grid, dim3(kBlock), 0, st, a, (uint32_t)vecs),
+                     hipLaunchKernelGGL((absmax_tokens_vec_k<KVQ_F32>), grid, dim3(kBlock), 0, st, a, (uint32_t)vecs))
+      } else {
+        const int64_t RD = (int64_t)a.R * a.D, chunk_elems = (int64_t)kBlock * 16;
+        const uint32_t cpt = (uint32_t)((RD + chunk_elems - 1) / chunk_elems);
+        const dim3 ggrid((unsigned)(a.T * cpt), (unsigned)gn);
+        KVQ_BY_DTYPE(hipLaunchKernelGGL((absmax_tokens_generic_k<KVQ_F16>), ggrid, dim3(kBlock), 0, st, a, cpt, chunk_elems),
+                     hipLaunchKernelGGL((absmax_tokens_generic_k<KVQ_BF16>), ggrid, dim3(kBlock), 0, st, a, cpt, chunk_elems),
+                     hipLaunchKernelGGL((absmax_tokens_generic_k<KVQ_F32>), ggrid, dim3(kBlock), 0, st, a, cpt, chunk_elems))
+      }
+    } else if (vec_here) {
+      if (bits == 8) {
+        KVQ_BY_DTYPE(hipLaunchKernelGGL((quant_tokens_scaled_vec_k<KVQ_F16, 8>), grid, dim3(kBlock), 0, st, a, (uint32_t)vecs),
+                     hipLaunchKernelGGL((quant_tokens_scaled_vec_k<KVQ_BF16, 8>), grid, dim3(kBlock), 0, st, a, (uint32_t)vecs),
+                     hipLaunchKernelGGL((quant_tokens_scaled_vec_k<KVQ_F32, 8>), grid, dim3(kBlock), 0, st, a, (uint32_t)vecs))
+      } else {
+        KVQ_BY_DTYPE(hipLaunchKernelGGL((quant_tokens_scaled_vec_k<KVQ_F16, 4>), grid, dim3(kBlock), 0, st, a, (uint32_t)vecs),
+                     hipLaunchKernelGGL((quant_tokens_scaled_vec_k<KVQ_BF16, 4>), grid, dim3(kBlock), 0, st, a, (uint32_t)vecs),
+                     hipLaunchKernelGGL((quant_tokens_scaled_vec_k<KVQ_F32, 4>), grid, dim3(kBlock), 0, st, a, (uint32_t)vecs))
+      }
+    } else {
+      const int64_t Dq = bits == 8 ? d->D : (d->D + 1) / 2;
+      const int64_t total = gn * d->B * d->H * d->T * Dq;
+      int64_t gb = (total + kBlock - 1) / kBlock;
+      if (gb > 256 * 32) gb = 256 * 32;
+      if (bits == 8) {
+        KVQ_BY_DTYPE(hipLaunchKernelGGL((quant_tokens_generic_k<KVQ_F16, 8>), dim3((unsigned)gb), dim3(kBlock), 0, st, a, total),
+                     hipLaunchKernelGGL((quant_tokens_generic_k<KVQ_BF16, 8>), dim3((unsigned)gb), dim3(kBlock), 0, st, a, total),
+                     hipLaunchKernelGGL((quant_tokens_generic_k<KVQ_F32, 8>), dim3((unsigned)gb), dim3(kBlock), 0, st, a, total))
+      } else {
+        KVQ_BY_DTYPE(hipLaunchKernelGGL((quant_tokens_generic_k<KVQ_F16, 4>), dim3((unsigned)gb), dim3(kBlock), 0, st, a, total),
+                     hipLaunchKernelGGL((quant_tokens_generic_k<KVQ_BF16, 4>), dim3((unsigned)gb), dim3(kBlock), 0, st, a, total),
+                     hipLaunchKernelGGL((quant_tokens_generic_k<KVQ_F32, 4>), dim3((unsigned)gb), dim3(kBlock), 0, st, a, total))
+      }
+    }
+#undef KVQ_BY_DTYPE
+    const int rc = check_launch(name);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 }  // namespace kvq
 
 using namespace kvq;
@@ -863,6 +1031,20 @@ int kvq_quant_i4_tokens(const void* in_base, const void* const* in_ptrs, const k
                         float* absmax_ws, float eps, const kvq_dims_t* dims, void* stream) {
   return quant_tokens<4>(in_base, in_ptrs, in_st, in_dtype, packed, p_st, scales, scale_stride_g, absmax_ws, eps,
                          dims, stream, "kvq_quant_i4_tokens");
+}
+
+int kvq_absmax_tokens(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st, int in_dtype,
+                      float* absmax, const kvq_dims_t* dims, void* stream) {
+  return split_phase<1>("kvq_absmax_tokens", 8, in_base, in_ptrs, in_st, in_dtype, nullptr, nullptr, nullptr, 0, absmax, 0.0f,
+                        dims, stream);
+}
+
+int kvq_quant_tokens_from_absmax(int bits, const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st,
+                                 int in_dtype, uint8_t* q, const kvq_strides_t* q_st, float* scales,
+                                 int64_t scale_stride_g, const float* absmax, float eps, const kvq_dims_t* dims,
+                                 void* stream) {
+  return split_phase<2>("kvq_quant_tokens_from_absmax", bits, in_base, in_ptrs, in_st, in_dtype, q, q_st, scales, scale_stride_g,
+                        const_cast<float*>(absmax), eps, dims, stream);
 }
 
 }  // extern "C"

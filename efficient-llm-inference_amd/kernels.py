@@ -92,6 +92,51 @@ def quant_tokens(x: TensorOrList, q: torch.Tensor, scales: torch.Tensor, absmax_
     check(rc, f"quant_tokens[{kind}]")
 
 
+def absmax_tokens(x: TensorOrList, out: torch.Tensor = None) -> torch.Tensor:
+    """Phase 1 of the sharded-batch quantise (kvq_absmax_tokens): ``[G,T]`` fp32 table of
+    ``max |x[g, :, :, t, :]|`` over THIS rank's batch rows; returns ``out`` (allocated when None).
+    Reference: the ``x32.abs().max()`` of quantize_int8 / int4_per_tensor (ops.py:27,48) before it is
+    completed across ranks by ``sharding.all_reduce_absmax``."""
+    base, arr, ist, (G, B, H, T, D), dt, dev, _keep = _in_views(x)
+    if out is None:
+        out = torch.empty(G, T, dtype=torch.float32, device=dev)
+    require_gpu(out, "absmax")
+    if tuple(out.shape) != (G, T) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise _lib.KvqError(f"kvq: absmax table must be contiguous fp32 {(G, T)}")
+    check(_lib.load().kvq_absmax_tokens(base, arr, byref(ist), dtype_code(dt), c_void_p(out.data_ptr()),
+                                        byref(dims5(G, B, H, T, D)), _lib.current_stream(dev)), "absmax_tokens")
+    return out
+
+
+def quant_tokens_with_absmax(x: TensorOrList, absmax: torch.Tensor, kind: str, eps: float = 1e-8,
+                             q: torch.Tensor = None, scales: torch.Tensor = None):
+    """Phase 2 (kvq_quant_tokens_from_absmax): quantise ``x`` with the scale
+    ``max(absmax[g,t] / QMAX, eps)`` — ``absmax`` being the table of :func:`absmax_tokens`, completed
+    across ranks when the batch is sharded. Returns ``(q [G,B,H,T,Dq], scales [G,T])`` (allocated
+    when not given); with the local table on one rank this equals :func:`quant_tokens` bit for bit."""
+    bits = KIND_BITS[kind]
+    base, arr, ist, (G, B, H, T, D), dt, dev, _keep = _in_views(x)
+    Dq = packed_dim(kind, D)
+    if q is None:
+        q = torch.empty(G, B, H, T, Dq, dtype=QDTYPE[kind], device=dev)
+    if scales is None:
+        scales = torch.empty(G, T, dtype=torch.float32, device=dev)
+    for name, t in (("q", q), ("scales", scales), ("absmax", absmax)):
+        require_gpu(t, name)
+    if tuple(q.shape) != (G, B, H, T, Dq) or q.dtype != QDTYPE[kind]:
+        raise _lib.KvqError(f"kvq: store window must be {(G, B, H, T, Dq)} {QDTYPE[kind]}, got {tuple(q.shape)} {q.dtype}")
+    if tuple(scales.shape) != (G, T) or scales.dtype != torch.float32 or (T > 1 and scales.stride(1) != 1):
+        raise _lib.KvqError(f"kvq: scales window must be fp32 {(G, T)} with unit token stride")
+    if tuple(absmax.shape) != (G, T) or absmax.dtype != torch.float32 or not absmax.is_contiguous():
+        raise _lib.KvqError(f"kvq: absmax table must be contiguous fp32 {(G, T)}")
+    if G * B * H * T * D:
+        check(_lib.load().kvq_quant_tokens_from_absmax(
+            bits, base, arr, byref(ist), dtype_code(dt), c_void_p(q.data_ptr()), byref(strides4(q)),
+            c_void_p(scales.data_ptr()), scales.stride(0), c_void_p(absmax.data_ptr()), float(eps),
+            byref(dims5(G, B, H, T, D)), _lib.current_stream(dev)), f"quant_tokens_with_absmax[{kind}]")
+    return q, scales
+
+
 def dequant_tokens(q: torch.Tensor, scales: torch.Tensor, out: torch.Tensor, kind: str) -> None:
     """``out[g,b,h,t,:] = RN(float(q[g,b,h,t,:]) * scales[g,t])`` for a whole KV set, one launch.
 

@@ -123,6 +123,24 @@ int kvq_quant_i4_tokens(const void* in_base, const void* const* in_ptrs, const k
                         int64_t scale_stride_g, float* absmax_ws, float eps,
                         const kvq_dims_t* dims, void* stream);
 
+/* ---- split phases: a batched slice whose batch rows are sharded over ranks -------------------- */
+
+/* The reference's scale spans the WHOLE [B,H,1,D] slice (ops.py:27,48), so when B is split over ranks
+ *  the abs-max must cross ranks between the reduction and the quantisation:
+ *   kvq_absmax_tokens            local rows -> absmax[g*T + t] = max |x| over this rank's [B_local,H,D]
+ *   all_reduce(MAX) of absmax    (the caller's collective: RCCL over xGMI, torch.distributed)
+ *   kvq_quant_tokens_from_absmax quantise the local rows with scale max(absmax/QMAX, eps), store the scale
+ * On one rank (no all_reduce) the pair is bit-identical with kvq_quant_i8_tokens / kvq_quant_i4_tokens.
+ * absmax: contiguous [G,T] fp32, overwritten by phase 1 (no pre-initialisation needed). */
+int kvq_absmax_tokens(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st, int in_dtype,
+                      float* absmax, const kvq_dims_t* dims, void* stream);
+
+/* bits: 8 (int8 store, strides in bytes = elements) or 4 (packed store, (D+1)/2 bytes per row). */
+int kvq_quant_tokens_from_absmax(int bits, const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st,
+                                 int in_dtype, uint8_t* q, const kvq_strides_t* q_st, float* scales,
+                                 int64_t scale_stride_g, const float* absmax, float eps, const kvq_dims_t* dims,
+                                 void* stream);
+
 /* ---- eviction ---------------------------------------------------------------------------- */
 
 /* Replaces trim_kv_sliding_window (src/cache/implementations.py:124-140), materialised:
@@ -228,7 +246,7 @@ int kvq_decode_step_layers(int64_t n_layers, int append, const void* const* q, i
 /* ---- tuning knobs (benchmarks only; defaults are what ships) ----------------------------- */
 
 /* key: "dequant_variant" (0..30, -1 = shipped default), "dequant_grid" (workgroups, 0 = one chunk
- * each), "quant_force_two_pass" (0/1), "quant_direct_stores" (0/1), "pool_grid" (workgroup cap, 0 = none), "nt_loads" (0/1), "quant_block" (64|128|256), "quant_nv" (8|4|16), "quant_lds_pad" (bytes of unused dynamic LDS, occupancy A-B), "quant_no_regmax" (0/1), "pool_block" (64|128|256), "attn_force_valu" (0/1), "attn_mfma_min_nq" (default 3), "attn_mfma_tc" (128|64), "attn_fused" (0/1: decode attention as one launch where it applies; default 0 = partial + merge launches, measured faster), "attn_fused_tc" / "attn_fused_nw" (tokens per wave / waves per workgroup of the fused launch: 128/4, 128/8, 64/8 or 32/16; 0 = by batch size).
+ * each), "quant_force_two_pass" (0/1), "quant_direct_stores" (0/1), "pool_grid" (workgroup cap, 0 = none), "nt_loads" (0/1), "quant_block" (64|128|256), "quant_nv" (8|4|16), "quant_lds_pad" (bytes of unused dynamic LDS, occupancy A-B), "quant_tpw" (tiles per wave of the pipelined one-wave quantise kernel: 0 = one tile per wave, 2 | 4 | 8), "quant_no_regmax" (0/1), "pool_block" (64|128|256), "attn_force_valu" (0/1), "attn_mfma_min_nq" (default 3), "attn_mfma_tc" (128|64), "attn_fused" (0/1: decode attention as one launch where it applies; default 0 = partial + merge launches, measured faster), "attn_fused_tc" / "attn_fused_nw" (tokens per wave / waves per workgroup of the fused launch: 128/4, 128/8, 64/8 or 32/16; 0 = by batch size).
  * Returns 0, or KVQ_E_DIMS for an unknown key. Process-global. */
 int kvq_set_tunable(const char* key, int64_t value);
 int64_t kvq_get_tunable(const char* key);

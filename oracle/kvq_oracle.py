@@ -185,6 +185,27 @@ def quantize_tokens(x: np.ndarray, kind: str, eps: float = 1e-8, dtype: str | No
     return q, stored, stored_scale_as_f32(stored, dtype)
 
 
+def absmax_tokens(x: np.ndarray, dtype: str | None = None) -> np.ndarray:
+    """[G,B,H,T,D] -> [G,T] fp32 ``max |x|`` over (B,H,D): the ``x32.abs().max()`` of ops.py:27 / :48 taken
+    over the rows at hand. For a batch split over ranks, the element-wise MAX of the ranks' tables IS the
+    abs-max of the whole slice (max is associative and exact), which is what the sharded path exchanges."""
+    assert x.ndim == 5
+    x32 = _widen(x, dtype)
+    return np.abs(x32).max(axis=(1, 2, 4)).astype(F32) if x32.size else np.zeros((x.shape[0], x.shape[3]), F32)
+
+
+def quantize_tokens_with_absmax(x: np.ndarray, max_abs: np.ndarray, kind: str, eps: float = 1e-8, dtype: str | None = None):
+    """:func:`quantize_tokens` with the abs-max table GIVEN (ops.py:28-30 / :49-65 after the max): the rows of a
+    sharded batch quantised with the whole batch's scale. Returns (q, scales_stored, scales_f32)."""
+    x32 = _widen(x, dtype)
+    s32 = _scale_f32(np.asarray(max_abs, dtype=F32), QMAX[kind], eps)
+    q = np.clip(np.rint(x32 / s32[:, None, None, :, None]), QMIN[kind], QMAX[kind]).astype(np.int8)
+    if kind == "int4":
+        q = pack_int4(q)
+    stored = _round_to_storage(s32, x, dtype)
+    return q, stored, stored_scale_as_f32(stored, dtype)
+
+
 def dequantize_tokens(q: np.ndarray, scales_f32: np.ndarray, kind: str, D: int, out_dtype: str = "f16"):
     """Inverse of :func:`quantize_tokens`: what ``get_kv`` (ops.py:213-269) returns after the
     T-way ``torch.cat(dim=2)``.  q [G,B,H,T,Dq], scales_f32 [G,T] -> [G,B,H,T,D]."""

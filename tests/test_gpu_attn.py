@@ -198,7 +198,7 @@ def test_decode_attn_many_splits(K):
     _run_case(K, 4, 8, 8, 9000, 32, "int8", "int8", "f16", False)  # 4 x 8 x 9000 tokens: 2 iterations per split
 
 
-@pytest.mark.parametrize("shape", [(1, 32, 8, 16384, 128), (2, 12, 12, 4000, 64)])
+@pytest.mark.parametrize("shape", [(1, 32, 8, 16384, 128), (2, 12, 12, 4000, 64), (8, 32, 8, 16384, 128)])
 def test_decode_attn_full_size_token_permutation(K, shape):
     """Size-independent property at the benchmark shape (no oracle at this size): attention does not
     depend on the ORDER of the stored tokens, so permuting the rows of both stores together with
@@ -213,7 +213,12 @@ def test_decode_attn_full_size_token_permutation(K, shape):
     q = torch.randn(B, Hq, D, device="cuda", dtype=torch.float16, generator=g)
     kn = torch.randn(B, Hkv, D, device="cuda", dtype=torch.float16, generator=g)
     vn = torch.randn(B, Hkv, D, device="cuda", dtype=torch.float16, generator=g)
-    ws = torch.empty(K.decode_attn_workspace(B, Hq, Hkv, T, D), dtype=torch.float32, device="cuda")
+    from efficient_llm_inference_amd import _lib
+    need = K.decode_attn_workspace(B, Hq, Hkv, T, D)
+    _lib.set_tunable("attn_stream_tpw", -1)  # the one-tile kernel writes more split partials than the streaming one
+    need = max(need, K.decode_attn_workspace(B, Hq, Hkv, T, D))
+    _lib.set_tunable("attn_stream_tpw", 0)
+    ws = torch.empty(need, dtype=torch.float32, device="cuda")
     sm = D ** -0.5
     out1 = torch.empty_like(q)
     K.decode_attn(q, k_store, k_sc, "int8", v_store, v_sc, "int4", T, out1, ws, sm, kn, vn)
@@ -224,6 +229,15 @@ def test_decode_attn_full_size_token_permutation(K, shape):
     torch.cuda.synchronize()
     a, b = out1.float(), out2.float()
     assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 2e-3 * float(a.abs().max())
+    if B == 8:  # the batch-8 shape takes the streaming kernel by size: it must agree with the one-tile kernel
+        _lib.set_tunable("attn_stream_tpw", -1)
+        try:
+            out4 = torch.empty_like(q)
+            K.decode_attn(q, k_store, k_sc, "int8", v_store, v_sc, "int4", T, out4, ws, sm, kn, vn)
+        finally:
+            _lib.set_tunable("attn_stream_tpw", 0)
+        torch.cuda.synchronize()
+        assert float((out4.float() - a).abs().max()) <= 2e-3 * float(a.abs().max())
     # a prefix of the context + the rest folded in as ... the same tokens: T1 + (T - T1) split at an odd place
     out3 = torch.empty_like(q)
     K.decode_attn(q, k_store, k_sc, "int8", v_store, v_sc, "int4", T - 1, out3, ws, sm, kn, vn)
@@ -370,6 +384,42 @@ def test_decode_attn_fused_workspace_reuse(K, tunable, shape):
         got = to_numpy(out).astype(np.float64)
         assert np.isfinite(got).all(), (si, T)
         assert (np.abs(got - ref) <= TOL["f16"] * (np.abs(ref) + np.abs(ref).max())).all(), (si, T)
+
+
+@pytest.mark.parametrize("tc", [64, 32])
+@pytest.mark.parametrize("tpw", [1, 2, 3, 5])
+def test_decode_attn_streaming_kernel_matches_oracle(K, tunable, tc, tpw):
+    """decode_attn_stream_mfma_k (one wave walks `tpw` tiles with the next tile's rows in flight, online
+    softmax across tiles): forced on small shapes through the tunables — odd / even tile counts per wave, a
+    ragged last tile, a last wave with fewer tiles, one-tile contexts, V scales that grow and shrink across
+    tiles (the running reference scale), every kind pair, fp16 and bf16."""
+    tunable("attn_stream_tpw", tpw)
+    tunable("attn_stream_tc", tc)
+    for case in [(1, 32, 8, 1000, 128), (2, 6, 2, 200, 128), (1, 16, 1, 300, 128), (1, 32, 8, 5000, 128), (3, 8, 2, 1, 128),
+                 (1, 8, 2, 513, 128), (2, 32, 8, 2048, 128), (1, 8, 2, 64, 128), (1, 8, 2, 129, 128)]:
+        for kinds in (("int8", "int4"), ("int4", "int8"), ("int8", "int8"), ("int4", "int4")):
+            _run_case(K, *case, kinds[0], kinds[1], "f16", True)
+        _run_case(K, *case, "int8", "int4", "bf16", True)
+        _run_case(K, *case, "int8", "int4", "f16", False)
+    # V magnitudes that differ by orders of magnitude between tiles
+    rng = np.random.default_rng(tpw * 100 + tc)
+    B, Hq, Hkv, T, D = 1, 8, 2, 700, 128
+    k = rng.standard_normal((1, B, Hkv, T, D)).astype(np.float16)
+    v = rng.standard_normal((1, B, Hkv, T, D)).astype(np.float32)
+    v[:, :, :, 100:300] *= 1e-3
+    v[:, :, :, 300:420] *= 30.0
+    v[:, :, :, 420:] *= 0.05
+    v = v.astype(np.float16)
+    kq, _, ks = O.quantize_tokens(k, "int8")
+    vq, _, vs = O.quantize_tokens(v, "int4")
+    q = rng.standard_normal((B, Hq, D)).astype(np.float16)
+    sm = D ** -0.5
+    ref = O.decode_attention(q, kq[0], ks[0], "int8", vq[0], vs[0], "int4", D, sm)
+    out = torch.empty(B, Hq, D, dtype=torch.float16, device="cuda")
+    ws = torch.empty(K.decode_attn_workspace(B, Hq, Hkv, T, D), dtype=torch.float32, device="cuda")
+    K.decode_attn(to_torch(q), to_torch(kq[0]), to_torch(ks[0]), "int8", to_torch(vq[0]), to_torch(vs[0]), "int4", T, out, ws, sm)
+    got = to_numpy(out).astype(np.float64)
+    assert (np.abs(got - ref) <= TOL["f16"] * (np.abs(ref) + np.abs(ref).max())).all()
 
 
 @pytest.mark.parametrize("fused", [0, 1])

@@ -326,3 +326,26 @@ def test_sliding_window_nll_through_hip_equals_plain_slicing(rig):
     assert got == (want, math.exp(want))
     wide = compute_sliding_window_nll(model, tok, text, window_size=4096, device="cuda")
     assert wide[0] > 0 and wide != got
+
+
+def test_config2_gpt2_quant_int8_prompt512_new512():
+    """BASELINE configs[1] at its stated size: gpt2 architecture (12 layers x 12 heads x 64, random-init
+    weights: there is no network for the checkpoint), quant_int8, prompt 512 + 512 new tokens through
+    generate_with_quantized_kv (reference src/benchmarking/benchmarker.py:422-491). The in-place staged
+    path and the reference-shaped tuple path (dequantise everything, rebuild the cache, cat) emit the same
+    512 tokens, and both report est_mb == the oracle's estimated_bytes for 1024 stored tokens."""
+    from efficient_llm_inference_amd import KVCacheBenchmarker
+    from efficient_llm_inference_amd.benchmarking.offline import load_model
+    model, tok = load_model("gpt2", "cuda", torch.float16)
+    bench = KVCacheBenchmarker(model, tok, device="cuda")
+    assert tok("<512>", return_tensors="pt").input_ids.shape[1] == 512
+    bench.inplace_decode = True
+    a = bench.generate_with_quantized_kv("<512>", 512, mode="int8")
+    bench.inplace_decode = False
+    b = bench.generate_with_quantized_kv("<512>", 512, mode="int8")
+    assert a[1] == b[1] == 512
+    assert a[0] == b[0], "in-place and tuple decode paths diverged"
+    want_mb = O.estimated_bytes("int8", 12, 1, 12, 1024, 64, 2) / 2**20  # fp16 stored scales: itemsize 2
+    assert a[2] == b[2] == want_mb
+    res = bench.benchmark_method(["<512>"], method="quant_int8", max_new_tokens=512)
+    assert res["total_new_tokens"] == 512 and res["est_kv_cache_mb_avg"] == want_mb and res["tokens_per_sec"] > 0

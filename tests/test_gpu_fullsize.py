@@ -113,3 +113,39 @@ def test_fullsize_eviction_properties(K):
     ref = x[:, :, :, : T - keep].float().view(G, B, H, -1, chunk, D).mean(dim=4)
     got = pooled[:, :, :, : Tout - keep].float()
     assert bool(((got - ref).abs() <= ref.abs() * 2.0**-10 + 1e-5).all())
+
+
+def test_config5_per_gpu_share_all_64_tensors():
+    """BASELINE configs[4] at its stated per-GPU size: Llama-3-8B sliding_window + chunk_summary, seq 32K,
+    batch 64 over 8 GPUs = 8 batch rows per GPU: the legacy tuple of ALL 32 layers x (K, V) = 64 separately
+    allocated [8, 8, 32768, 128] fp16 tensors (32 GiB) through the public trim_kv_sliding_window /
+    chunk_summarize_kv (two launches each: 64 base pointers per launch). Window = exact gather of the last
+    256 tokens; kept tail = exact copy; every pooled row within 1 fp16 ulp of torch's per-tensor mean."""
+    import efficient_llm_inference_amd as E
+    L, B, H, T, D = 32, 8, 8, 32768, 128
+    W, chunk, keep = 256, 64, 256  # CacheConfig defaults (reference src/core/config.py:64-67)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2**30:
+        pytest.skip(f"needs 40 GiB of free HBM, {free / 2**30:.0f} GiB available")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    past = []
+    for _ in range(L):
+        k = torch.empty(B, H, T, D, device="cuda", dtype=torch.float16).normal_(generator=g)
+        v = torch.empty(B, H, T, D, device="cuda", dtype=torch.float16).normal_(generator=g)
+        past.append((k, v))
+    past = tuple(past)
+    win = E.trim_kv_sliding_window(past, W)
+    pooled = E.chunk_summarize_kv(past, chunk_size=chunk, keep_last=keep)
+    torch.cuda.synchronize()
+    Tout = 764  # SURVEY §3.3: 508 summaries + 256 recent
+    assert len(win) == len(pooled) == L
+    for l in range(L):
+        for i in range(2):
+            x, w, p = past[l][i], win[l][i], pooled[l][i]
+            assert tuple(w.shape) == (B, H, W, D) and tuple(p.shape) == (B, H, Tout, D) and p.dtype == x.dtype
+            assert torch.equal(w, x[:, :, T - W:]), f"window layer {l} tensor {i}"
+            assert torch.equal(p[:, :, Tout - keep:], x[:, :, T - keep:]), f"tail layer {l} tensor {i}"
+            ref = x[:, :, : T - keep].float().view(B, H, -1, chunk, D).mean(dim=3)
+            got = p[:, :, : Tout - keep].float()
+            assert bool(((got - ref).abs() <= ref.abs() * 2.0**-10 + 1e-5).all()), f"pool layer {l} tensor {i}"
+            del ref, got

@@ -1,0 +1,156 @@
+"""SURVEY §8e's one exchange step: a batched ``[B>1,H,1,D]`` slice whose batch rows are split over
+ranks keeps ONE scale per token (reference src/quantization/ops.py:27,48), so the ``[G,T]`` abs-max
+table crosses ranks (``all_reduce(MAX)``) between the reduction and the quantisation.
+
+CPU (``-m "not gpu"``): world-size-2 gloo harness — rows sharded by ``shard_batch_rows``, the table
+reduced by ``sharding.all_reduce_absmax``, both phases evaluated by the oracle: bit-exact with the
+oracle quantising the un-sharded batch, on both ranks.
+GPU (``-m gpu``): the same through the HIP kernels (kvq_absmax_tokens / kvq_quant_tokens_from_absmax),
+single process (pair == fused kernels) and two processes sharing the card (gloo carries the table).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import kvq_oracle as O
+from tests.conftest import ROOT
+from tests.util import bits, odt, seeded_kv, to_numpy, to_torch
+
+SHAPE = (3, 5, 4, 9, 64)  # G, B, H, T, D: 5 batch rows over 2 ranks = 3 + 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batch(dtype="f16", shape=SHAPE):
+    x = seeded_kv(shape, dtype, seed=77, dist="heavy")
+    # make the abs-max of some tokens live on rank 1's rows only and of others on rank 0's only
+    x32 = O._widen(x, odt(dtype)).copy()
+    x32[:, 4, :, 0::2, :] *= 5.0
+    x32[:, 0, :, 1::2, :] *= 7.0
+    return O.f32_to_bf16_bits(x32) if dtype == "bf16" else x32.astype(x.dtype)
+
+
+def _cpu_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from efficient_llm_inference_amd import sharding
+    sharding.init_distributed(rank, world, None)
+    try:
+        x = _batch()
+        rows = sharding.shard_batch_rows(x.shape[1])
+        mine = x[:, rows.start:rows.stop]
+        res = {}
+        for kind in ("int8", "int4"):
+            amax = torch.from_numpy(O.absmax_tokens(mine))
+            sharding.all_reduce_absmax(amax)  # gloo: the table is a host tensor here
+            qq, _, s32 = O.quantize_tokens_with_absmax(mine, amax.numpy(), kind)
+            res[kind] = (qq, s32)
+        q.put((rank, list(rows), res))
+    finally:
+        sharding.shutdown()
+
+
+def test_sharded_batch_scales_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x = _batch()
+    assert out[0][1] == [0, 1, 2] and out[1][1] == [3, 4]
+    for kind in ("int8", "int4"):
+        q_ref, _, s32_ref = O.quantize_tokens(x, kind)
+        got = np.concatenate([out[0][2][kind][0], out[1][2][kind][0]], axis=1)
+        assert np.array_equal(got, q_ref)
+        for r in range(2):  # identical, whole-batch scales on every rank
+            assert np.array_equal(out[r][2][kind][1].view(np.uint32), s32_ref.view(np.uint32))
+        # and they differ from what each rank would have got on its own rows (the exchange matters)
+        assert not np.array_equal(O.quantize_tokens(x[:, :3], kind)[2].view(np.uint32), s32_ref.view(np.uint32))
+
+
+# ---------------------------------------------------------------------------- GPU
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [SHAPE, (2, 2, 8, 33, 128), (2, 3, 3, 7, 5), (1, 4, 2, 6, 24), (130, 1, 2, 3, 16)])
+@pytest.mark.parametrize("dtype", ["f16", "bf16", "f32"])
+def test_split_phases_equal_fused_kernels(shape, dtype):
+    """One rank: kvq_absmax_tokens + kvq_quant_tokens_from_absmax == the oracle == kvq_quant_*_tokens, bit for bit
+    (vector and generic paths, list and single-buffer inputs, > 128 groups)."""
+    from efficient_llm_inference_amd import kernels as K
+    G, B, H, T, D = shape
+    x_np = seeded_kv(shape, dtype, seed=3, dist="heavy")
+    x = to_torch(x_np, dtype)
+    amax = K.absmax_tokens(x)
+    assert np.array_equal(bits(amax), bits(O.absmax_tokens(x_np, odt(dtype))))
+    for kind in ("int8", "int4"):
+        q_ref, _, s32_ref = O.quantize_tokens(x_np, kind, dtype=odt(dtype))
+        for src in (x, [x[g] for g in range(G)] if G <= 256 else x):
+            q, sc = K.quant_tokens_with_absmax(src, amax, kind)
+            assert np.array_equal(to_numpy(q), q_ref) and np.array_equal(bits(sc), bits(s32_ref)), kind
+        store = torch.zeros_like(q)
+        scales = torch.zeros_like(sc)
+        K.quant_tokens(x, store, scales, torch.empty(G * T, dtype=torch.float32, device="cuda"), kind)
+        assert torch.equal(store, q) and torch.equal(scales, sc)
+
+
+def _gpu_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from efficient_llm_inference_amd import sharding
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    # both ranks share the one GPU of the box: RCCL refuses duplicate devices, gloo carries the table
+    backend = sharding.init_distributed(rank, world, dev, allow_gloo=True, ranks_share_device=True)
+    try:
+        res = {}
+        for dtype in ("f16", "bf16"):
+            x = _batch(dtype, (3, 5, 4, 9, 128))
+            rows = sharding.shard_batch_rows(x.shape[1])
+            mine = to_torch(np.ascontiguousarray(x[:, rows.start:rows.stop]), dtype)
+            for kind in ("int8", "int4"):
+                qq, sc = sharding.quantize_tokens_batch_sharded(mine, kind)
+                res[(dtype, kind)] = (to_numpy(qq), to_numpy(sc))
+        q.put((rank, backend, res))
+    finally:
+        sharding.shutdown()
+
+
+@pytest.mark.gpu
+def test_sharded_batch_two_processes_share_gpu():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert out[0][1] == out[1][1] == "gloo"
+    for dtype in ("f16", "bf16"):
+        x = _batch(dtype, (3, 5, 4, 9, 128))
+        for kind in ("int8", "int4"):
+            q_ref, _, s32_ref = O.quantize_tokens(x, kind, dtype=odt(dtype))
+            got = np.concatenate([out[0][2][(dtype, kind)][0], out[1][2][(dtype, kind)][0]], axis=1)
+            assert np.array_equal(got, q_ref), (dtype, kind)
+            for r in range(2):
+                assert np.array_equal(out[r][2][(dtype, kind)][1].view(np.uint32), s32_ref.view(np.uint32)), (dtype, kind, r)

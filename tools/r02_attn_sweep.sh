@@ -16,6 +16,13 @@ for wl in llama3_8b_decode_attn_seq16k llama3_8b_decode_attn_seq16k_b8; do
   run --workload $wl --steps 20 --warmup 3 --per-layer-calls
   run --workload $wl --steps 20 --warmup 3 --tunable attn_mfma_tc=64
 done
+# streaming kernel (one wave per several tiles, next tile in flight): by size, and forced shapes, vs the one-tile kernel
+for tc in 64 32; do for tpw in 0 2 4 8; do
+  run --workload llama3_8b_decode_attn_seq16k_b8 --steps 20 --warmup 3 --tunable attn_stream_tc=$tc --tunable attn_stream_tpw=$tpw
+done; done
+run --workload llama3_8b_decode_attn_seq16k_b8 --steps 20 --warmup 3 --tunable attn_stream_tpw=-1
+run --workload llama3_8b_decode_attn_seq16k --steps 20 --warmup 3 --tunable attn_stream_tpw=2
+run --workload llama3_8b_decode_attn_seq16k --steps 20 --warmup 3 --tunable attn_stream_tpw=2 --tunable attn_stream_tc=32
 run --workload llama32_1b_decode_attn_seq16k_b8 --steps 20 --warmup 3
 run --workload llama32_1b_decode_attn_seq16k_b8 --steps 20 --warmup 3 
 python3 - <<'PY'
