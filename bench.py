@@ -86,6 +86,9 @@ def parse():
                          "instead of failing (recorded as timing_reduction_backend)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-launcher waits for its ranks")
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--graph-decode", action="store_true",
+                    help="decode:* workloads with quant_* methods: capture the fused-attention decode step into a HIP graph "
+                         "and replay it per token (implies --fused-attention)")
     ap.add_argument("--fused-attention", action="store_true",
                     help="decode:* workloads with quant_* methods: attend straight over the quantised store "
                          "(kvq_decode_attn) instead of the staged fp16 copy")
@@ -182,7 +185,8 @@ def run_decode(args, rank, world, dev):
     n_new = int(parts[4]) if len(parts) > 4 else DECODE_DEFAULT[3]
     model, tok = load_model(arch, "cuda", torch.float16)
     bm = E.KVCacheBenchmarker(model, tok, device="cuda")
-    bm.fused_attention = bool(args.fused_attention)
+    bm.fused_attention = bool(args.fused_attention or args.graph_decode)
+    bm.graph_decode = bool(args.graph_decode)
     prompts = [f"<{n_prompt}>"] * (args.steps * world)
     for _ in range(args.warmup):
         bm.benchmark_method([f"<{min(n_prompt, 64)}>"], method=method, max_new_tokens=8)
@@ -197,7 +201,8 @@ def run_decode(args, rank, world, dev):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(res["elapsed_sec"] / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16 model, u8/u4 KV", "data": "synthetic",
-            "config": {"workload": args.workload, "arch": arch, "method": method, "fused_attention": bool(args.fused_attention),
+            "config": {"workload": args.workload, "arch": arch, "method": method, "fused_attention": bm.fused_attention,
+                       "graph_decode": bm.graph_decode,
                        "prompt_tokens": n_prompt,
                        "new_tokens": n_new, "weights": "random-init (offline)",
                        "layers": getattr(cfg, "num_hidden_layers", None) or cfg.n_layer,

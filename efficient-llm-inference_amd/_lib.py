@@ -42,6 +42,7 @@ EXPORTS = (
     "kvq_decode_attn_workspace_cap",
     "kvq_decode_attn",
     "kvq_decode_step",
+    "kvq_decode_step_dev",
     "kvq_decode_step_layers",
     "kvq_set_tunable",
     "kvq_get_tunable",
@@ -116,6 +117,9 @@ def _declare(lib):
     lib.kvq_decode_step.restype = c_int
     lib.kvq_decode_step.argtypes = [P, c_int64, c_int64, P, c_int64, c_int64, P, c_int64, c_int64, P, ST, P, c_int,
                                     P, ST, P, c_int, P, c_int64, c_int64, c_int, c_float, c_float, P, c_int64, AD, P]
+    lib.kvq_decode_step_dev.restype = c_int
+    lib.kvq_decode_step_dev.argtypes = [P, c_int64, c_int64, P, c_int64, c_int64, P, c_int64, c_int64, P, ST, P, c_int,
+                                        P, ST, P, c_int, P, c_int64, c_int64, c_int, c_float, c_float, P, c_int64, AD, P, P]
     PP = POINTER(c_void_p)
     lib.kvq_decode_step_layers.restype = c_int
     lib.kvq_decode_step_layers.argtypes = [c_int64, c_int, PP, c_int64, c_int64, PP, c_int64, c_int64, PP, c_int64, c_int64,

@@ -97,6 +97,10 @@ class KVCacheBenchmarker:
         # opt-in: attend straight over the INT8 / INT4 store (quantization/fused_attention.py): no
         # fp16 copy of the cache exists, the model's attention function is kvq_decode_attn
         self.fused_attention = False
+        # opt-in, with fused_attention: after two eager steps the decode step (model forward + kvq_decode_step_dev
+        # per layer + arg-max) is captured ONCE into a HIP graph and replayed per token (_graph_decode): the
+        # reference's Python loop is launch-bound (≈ 3.3 ms of host work per GPT-2 token), the graph is not
+        self.graph_decode = False
 
     # ------------------------------------------------------------------ shared loop machinery
 
@@ -190,6 +194,8 @@ class KVCacheBenchmarker:
         """Decode with the KV cache stored quantised (int8 / int4 / mixed); returns
         ``(text, n_new, estimated cache MB)`` (reference benchmarker.py:422-491)."""
         input_ids = self._encode(prompt, truncate=False)
+        if self.graph_decode and not self.fused_attention:
+            raise RuntimeError("kvq: graph_decode captures the fused-attention decode step; set fused_attention = True")
         if self.fused_attention:
             return self._generate_fused(input_ids, max_new_tokens, mode)
         out = self.model(input_ids=input_ids, use_cache=True)
@@ -238,13 +244,71 @@ class KVCacheBenchmarker:
         with fused_attention.fused_attention(self.model, fc) as cache:
             out = self.model(input_ids=input_ids, use_cache=True, past_key_values=cache)
             logits = out.logits[:, -1, :]
-            for _ in range(max_new_tokens):
+            # graph mode keeps a few eager steps (lazy initialisations, workspace and plan set-up), then captures
+            n_eager = min(max_new_tokens, 2) if self.graph_decode else max_new_tokens
+            for _ in range(n_eager):
                 next_token = torch.argmax(logits, dim=-1, keepdim=True)
                 generated = torch.cat([generated, next_token], dim=-1)
                 out = self.model(input_ids=next_token, use_cache=True, past_key_values=cache)
                 logits = out.logits[:, -1, :]
+            if max_new_tokens > n_eager:
+                generated = torch.cat([generated, self._graph_decode(fc, cache, logits, max_new_tokens - n_eager)], dim=-1)
         text, n_new = self._finish(generated, input_ids)
         return text, n_new, mb(fc.estimated_bytes())
+
+    def _graph_decode(self, fc, cache, logits: torch.Tensor, n_steps: int) -> torch.Tensor:
+        """The remaining ``n_steps`` decode steps as ONE captured HIP graph replayed per token: the model's forward
+        (every kernel of it), kvq_decode_step_dev per layer (stored-token count in device memory), the arg-max and
+        the position / counter updates. The reference's Python loop (benchmarker.py:465-486: ~3.3 ms of host work
+        per GPT-2 token here) leaves the critical path. Returns the ``[1, n_steps]`` tokens generated."""
+        qc = fc.qcache
+        dev = logits.device
+        T0 = qc._k.lens[0]
+        if T0 + n_steps > qc._k.cap or logits.shape[0] != 1:
+            raise RuntimeError("kvq: graphed decode needs batch 1 and a store reserved for every token")
+        static_ids = torch.argmax(logits, dim=-1, keepdim=True).clone()
+        gen = torch.zeros(1, n_steps, dtype=static_ids.dtype, device=dev)
+        pos = torch.full((1, 1), T0, dtype=torch.long, device=dev)
+        step = torch.zeros(1, dtype=torch.long, device=dev)
+        fc.t_dev = torch.full((1,), T0, dtype=torch.int32, device=dev)
+        fc.t_bound = max(1, T0 + n_steps - 1)
+        fc.ignore_decode_mask = True  # un-padded single prompt: the materialised causal row is all-true
+
+        def body():
+            gen.index_copy_(1, step, static_ids)  # the token fed to this forward is part of the output
+            out = self.model(input_ids=static_ids, position_ids=pos, use_cache=True, past_key_values=cache)
+            static_ids.copy_(torch.argmax(out.logits[:, -1, :], dim=-1, keepdim=True))
+            pos.add_(1)
+            step.add_(1)
+            fc.t_dev.add_(1)
+
+        def advance(n):  # host-side mirror of what n executed steps did to the stores
+            for i in range(len(qc._k.lens)):
+                qc._k.lens[i] += n
+                qc._v.lens[i] += n
+
+        try:
+            done = 0
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):  # warm-up of the device-T path, executed for real
+                for _ in range(min(2, n_steps)):
+                    body()
+                    done += 1
+            torch.cuda.current_stream(dev).wait_stream(side)
+            advance(done)
+            if done < n_steps:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):  # capture only: nothing executes, host-side counts untouched
+                    body()
+                for _ in range(n_steps - done):
+                    graph.replay()
+                advance(n_steps - done)
+            torch.cuda.current_stream(dev).synchronize()
+        finally:
+            fc.t_dev = None
+            fc.ignore_decode_mask = False
+        return gen
 
     @torch.no_grad()
     def generate_with_chunked_cache(self, prompt: str, max_new_tokens: int = 32, chunk_size: int = 64,

@@ -49,6 +49,8 @@ struct TunableKey {
 static const TunableKey kTunableKeys[] = {
     {"dequant_variant", &Tunables::dequant_variant},
     {"dequant_grid", &Tunables::dequant_grid},
+    {"dequant_xcd_group", &Tunables::dequant_xcd_group},
+    {"quant_xcd_group", &Tunables::quant_xcd_group},
     {"quant_force_two_pass", &Tunables::quant_force_two_pass},
     {"quant_direct_stores", &Tunables::quant_direct_stores},
     {"pool_grid", &Tunables::pool_grid},

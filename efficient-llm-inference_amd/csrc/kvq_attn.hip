@@ -57,7 +57,16 @@ struct AttnArgs {
   int32_t dtype;      // KVQ_F16 | KVQ_BF16 (q, k_new, v_new, out)
   int32_t mfma;       // host: the MFMA partial kernel serves this call
   uint32_t stream_tpw;  // host: > 0 = the streaming MFMA kernel, that many 64-token tiles per wave
+  // kvq_decode_step_dev: the stored-token count lives in DEVICE memory (a captured HIP graph replays
+  // the same launch for every decode step). T above is then the host's upper bound: it sizes the grid and
+  // the workspace; workgroups past the real count exit, the merge reads ceil(T / TS) partials.
+  const int32_t* t_dev;
 };
+
+// stored tokens this launch attends: the host's count, or the device word of a graph-replayed step
+__device__ inline uint32_t live_tokens(const AttnArgs& a) {
+  return a.t_dev ? (uint32_t)__builtin_nontemporal_load(a.t_dev) : a.T;
+}
 
 __device__ inline f16x2 bits_h2(uint32_t u) {
   f16x2 h;
@@ -202,7 +211,9 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_partial_k(const AttnAr
   const uint32_t tid = threadIdx.x;
   const uint32_t split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
   const uint32_t t0 = split * a.TS;
-  const uint32_t nt = a.T - t0 < a.TS ? a.T - t0 : a.TS;
+  const uint32_t T = live_tokens(a);
+  if (t0 >= T) return;  // device-side T (graph replay): this split holds nothing yet
+  const uint32_t nt = T - t0 < a.TS ? T - t0 : a.TS;
   const uint32_t lpt = 1u << a.lpt_shift;
   const uint32_t ld = tid & (lpt - 1u);    // which 16-element slice of D
   const uint32_t tl = tid >> a.lpt_shift;  // token lane
@@ -746,7 +757,9 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
   const uint32_t x = lane & 15u, g = lane >> 4;
   const uint32_t split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
   const uint32_t t0 = split * TC;
-  const uint32_t nt = a.T - t0 < (uint32_t)TC ? a.T - t0 : (uint32_t)TC;
+  const uint32_t T = live_tokens(a);
+  if (t0 >= T) return;  // device-side T (graph replay): this split holds nothing yet
+  const uint32_t nt = T - t0 < (uint32_t)TC ? T - t0 : (uint32_t)TC;
   Tile tile;
   tile.run(a, b, hk, t0, nt, s_ks, s_vs);
   // ---- workspace: (m, l) per head, acc[heads][D] --------------------------------------------------
@@ -1354,8 +1367,17 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_k(const AttnArgs
   __shared__ float s_red[kAttnBlock / kWave];
   if (blockIdx.x >= a.Hq) {
     if (fuse_quant && blockIdx.y == 0u) {
-      if (a.dtype == KVQ_F16) quant_new_token_block<KVQ_F16>(nt, blockIdx.x - a.Hq, s_red);
-      else quant_new_token_block<KVQ_BF16>(nt, blockIdx.x - a.Hq, s_red);
+      NewTokenArgs slot = nt;
+      if (a.t_dev) {  // the host passed slot 0; the real slot is the device-side T
+        const int64_t T = (int64_t)live_tokens(a);
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          slot.q[w] += T * nt.qs_t[w];
+          slot.scale[w] += T;
+        }
+      }
+      if (a.dtype == KVQ_F16) quant_new_token_block<KVQ_F16>(slot, blockIdx.x - a.Hq, s_red);
+      else quant_new_token_block<KVQ_BF16>(slot, blockIdx.x - a.Hq, s_red);
     }
     return;
   }
@@ -1384,13 +1406,15 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_k(const AttnArgs
   }
   const float* ml = a.ws + ((int64_t)b * a.Hq + hq) * a.nsplit * 2;
   const float* accb = a.ws + a.acc_off + ((int64_t)b * a.Hq + hq) * a.nsplit * a.D;
+  // a.nsplit is the row stride of the partials; with a device-side T only the first ceil(T / TS) are live
+  const uint32_t ns = a.t_dev ? (live_tokens(a) + a.TS - 1u) / a.TS : a.nsplit;
   // this thread's splits: tid, tid + 256, ...; (m, l) is read twice (second time from cache) rather
   // than kept in a register array sized for kAttnMaxSplit
   float m_max = s_tok;
-  for (uint32_t s = tid; s < a.nsplit; s += kAttnBlock) m_max = fmaxf(m_max, ml[2 * s]);
+  for (uint32_t s = tid; s < ns; s += kAttnBlock) m_max = fmaxf(m_max, ml[2 * s]);
   const float M = block_reduce(m_max, true);
   float lsum = 0.0f;
-  for (uint32_t s = tid; s < a.nsplit; s += kAttnBlock) {
+  for (uint32_t s = tid; s < ns; s += kAttnBlock) {
     const float w = __expf(ml[2 * s] - M);
     s_wt[s] = w;
     lsum += ml[2 * s + 1] * w;
@@ -1408,14 +1432,14 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_k(const AttnArgs
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(accb) + d4;
     uint32_t s = g;
-    for (; s + 3u * groups < a.nsplit; s += 4u * groups) {  // 4 independent loads in flight
+    for (; s + 3u * groups < ns; s += 4u * groups) {  // 4 independent loads in flight
       const f32x4 x0 = src[(int64_t)s * dv];
       const f32x4 x1 = src[(int64_t)(s + groups) * dv];
       const f32x4 x2 = src[(int64_t)(s + 2u * groups) * dv];
       const f32x4 x3 = src[(int64_t)(s + 3u * groups) * dv];
       o += x0 * s_wt[s] + x1 * s_wt[s + groups] + x2 * s_wt[s + 2u * groups] + x3 * s_wt[s + 3u * groups];
     }
-    for (; s < a.nsplit; s += groups) o += src[(int64_t)s * dv] * s_wt[s];
+    for (; s < ns; s += groups) o += src[(int64_t)s * dv] * s_wt[s];
   }
   *reinterpret_cast<f32x4*>(&s_out[tid * 4]) = o;  // [g][d]
   __syncthreads();
@@ -1454,6 +1478,7 @@ static uint32_t stream_tpw(const kvq_attn_dims_t* d) {
   if (tpw > ntiles) tpw = ntiles;
   return (uint32_t)tpw;
 }
+static bool plan_onetile(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit);
 static bool plan(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit) {
   if (const uint32_t tpw = stream_tpw(d)) {  // one wave per tpw tiles of 64 (32) tokens
     const int64_t per = (int64_t)tpw * stream_tc();
@@ -1461,6 +1486,10 @@ static bool plan(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit) {
     *nsplit = (uint32_t)((d->T + per - 1) / per);
     if (*nsplit <= (uint32_t)kAttnMaxSplit) return true;
   }
+  return plan_onetile(d, ts, nsplit);
+}
+// one tile (MFMA kernel) / one workgroup pass (VALU kernel) per split: also the only shapes a device-side T takes
+static bool plan_onetile(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit) {
   if (use_mfma(d)) {  // one wave per split of TC tokens
     int64_t tc = tunables().attn_mfma_tc == 64 && d->D == 128 ? 64 : kAttnMfmaTC;
     if ((d->T + tc - 1) / tc > kAttnMaxSplit) tc = kAttnMfmaTC;
@@ -1594,7 +1623,8 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
                             const kvq_strides_t* v_st, const float* v_scales, int v_bits, const void* k_new,
                             int64_t kn_sb, int64_t kn_sh, const void* v_new, int64_t vn_sb, int64_t vn_sh, void* out,
                             int64_t o_sb, int64_t o_sh, int dtype, float sm_scale, float* workspace,
-                            int64_t workspace_floats, const kvq_attn_dims_t* d, void* stream, const NewTokenArgs* nt) {
+                            int64_t workspace_floats, const kvq_attn_dims_t* d, void* stream, const NewTokenArgs* nt,
+                            const int32_t* t_dev = nullptr) {
   if (!d || !q || !out) {
     set_error("%s: NULL q / out / dims", name);
     return KVQ_E_NULL;
@@ -1668,19 +1698,26 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
   a.lpt_shift = ilog2_exact(d->D / 16);
   a.dtype = dtype;
   a.mfma = use_mfma(d) ? 1 : 0;
-  a.stream_tpw = stream_tpw(d);
-  if (!plan(d, &a.TS, &a.nsplit)) {
+  a.stream_tpw = t_dev ? 0u : stream_tpw(d);
+  a.t_dev = t_dev;
+  if (!(t_dev ? plan_onetile(d, &a.TS, &a.nsplit) : plan(d, &a.TS, &a.nsplit))) {
     set_error("%s: T=%lld needs more than %d splits of %d tokens", name, (long long)d->T, kAttnMaxSplit, kAttnMaxTS);
     return KVQ_E_DIMS;
   }
   a.acc_off = ((int64_t)a.B * a.Hq * a.nsplit * 2 + 3) / 4 * 4;
+  // the split layout actually chosen (a device-side T always takes one-tile splits) must fit too
+  if (d->T > 0 && workspace_floats < a.acc_off + (int64_t)a.B * a.Hq * a.nsplit * a.D) {
+    set_error("%s: workspace of %lld floats, %lld needed for %u splits", name, (long long)workspace_floats,
+              (long long)(a.acc_off + (int64_t)a.B * a.Hq * a.nsplit * a.D), a.nsplit);
+    return KVQ_E_DIMS;
+  }
   if (d->T > 0 && !aligned(workspace, 16)) {
     set_error("%s: workspace must be 16-byte aligned", name);
     return KVQ_E_DIMS;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   FusedPlan fp;
-  if (plan_fused(d, &fp)) {  // ONE launch: tiles, in-workgroup merge, ticketed final merge, new-token quantise
+  if (!t_dev && plan_fused(d, &fp)) {  // ONE launch: tiles, in-workgroup merge, ticketed final merge, new-token quantise
     if (k_bits == 8 && v_bits == 8) launch_fused<8, 8>(a, fp, nt, st);
     else if (k_bits == 8) launch_fused<8, 4>(a, fp, nt, st);
     else if (v_bits == 8) launch_fused<4, 8>(a, fp, nt, st);
@@ -1753,6 +1790,7 @@ int kvq_decode_step(const void* q, int64_t q_sb, int64_t q_sh, const void* k_new
     nt.x[1] = v_new; nt.xs_b[1] = vn_sb; nt.xs_h[1] = vn_sh;
     nt.q[0] = k_store + d->T * k_st->t; nt.qs_b[0] = k_st->b; nt.qs_h[0] = k_st->h; nt.scale[0] = k_scales + d->T; nt.bits[0] = k_bits;
     nt.q[1] = v_store + d->T * v_st->t; nt.qs_b[1] = v_st->b; nt.qs_h[1] = v_st->h; nt.scale[1] = v_scales + d->T; nt.bits[1] = v_bits;
+    nt.qs_t[0] = k_st->t; nt.qs_t[1] = v_st->t;
     nt.B = (uint32_t)d->B; nt.H = (uint32_t)d->Hkv; nt.D = (uint32_t)d->D; nt.eps = eps;
     return decode_attn_impl(name, q, q_sb, q_sh, k_store, k_st, k_scales, k_bits, v_store, v_st, v_scales, v_bits, k_new, kn_sb,
                             kn_sh, v_new, vn_sb, vn_sh, out, o_sb, o_sh, dtype, sm_scale, workspace, workspace_floats, d,
@@ -1778,6 +1816,32 @@ int kvq_decode_step(const void* q, int64_t q_sb, int64_t q_sh, const void* k_new
                                    v_scales + d->T, 0, absmax_ws, eps, &qd, stream)
              : kvq_quant_i4_tokens(v_new, nullptr, &vin, dtype, v_store + d->T * v_st->t, v_st, v_scales + d->T, 0,
                                    absmax_ws, eps, &qd, stream);
+}
+
+int kvq_decode_step_dev(const void* q, int64_t q_sb, int64_t q_sh, const void* k_new, int64_t kn_sb, int64_t kn_sh,
+                        const void* v_new, int64_t vn_sb, int64_t vn_sh, uint8_t* k_store, const kvq_strides_t* k_st,
+                        float* k_scales, int k_bits, uint8_t* v_store, const kvq_strides_t* v_st, float* v_scales,
+                        int v_bits, void* out, int64_t o_sb, int64_t o_sh, int dtype, float sm_scale, float eps,
+                        float* workspace, int64_t workspace_floats, const kvq_attn_dims_t* d, const int32_t* t_dev,
+                        void* stream) {
+  const char* name = "kvq_decode_step_dev";
+  if (!d || !t_dev || !k_new || !v_new || !k_store || !v_store || !k_scales || !v_scales || !k_st || !v_st || !workspace) {
+    set_error("%s: NULL argument", name);
+    return KVQ_E_NULL;
+  }
+  if (d->T < 1 || d->B * d->Hkv * d->D > 65536 || (dtype != KVQ_F16 && dtype != KVQ_BF16)) {
+    set_error("%s: needs an upper bound T >= 1, B * Hkv * D <= 65536 and fp16 / bf16 tensors", name);
+    return KVQ_E_DIMS;
+  }
+  NewTokenArgs nt;  // slot 0: the merge launch adds the device-side T
+  nt.x[0] = k_new; nt.xs_b[0] = kn_sb; nt.xs_h[0] = kn_sh;
+  nt.x[1] = v_new; nt.xs_b[1] = vn_sb; nt.xs_h[1] = vn_sh;
+  nt.q[0] = k_store; nt.qs_b[0] = k_st->b; nt.qs_h[0] = k_st->h; nt.qs_t[0] = k_st->t; nt.scale[0] = k_scales; nt.bits[0] = k_bits;
+  nt.q[1] = v_store; nt.qs_b[1] = v_st->b; nt.qs_h[1] = v_st->h; nt.qs_t[1] = v_st->t; nt.scale[1] = v_scales; nt.bits[1] = v_bits;
+  nt.B = (uint32_t)d->B; nt.H = (uint32_t)d->Hkv; nt.D = (uint32_t)d->D; nt.eps = eps;
+  return decode_attn_impl(name, q, q_sb, q_sh, k_store, k_st, k_scales, k_bits, v_store, v_st, v_scales, v_bits, k_new, kn_sb,
+                          kn_sh, v_new, vn_sb, vn_sh, out, o_sb, o_sh, dtype, sm_scale, workspace, workspace_floats, d,
+                          stream, &nt, t_dev);
 }
 
 int kvq_decode_step_layers(int64_t n_layers, int append, const void* const* q, int64_t q_sb, int64_t q_sh,

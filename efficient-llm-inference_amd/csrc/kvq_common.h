@@ -36,6 +36,8 @@ int check_launch(const char* what);
 struct Tunables {
   int64_t dequant_variant;       // -1 = shipped default
   int64_t dequant_grid;          // 0 = one chunk per workgroup
+  int64_t dequant_xcd_group;     // consecutive chunks per XCD (xcd_grouped_item): 0 / 1 = round robin
+  int64_t quant_xcd_group;       // same for the one-wave quantise tiles
   int64_t quant_force_two_pass;  // 1 = generic two-pass quantise for every shape (tests)
   int64_t quant_direct_stores;   // 1 = skip the LDS-staged 16 B stores (tests / A-B)
   int64_t pool_grid;             // benchmarks: cap the chunk mean-pool grid (256-thread equivalents); 0 = one item per thread
@@ -278,6 +280,7 @@ struct NewTokenArgs {
   int64_t xs_b[2], xs_h[2];  // elements
   uint8_t* q[2];             // slot T of the store
   int64_t qs_b[2], qs_h[2];  // bytes
+  int64_t qs_t[2];           // bytes per token row (device-side slot: kvq_decode_step_dev)
   float* scale[2];           // &scales[T]
   int32_t bits[2];
   uint32_t B, H, D;
@@ -315,6 +318,20 @@ __device__ inline void quant_new_token_block(const NewTokenArgs& a, uint32_t w, 
       a.q[w][(int64_t)(r / a.H) * a.qs_b[w] + (int64_t)(r % a.H) * a.qs_h[w] + j] = (uint8_t)(((hi & 0xF) << 4) | (lo & 0xF));
     }
   }
+}
+
+// Workgroup id -> work item with `k` consecutive items per XCD: the dispatcher deals workgroups round robin
+// over the 8 XCDs (MI355X_MICROARCH: blocks b and b + 8 share one), so with the identity map XCD x sees
+// every 8th item; this map gives it runs of k consecutive items (k x the item's bytes contiguous per XCD L2)
+// while all XCDs stay inside one window of 8 k items. A speed knob only: any k gives the same results.
+// Items past the last complete window keep the identity map.
+__device__ inline uint32_t xcd_grouped_item(uint32_t wg, uint32_t k, uint32_t total) {
+  if (k <= 1u) return wg;
+  const uint32_t win = 8u * k;
+  const uint32_t base = wg / win * win;
+  if (base + win > total) return wg;
+  const uint32_t r = wg - base;
+  return base + (r & 7u) * k + (r >> 3);
 }
 
 static inline int ilog2_exact(int64_t v) {  // log2 if power of two else -1

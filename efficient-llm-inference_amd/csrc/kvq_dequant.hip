@@ -28,6 +28,7 @@ struct DequantArgs {
   int32_t dshift;    // log2(D) or -1
   uint32_t cpr;      // chunks per (g,b,h) row
   uint32_t total_items;
+  uint32_t xcd_group;  // consecutive chunks per XCD (0 / 1 = round robin); only with one chunk per workgroup
 };
 
 template <int NW, bool NTL = false>
@@ -87,7 +88,8 @@ __global__ __launch_bounds__(BLK) void dequant_tokens_fast_k(const DequantArgs a
   const uint32_t tid = threadIdx.x;
   const uint32_t D = a.D;
 
-  for (uint32_t item = blockIdx.x; item < a.total_items; item += gridDim.x) {
+  for (uint32_t wg = blockIdx.x; wg < a.total_items; wg += gridDim.x) {
+    const uint32_t item = xcd_grouped_item(wg, a.xcd_group, a.total_items);
     const uint32_t row = item / a.cpr;
     const uint32_t chunk = item - row * a.cpr;
     const uint32_t g = row / a.BH;
@@ -359,6 +361,7 @@ static int dequant_tokens(const uint8_t* q, const kvq_strides_t* q_st, const flo
     a.dshift = ilog2_exact(d->D);
     a.cpr = (uint32_t)cpr;
     a.total_items = (uint32_t)(rows * cpr);
+    a.xcd_group = (uint32_t)(tunables().dequant_xcd_group > 1 ? tunables().dequant_xcd_group : 0);
     int64_t cap = tunables().dequant_grid > 0 ? tunables().dequant_grid : (int64_t(1) << 31) - 1;
     const unsigned grid = grid_for(a.total_items, cap);
     bool ok = false;
@@ -383,6 +386,7 @@ static int dequant_tokens(const uint8_t* q, const kvq_strides_t* q_st, const flo
   a.dshift = -1;
   a.cpr = 0;
   a.total_items = 0;
+  a.xcd_group = 0;
   const unsigned grid = grid_for((total + kBlock - 1) / kBlock, 256 * 32);
   switch (out_dtype) {
     case KVQ_F16: hipLaunchKernelGGL((dequant_tokens_generic_k<KVQ_F16, BITS>), dim3(grid), dim3(kBlock), 0, st, a, total); break;

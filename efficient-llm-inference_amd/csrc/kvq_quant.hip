@@ -53,6 +53,7 @@ struct QuantArgs {
   int32_t blk;       // workgroup size of the fused kernel (256, or 64 = one wave per tile)
   int32_t nv;        // vectors per lane per tile (8, or 4 for the small one-wave tile)
   int32_t bh_contig; // rows addressable as r * stride_h on both sides
+  uint32_t xcd_group;  // consecutive tiles per XCD for the fused one-tile kernel (0 / 1 = round robin)
 };
 
 // ---------------------------------------------------------------------------- fused single pass
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
   __shared__ float s_scale[kMaxTT], s_rcp[kMaxTT];
   const uint32_t tid = threadIdx.x;
   const uint32_t g = blockIdx.y;
-  const uint32_t t0 = a.t_begin + blockIdx.x * a.TT;
+  const uint32_t t0 = a.t_begin + xcd_grouped_item(blockIdx.x, a.xcd_group, gridDim.x) * a.TT;
   const uint32_t DV = a.D >> 3;
   const uint32_t wmask = (1u << a.vshift) - 1u;
   // is.t == D and qs.t == Dq (or a single token per tile), so within a row the tile is one
@@ -796,6 +797,7 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
   a.nv = kNVMax;
   a.nt_loads = (int32_t)tunables().nt_loads;
   a.bh_contig = bh_contig ? 1 : 0;
+  a.xcd_group = (uint32_t)(tunables().quant_xcd_group > 1 ? tunables().quant_xcd_group : 0);
   if (fused && anydv) {
     const int64_t dv = d->D / 8;
     int64_t tt = (256 * 1024) / (R * d->D * esz);

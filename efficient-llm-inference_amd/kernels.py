@@ -407,6 +407,35 @@ def decode_step(plan: DecodeStepPlan, q: torch.Tensor, k_new: torch.Tensor, v_ne
         c_void_p(workspace.data_ptr()), workspace.numel(), byref(dims), _lib.current_stream(q.device)), "decode_step")
 
 
+def decode_step_dev(plan: DecodeStepPlan, q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, t_dev: torch.Tensor,
+                    t_bound: int, out: torch.Tensor, workspace: torch.Tensor, sm_scale: float) -> None:
+    """:func:`decode_step` with the stored-token count in device memory (kvq_decode_step_dev): ``t_dev`` is a
+    one-element int32 GPU tensor, ``t_bound`` the host's upper bound on it (sizes the grid; the workspace must
+    cover ``decode_attn_workspace(..., t_bound, ...)``). Every launch argument is step-independent, so the call
+    can be captured into a HIP graph and replayed; the caller adds 1 to ``t_dev`` on the same stream afterwards
+    and guarantees ``t_dev <= t_bound < capacity``."""
+    t_bound = int(t_bound)
+    if t_bound < 1 or t_bound >= plan.cap:
+        raise _lib.KvqError(f"kvq: decode_step_dev bound {t_bound} is outside the store (capacity {plan.cap})")
+    require_gpu(t_dev, "t_dev")
+    if t_dev.dtype != torch.int32 or t_dev.numel() != 1:
+        raise _lib.KvqError("kvq: decode_step_dev t_dev must be a one-element int32 tensor")
+    if (q.shape != (plan.B, plan.Hq, plan.D) or out.shape != q.shape or k_new.shape != (plan.B, plan.Hkv, plan.D)
+            or v_new.shape != k_new.shape or not (q.is_cuda and k_new.is_cuda and v_new.is_cuda and out.is_cuda)
+            or q.stride(2) != 1 or k_new.stride(2) != 1 or v_new.stride(2) != 1 or out.stride(2) != 1
+            or k_new.dtype != q.dtype or v_new.dtype != q.dtype or out.dtype != q.dtype):
+        raise _lib.KvqError("kvq: decode_step_dev tensors do not match the plan (shape / dtype / device / contiguity)")
+    dims = _lib.KvqAttnDims(plan.B, plan.Hq, plan.Hkv, t_bound, plan.D)
+    check(_lib.load().kvq_decode_step_dev(
+        c_void_p(q.data_ptr()), q.stride(0), q.stride(1),
+        c_void_p(k_new.data_ptr()), k_new.stride(0), k_new.stride(1),
+        c_void_p(v_new.data_ptr()), v_new.stride(0), v_new.stride(1),
+        plan.k_ptr, byref(plan.kst), plan.ks_ptr, plan.kbits, plan.v_ptr, byref(plan.vst), plan.vs_ptr, plan.vbits,
+        c_void_p(out.data_ptr()), out.stride(0), out.stride(1), plan.dtype_code, float(sm_scale), plan.eps,
+        c_void_p(workspace.data_ptr()), workspace.numel(), byref(dims), c_void_p(t_dev.data_ptr()),
+        _lib.current_stream(q.device)), "decode_step_dev")
+
+
 class DecodeLayersPlan:
     """Pointer tables of :func:`decode_step_layers`: one decode step's attention for ALL layers of a
     store behind one host call (kvq_decode_step_layers). Built once per (store allocation, query /

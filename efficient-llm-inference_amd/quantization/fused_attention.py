@@ -75,8 +75,9 @@ if DynamicLayer is not None:
             if key_states.shape[-2] == 1 and self.past > 0:
                 # decode: the attention function quantises this token into slot `past` in the same
                 # host call that attends (kvq_decode_step); only the capacity is settled here
-                qc._k.reserve(self.past + 1)
-                qc._v.reserve(self.past + 1)
+                if self._owner.t_dev is None:  # graph mode: capacity was reserved up front, nothing may reallocate
+                    qc._k.reserve(self.past + 1)
+                    qc._v.reserve(self.past + 1)
                 self.pending = True
                 return key_states, value_states
             # prompt: a dense copy takes the single-pass quantise path; one launch per store
@@ -104,6 +105,15 @@ class FusedQuantizedCache:
         self._ws: Optional[torch.Tensor] = None
         self._ws_key = None
         self._ws_T = 0
+        # transformers materialises the (all-true) causal mask of a single-token query while a stream is being
+        # captured instead of skipping it; a driver that guarantees un-padded prompts (the graphed decode of
+        # KVCacheBenchmarker) sets this so that the mask is ignored rather than refused
+        self.ignore_decode_mask = False
+        # graph mode (KVCacheBenchmarker.graph_decode): the stored-token count lives in this one-element int32
+        # GPU tensor, every decode step runs kvq_decode_step_dev with step-independent launch arguments, and the
+        # DRIVER advances the host-side lengths (once per replayed step) — see _fused_attention_forward
+        self.t_dev: Optional[torch.Tensor] = None
+        self.t_bound = 0
 
     def workspace(self, B: int, Hq: int, Hkv: int, T: int, D: int, device) -> torch.Tensor:
         """Scratch for the split partials, sized once for the reserved capacity (decode never reallocates
@@ -163,7 +173,7 @@ def _fused_attention_forward(module, query, key, value, attention_mask=None, dro
         out = torch.nn.functional.scaled_dot_product_attention(query, key, value, is_causal=n > 1, scale=scale,
                                                                enable_gqa=Hkv != Hq)
         return out.transpose(1, 2).contiguous(), None
-    if attention_mask is not None:
+    if attention_mask is not None and not owner.ignore_decode_mask:
         raise RuntimeError("kvq: fused decode attention does not take a padding mask")
     qc, i = owner.qcache, module.layer_idx
     T = layer.past
@@ -173,6 +183,13 @@ def _fused_attention_forward(module, query, key, value, attention_mask=None, dro
     if plan is None or plan.key != (qc._k.q[i].data_ptr(), qc._v.q[i].data_ptr(), query.dtype, B, Hq, D):
         plan = layer.plan = kernels.DecodeStepPlan(q3, qc._k.q[i], qc._k.scales[i], qc._k.kind, qc._v.q[i],
                                                    qc._v.scales[i], qc._v.kind, qc._k.eps)
+    if owner.t_dev is not None:
+        # device-side T: the same launches serve every later step (captured once, replayed per token); the
+        # host-side lengths are the driver's to advance
+        kernels.decode_step_dev(plan, q3, key[:, :, 0], value[:, :, 0], owner.t_dev, owner.t_bound, out[:, 0],
+                                owner.workspace(B, Hq, Hkv, owner.t_bound, D, query.device), scale)
+        layer.pending = False
+        return out, None
     kernels.decode_step(plan, q3, key[:, :, 0], value[:, :, 0], T, out[:, 0],
                         owner.workspace(B, Hq, Hkv, T, D, query.device), scale)
     qc._k.lens[i] = qc._v.lens[i] = T + 1  # the step appended the token

@@ -346,7 +346,7 @@ int main(int argc, char** argv) {
 
   auto run_quant = [&](int bits) {
     const double bytes = bits == 4 ? N * 2.5 : N * 3.0;
-    for (int two_pass = 0; two_pass < ((what == "ntload" || what == "qblock" || what == "regmax" || what == "qnv" || what == "qocc" || what == "qtpw") ? 1 : 2); ++two_pass) {
+    for (int two_pass = 0; two_pass < ((what == "ntload" || what == "qblock" || what == "regmax" || what == "qnv" || what == "qocc" || what == "qtpw" || what == "xcdgroup") ? 1 : 2); ++two_pass) {
       KVQ_OK(kvq_set_tunable("quant_force_two_pass", two_pass));
       double ms = tm.ms_per(
           [&] {
@@ -392,6 +392,31 @@ int main(int argc, char** argv) {
         run_quant(8);
       }
     KVQ_OK(kvq_set_tunable("quant_tpw", 0));
+  }
+  if (what == "xcdgroup") {  // consecutive work items per XCD (xcd_grouped_item), interleaved rounds
+    auto run_dequant = [&](int bits) {
+      const double bytes = bits == 4 ? N * 2.5 : N * 3.0;
+      double ms = tm.ms_per(
+          [&] {
+            rotate();
+            if (bits == 4) KVQ_OK(kvq_dequant_i4_tokens((const uint8_t*)q4, &s_half, scales, T, out, &s_full, KVQ_F16, &dims, 0));
+            else KVQ_OK(kvq_dequant_i8_tokens((const int8_t*)q8, &s_full, scales, T, out, &s_full, KVQ_F16, &dims, 0));
+          },
+          iters);
+      printf("dequant_i%d  %8.3f ms  %8.1f GB/s  frac8T=%.3f\n", bits, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0);
+    };
+    for (int rep = 0; rep < 3; ++rep)
+      for (int k : {0, 2, 4, 8, 16, 64}) {
+        KVQ_OK(kvq_set_tunable("dequant_xcd_group", k));
+        KVQ_OK(kvq_set_tunable("quant_xcd_group", k));
+        printf("xcd_group=%d\n", k);
+        run_dequant(4);
+        run_dequant(8);
+        run_quant(4);
+        run_quant(8);
+      }
+    KVQ_OK(kvq_set_tunable("dequant_xcd_group", 0));
+    KVQ_OK(kvq_set_tunable("quant_xcd_group", 0));
   }
   if (what == "qocc") {  // waves per CU of the one-wave quantise kernel, capped through unused dynamic LDS
     for (int rep = 0; rep < 2; ++rep)

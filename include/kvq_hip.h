@@ -227,6 +227,23 @@ int kvq_decode_step(const void* q, int64_t q_stride_b, int64_t q_stride_h,
                     void* out, int64_t out_stride_b, int64_t out_stride_h, int dtype, float sm_scale, float eps,
                     float* workspace, int64_t workspace_floats, const kvq_attn_dims_t* dims, void* stream);
 
+/* kvq_decode_step with the stored-token count in DEVICE memory: every argument of the two launches is then the
+ * same from one decode step to the next, so a HIP graph that captured the step (together with the model's own
+ * kernels) can be replayed for every later token — the host loop of the reference's generate_with_quantized_kv
+ * (src/benchmarking/benchmarker.py:465-486) leaves the critical path. `*t_dev` (int32) = tokens stored before
+ * the step; the caller increments it on the same stream afterwards. dims->T is the HOST's upper bound on
+ * *t_dev (e.g. the store's capacity - 1): it sizes the grid and the workspace (kvq_decode_attn_workspace for
+ * that T); workgroups beyond the live count exit at once. The caller guarantees *t_dev <= dims->T and room for
+ * slot *t_dev. One-tile kernels only (no streaming / fused variants); B * Hkv * D <= 65536. */
+int kvq_decode_step_dev(const void* q, int64_t q_stride_b, int64_t q_stride_h,
+                        const void* k_new, int64_t kn_stride_b, int64_t kn_stride_h,
+                        const void* v_new, int64_t vn_stride_b, int64_t vn_stride_h,
+                        uint8_t* k_store, const kvq_strides_t* k_st, float* k_scales, int k_bits,
+                        uint8_t* v_store, const kvq_strides_t* v_st, float* v_scales, int v_bits,
+                        void* out, int64_t out_stride_b, int64_t out_stride_h, int dtype, float sm_scale, float eps,
+                        float* workspace, int64_t workspace_floats, const kvq_attn_dims_t* dims, const int32_t* t_dev,
+                        void* stream);
+
 /* kvq_decode_step (append != 0) or kvq_decode_attn with the new token given (append == 0) for n_layers
  * layers behind ONE host call: the per-layer launches are enqueued back to back on `stream` (each layer
  * one launch on the fused path), so a decode step costs one trip through the binding instead of one per

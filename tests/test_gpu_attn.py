@@ -464,3 +464,50 @@ def test_decode_step_layers_equals_per_layer_calls(K, tunable, append, fused):
     from efficient_llm_inference_amd._lib import KvqError
     with pytest.raises(KvqError):
         K.decode_step_layers(plan, cap + 1, ws, sm)
+
+
+@pytest.mark.parametrize("shape", [(1, 12, 12, 64), (2, 32, 8, 128), (1, 8, 2, 128)])
+@pytest.mark.parametrize("kinds", [("int8", "int8"), ("int8", "int4"), ("int4", "int8")])
+def test_decode_step_dev_reads_token_count_from_device(K, shape, kinds):
+    """kvq_decode_step_dev: ONE set of launch arguments (upper bound as the host's T) serves every context length;
+    the stored-token count is read from a device word. For a sweep of counts written into that word: output within
+    tolerance of the oracle, slot T quantised bit-exactly, nothing else touched — VALU and MFMA kernels."""
+    B, Hq, Hkv, D = shape
+    cap, bound = 420, 400
+    rng = np.random.default_rng(Hq * 7 + D)
+    k = rng.standard_normal((1, B, Hkv, cap, D)).astype(np.float16)
+    v = rng.standard_normal((1, B, Hkv, cap, D)).astype(np.float16)
+    kq, _, ks = O.quantize_tokens(k, kinds[0])
+    vq, _, vs = O.quantize_tokens(v, kinds[1])
+    q = rng.standard_normal((B, Hq, D)).astype(np.float16)
+    sm = D ** -0.5
+    qt = to_torch(q)
+    ws = torch.empty(K.decode_attn_workspace_cap(B, Hq, Hkv, cap, D), dtype=torch.float32, device="cuda")
+    t_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for T in (1, 2, 77, 128, 129, 256, 300, 400):
+        k_store = torch.full((B, Hkv, cap, kq.shape[-1]), 9, dtype=K.QDTYPE[kinds[0]], device="cuda")
+        v_store = torch.full((B, Hkv, cap, vq.shape[-1]), 9, dtype=K.QDTYPE[kinds[1]], device="cuda")
+        k_sc = torch.full((cap,), -1.0, device="cuda")
+        v_sc = torch.full((cap,), -1.0, device="cuda")
+        k_store[:, :, :T] = to_torch(kq[0][:, :, :T])
+        v_store[:, :, :T] = to_torch(vq[0][:, :, :T])
+        k_sc[:T] = to_torch(ks[0][:T])
+        v_sc[:T] = to_torch(vs[0][:T])
+        kn, vn = to_torch(k[0][:, :, T].copy()), to_torch(v[0][:, :, T].copy())
+        out = torch.full_like(qt, float("nan"))
+        plan = K.DecodeStepPlan(qt, k_store, k_sc, kinds[0], v_store, v_sc, kinds[1], 1e-8)
+        t_dev.fill_(T)
+        K.decode_step_dev(plan, qt, kn, vn, t_dev, bound, out, ws, sm)
+        torch.cuda.synchronize()
+        ref = O.decode_attention(q, kq[0][:, :, :T], ks[0][:T], kinds[0], vq[0][:, :, :T], vs[0][:T], kinds[1], D, sm,
+                                 k[0][:, :, T].astype(np.float32), v[0][:, :, T].astype(np.float32))
+        got = to_numpy(out).astype(np.float64)
+        assert np.isfinite(got).all() and (np.abs(got - ref) <= TOL["f16"] * (np.abs(ref) + np.abs(ref).max())).all(), T
+        assert np.array_equal(to_numpy(k_store[:, :, :T + 1]), kq[0][:, :, :T + 1]) and np.array_equal(to_numpy(v_store[:, :, :T + 1]), vq[0][:, :, :T + 1]), T
+        assert np.array_equal(to_numpy(k_sc[:T + 1]), ks[0][:T + 1]) and np.array_equal(to_numpy(v_sc[:T + 1]), vs[0][:T + 1])
+        assert int((k_store[:, :, T + 1:] != 9).sum()) == 0 and float((k_sc[T + 1:] + 1.0).abs().sum()) == 0.0
+    from efficient_llm_inference_amd._lib import KvqError
+    with pytest.raises(KvqError):
+        K.decode_step_dev(plan, qt, kn, vn, t_dev, cap, out, ws, sm)  # bound outside the store
+    with pytest.raises(KvqError):
+        K.decode_step_dev(plan, qt, kn, vn, t_dev.long(), bound, out, ws, sm)  # not int32

@@ -435,3 +435,29 @@ def test_golden_cache_bf16_kv_fp16_compute(E, cname, mode):
     sc = torch.stack([torch.stack([torch.stack(l.k_scales), torch.stack(l.v_scales)]) for l in qc.layers])
     assert sc.dtype == torch.bfloat16 and np.array_equal(bits(sc), bits(g[f"{cname}.{mode}.scales"]))
     assert qc.estimated_bytes() == int(g[f"{cname}.{mode}.bytes"][0])
+
+
+@pytest.mark.parametrize("k", [2, 4, 8, 16])
+def test_xcd_grouped_item_order_is_a_permutation(E, k):
+    """dequant_xcd_group / quant_xcd_group only re-order which workgroup takes which chunk / tile
+    (xcd_grouped_item: k consecutive items per XCD): results stay bit-exact for every k, with item counts
+    that are and are not multiples of the 8 k window."""
+    from efficient_llm_inference_amd import _lib, kernels
+    for case in ((4, 1, 8, 300, 128), (2, 1, 8, 64, 128), (3, 1, 8, 1031, 128), (1, 2, 4, 37, 128)):
+        G, B, H, T, D = case
+        x_np = seeded_kv(case, "f16", seed=k * 131 + T, dist="heavy")
+        for kind in ("int8", "int4"):
+            q_ref, _, s32_ref = O.quantize_tokens(x_np, kind)
+            _lib.set_tunable("quant_xcd_group", k)
+            _lib.set_tunable("dequant_xcd_group", k)
+            try:
+                store, scales = _quant_via_kernels(E, x_np, "f16", kind, False, False, block=64)
+                assert np.array_equal(to_numpy(store[:, :, :, 1:T + 1]), q_ref) and np.array_equal(bits(scales[:, 1:T + 1]), bits(s32_ref))
+                q = to_torch(q_ref)
+                sc = to_torch(s32_ref)
+                out = torch.empty(case, dtype=torch.float16, device="cuda")
+                kernels.dequant_tokens(q, sc, out, kind)
+                assert np.array_equal(bits(out), bits(O.dequantize_tokens(q_ref, s32_ref, kind, D, "f16"))), (case, kind, k)
+            finally:
+                _lib.set_tunable("quant_xcd_group", 0)
+                _lib.set_tunable("dequant_xcd_group", 0)
