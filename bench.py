@@ -438,7 +438,8 @@ def launch_ranks(args, argv):
         sys.stderr.write(out0)
         who = "the launcher's timeout" if failed[0] < 0 else f"rank {failed[0]} (exit code {failed[1]})"
         raise SystemExit(f"bench.py --gpus {n}: failed in {who}; no result line")
-    sys.stdout.write(procs[0].stdout.read())
+    for line in procs[0].stdout.read().splitlines():  # the result line to stdout; library chatter (gloo prints to stdout) to stderr
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
 
 
@@ -575,18 +576,18 @@ def run_dequant(args, rank, world, dev, backend):
     def step(i, evs=None):
         ko, vo = outs[i & 1]
         c = caches[i % len(caches)]
-        if evs is not None:
-            evs[0].record()
         c._k.dequant(torch.float16, out=ko)  # all layers of K: one launch
         if evs is not None:
-            evs[1].record()
-        c._v.dequant(torch.float16, out=vo)  # all layers of V: one launch
+            evs[0].record()
+        c._v.dequant(torch.float16, out=vo)  # all layers of V: one launch (the roofline kernel, bracketed by events)
         if evs is not None:
-            evs[2].record()
+            evs[1].record()
 
     for i in range(args.warmup):
         step(i)
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    # Two events per step, around the INT4 launch only: an event record is a barrier packet on the queue (several
+    # microseconds), so bracketing every launch would slow the very step whose wall time is `value`.
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps)]
     torch.cuda.synchronize()
     sharding.barrier()
     torch.cuda.synchronize()
@@ -598,9 +599,23 @@ def run_dequant(args, rank, world, dev, backend):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    k_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
-    v_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
+    v_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
     elapsed = sharding.max_over_ranks(elapsed, dev)  # the step takes as long as the slowest rank
+
+    # side measurement, outside the timed region: the INT8 (K) launch on the same rotation of caches / outputs
+    kev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    k_ms, k_n = 0.0, 8
+    for i in range(k_n + 2):
+        ko, _ = outs[i & 1]
+        c = caches[i % len(caches)]
+        if i >= 2:
+            kev[0].record()
+        c._k.dequant(torch.float16, out=ko)
+        if i >= 2:
+            kev[1].record()
+            torch.cuda.synchronize()
+            k_ms += kev[0].elapsed_time(kev[1])
+    k_ms /= k_n
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -638,13 +653,14 @@ def run_dequant(args, rank, world, dev, backend):
                 "traffic": traffic, "traffic_source": "profiles/traffic.json (rocprofv3 PMC passes of this command, committed; "
                                                       "not re-measured in this run)" if traffic is not None else None,
                 "algorithmic_bytes_per_launch": int(target_bytes),
-                "avg_launch_ms": round(target_ms, 4), "timer": "HIP events on the launch stream, per launch, in the timed region",
+                "avg_launch_ms": round(target_ms, 4), "timer": "HIP events on the launch stream around every INT4 launch of the timed region",
             },
             "roofline_k": {
                 "kernel": f"dequant_tokens_fast_k<{kk}>", "bound": "hbm",
                 "achieved": round(bytes_k / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(bytes_k / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                 "algorithmic_bytes_per_launch": int(bytes_k), "avg_launch_ms": round(k_ms, 4),
+                "timer": "HIP events around 8 launches after the timed region",
             },
             "roofline_quantise": quant_info,
             "est_kv_cache_mb": round(est_mb, 3),
