@@ -543,6 +543,14 @@ def run_dequant(args, rank, world, dev, backend):
     torch.cuda.synchronize()
     est_mb = qc.estimated_bytes() / 2**20
 
+    # two rotating output sets so consecutive steps never write the same lines (allocated before the side
+    # measurement below, so that nothing idles the GPU between it, the warm-up and the timed region)
+    outs = [(torch.empty(L, B, H, T, D, device=dev, dtype=torch.float16),
+             torch.empty(L, B, H, T, D, device=dev, dtype=torch.float16)) for _ in range(2)]
+    for ko, vo in outs:  # first touch of the fresh pages happens here, not in a timed step
+        ko.zero_()
+        vo.zero_()
+
     # side measurement, outside the timed region: the prefill quantise kernels (rows a1/a2) on the
     # same tensors, re-quantising into the same store (identical bytes every time)
     from efficient_llm_inference_amd import kernels as _k
@@ -561,17 +569,10 @@ def run_dequant(args, rank, world, dev, backend):
         quant_info[f"quant_{store.kind}"] = {"avg_launch_ms": round(ms, 4), "achieved": round(qbytes / (ms * 1e-3) / 1e9, 1),
                                              "frac": round(qbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                              "algorithmic_bytes_per_launch": int(qbytes), "set": name.upper()}
-    del past
-    torch.cuda.empty_cache()
-
     n_elts = L * B * H * T * D  # per K or V set
     bytes_k = n_elts * BYTES_PER_ELT[kk]
     bytes_v = n_elts * BYTES_PER_ELT[vk]
     step_bytes = bytes_k + bytes_v
-
-    # two rotating output sets so consecutive steps never write the same lines
-    outs = [(torch.empty(L, B, H, T, D, device=dev, dtype=torch.float16),
-             torch.empty(L, B, H, T, D, device=dev, dtype=torch.float16)) for _ in range(2)]
 
     def step(i, evs=None):
         ko, vo = outs[i & 1]
@@ -599,7 +600,8 @@ def run_dequant(args, rank, world, dev, backend):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    v_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
+    v_each = sorted(e[0].elapsed_time(e[1]) for e in events)
+    v_ms = sum(v_each) / args.steps
     elapsed = sharding.max_over_ranks(elapsed, dev)  # the step takes as long as the slowest rank
 
     # side measurement, outside the timed region: the INT8 (K) launch on the same rotation of caches / outputs
@@ -653,7 +655,9 @@ def run_dequant(args, rank, world, dev, backend):
                 "traffic": traffic, "traffic_source": "profiles/traffic.json (rocprofv3 PMC passes of this command, committed; "
                                                       "not re-measured in this run)" if traffic is not None else None,
                 "algorithmic_bytes_per_launch": int(target_bytes),
-                "avg_launch_ms": round(target_ms, 4), "timer": "HIP events on the launch stream around every INT4 launch of the timed region",
+                "avg_launch_ms": round(target_ms, 4), "median_launch_ms": round(v_each[len(v_each) // 2], 4),
+                "min_launch_ms": round(v_each[0], 4), "max_launch_ms": round(v_each[-1], 4),
+                "timer": "HIP events on the launch stream around every INT4 launch of the timed region",
             },
             "roofline_k": {
                 "kernel": f"dequant_tokens_fast_k<{kk}>", "bound": "hbm",

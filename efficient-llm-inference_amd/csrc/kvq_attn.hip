@@ -465,6 +465,9 @@ __device__ inline void transpose4x4(uint32_t a0, uint32_t a1, uint32_t a2, uint3
 // on return lane (x, g) holds m (log2 domain) and l of head x, and acc[c][r] = head 4 g + r, element
 // d = DVN x + e(c) (see attn_tile_store) of sum_t p[t] sv[t] v_int[t, d] / svmax. s_ks / s_vs: TC floats of
 // LDS each, private to this wave.
+// (Requesting EVERY V step together with the K rows — one round trip for the whole tile — was measured at batch 1,
+// where the launch is a single round of waves and registers are free: 10.5 us vs 9.6 us for the partial kernel,
+// profiles/r02s_attn_b1_vfirst.txt. The staggered requests below stay.)
 template <int KBITS, int VBITS, int TC, int HD>
 struct AttnTile {
   static_assert(HD == 64 || HD == 128, "head_dim of the MFMA kernel");
@@ -1432,6 +1435,13 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_k(const AttnArgs
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(accb) + d4;
     uint32_t s = g;
+    for (; s + 7u * groups < ns; s += 8u * groups) {  // 8 independent loads in flight: at batch 1 the merge is pure latency
+      f32x4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = src[(int64_t)(s + (uint32_t)u * groups) * dv];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) o += x[u] * s_wt[s + (uint32_t)u * groups];
+    }
     for (; s + 3u * groups < ns; s += 4u * groups) {  // 4 independent loads in flight
       const f32x4 x0 = src[(int64_t)s * dv];
       const f32x4 x1 = src[(int64_t)(s + groups) * dv];

@@ -104,6 +104,24 @@ __global__ __launch_bounds__(256) void read_seg_k(const u32x4* __restrict__ in, 
   }
   if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
 }
+// the same bytes per wave (4 chunks of 16 KiB) with every wave-level load instruction ONE contiguous 1 KiB
+// (4 consecutive rows of one chunk; the instruction stream cycles over the wave's 4 chunks)
+template <int BATCH>
+__global__ __launch_bounds__(64) void read_seg_rows_k(const u32x4* __restrict__ in, uint32_t* sink, int64_t n_chunks) {
+  const int64_t wave = blockIdx.x;
+  const int lane = threadIdx.x, g = lane >> 4, x = lane & 15;
+  if (wave * 4 + 3 >= n_chunks) return;
+  const u32x4* p = in + wave * 4 * 1024 + g * 16 + x;
+  u32x4 acc = {0, 0, 0, 0};
+  for (int b = 0; b < 64 / (BATCH / 4 * 4); ++b) {  // BATCH loads cover BATCH / 4 row quads of each of the 4 chunks
+    u32x4 v[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) v[u] = p[(u & 3) * 1024 + (b * (BATCH / 4) + (u >> 2)) * 64];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) acc ^= v[u];
+  }
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
+}
 __global__ void rand_fill_k(uint32_t* p, int64_t n_words, uint32_t seed) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * 256) {
     uint32_t x = (uint32_t)i * 2654435761u + seed;
@@ -235,6 +253,24 @@ int main(int argc, char** argv) {
   kvq_strides_t s_full = {B * H * T * D, H * T * D, T * D, D};
   kvq_strides_t s_half = {B * H * T * D / 2, H * T * D / 2, T * D / 2, D / 2};
 
+  if (what == "readpat") {  // read patterns of the chunk mean-pool kernel, no arithmetic
+    const int64_t n_chunks = N * 2 / 16384;
+    const int grid = (int)((n_chunks * 16 + 255) / 256);
+    const int grid64 = (int)(n_chunks / 4);
+    const int64_t n16 = N * 2 / 16;
+    for (int rep = 0; rep < 3; ++rep) {
+      double ms = tm.ms_per([&] { rotate(); read_seg_k<16><<<grid, 256>>>((const u32x4*)in16, (uint32_t*)ws, n_chunks); }, iters);
+      printf("calib readseg  batch=16 block=256 %8.3f ms  %8.1f GB/s (r, 4 x 256 B segments per wave load)\n", ms, 1.0 * N * 2 / ms / 1e6);
+      ms = tm.ms_per([&] { rotate(); read_seg_rows_k<8><<<grid64, 64>>>((const u32x4*)in16, (uint32_t*)ws, n_chunks); }, iters);
+      printf("calib readrows batch=8  block=64  %8.3f ms  %8.1f GB/s (r, 1 KiB contiguous per wave load)\n", ms, 1.0 * N * 2 / ms / 1e6);
+      ms = tm.ms_per([&] { rotate(); read_seg_rows_k<16><<<grid64, 64>>>((const u32x4*)in16, (uint32_t*)ws, n_chunks); }, iters);
+      printf("calib readrows batch=16 block=64  %8.3f ms  %8.1f GB/s (r, 1 KiB contiguous per wave load)\n", ms, 1.0 * N * 2 / ms / 1e6);
+      ms = tm.ms_per([&] { rotate(); read_seg_rows_k<32><<<grid64, 64>>>((const u32x4*)in16, (uint32_t*)ws, n_chunks); }, iters);
+      printf("calib readrows batch=32 block=64  %8.3f ms  %8.1f GB/s (r, 1 KiB contiguous per wave load)\n", ms, 1.0 * N * 2 / ms / 1e6);
+      ms = tm.ms_per([&] { rotate(); read16_k<<<4096, 256>>>((const u32x4*)in16, (uint32_t*)ws, n16); }, iters);
+      printf("calib read16   grid=4096  %8.3f ms  %8.1f GB/s (r)\n", ms, 1.0 * N * 2 / ms / 1e6);
+    }
+  }
   if (what == "copy" || what == "all") {
     const int64_t n16 = N * 2 / 16;  // 1 GiB
     for (int grid : {2048, 4096, 16384, 65536}) {
@@ -285,6 +321,13 @@ int main(int argc, char** argv) {
       printf("calib readseg  batch=16  %8.3f ms  %8.1f GB/s (r, 4 x 256 B segments per wave load)\n", ms, 1.0 * N * 2 / ms / 1e6);
       ms = tm.ms_per([&] { rotate(); read_seg_k<32><<<grid, 256>>>((const u32x4*)in16, (uint32_t*)ws, n_chunks); }, iters);
       printf("calib readseg  batch=32  %8.3f ms  %8.1f GB/s (r, 4 x 256 B segments per wave load)\n", ms, 1.0 * N * 2 / ms / 1e6);
+      const int grid64 = (int)(n_chunks / 4);
+      ms = tm.ms_per([&] { rotate(); read_seg_rows_k<16><<<grid64, 64>>>((const u32x4*)in16, (uint32_t*)ws, n_chunks); }, iters);
+      printf("calib readrows batch=16 block=64  %8.3f ms  %8.1f GB/s (r, 1 KiB contiguous per wave load, 4 chunks per wave)\n", ms, 1.0 * N * 2 / ms / 1e6);
+      ms = tm.ms_per([&] { rotate(); read_seg_rows_k<32><<<grid64, 64>>>((const u32x4*)in16, (uint32_t*)ws, n_chunks); }, iters);
+      printf("calib readrows batch=32 block=64  %8.3f ms  %8.1f GB/s (r, 1 KiB contiguous per wave load, 4 chunks per wave)\n", ms, 1.0 * N * 2 / ms / 1e6);
+      ms = tm.ms_per([&] { rotate(); read_seg_rows_k<8><<<grid64, 64>>>((const u32x4*)in16, (uint32_t*)ws, n_chunks); }, iters);
+      printf("calib readrows batch=8  block=64  %8.3f ms  %8.1f GB/s (r, 1 KiB contiguous per wave load, 4 chunks per wave)\n", ms, 1.0 * N * 2 / ms / 1e6);
     }
     for (int grid : {2048, 4096, 16384}) {
       double ms = tm.ms_per([&] { rotate(); read16_k<<<grid, 256>>>((const u32x4*)in16, (uint32_t*)ws, n16); }, iters);
