@@ -461,3 +461,21 @@ def test_xcd_grouped_item_order_is_a_permutation(E, k):
             finally:
                 _lib.set_tunable("quant_xcd_group", 0)
                 _lib.set_tunable("dequant_xcd_group", 0)
+
+
+@pytest.mark.parametrize("shape,chunk,keep", [((2, 2, 3, 1024, 128), 64, 0), ((2, 1, 8, 1000, 128), 64, 256), ((4, 1, 2, 333, 128), 16, 7),
+                                              ((2, 2, 2, 520, 128), 32, 8), ((2, 1, 1, 256, 128), 64, 0), ((2, 1, 3, 255, 128), 64, 1)])
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_chunk_pool_head_dim_128_bit_exact(E, shape, chunk, keep, dtype):
+    """Chunk mean-pool at the Llama row shape (256-byte token rows): bit-exact with the oracle for chunk counts that
+    are / are not multiples of 4, a ragged last chunk, keep_last 0, single-buffer and pointer-list inputs."""
+    from efficient_llm_inference_amd import kernels
+    G, B, H, T, D = shape
+    x_np = seeded_kv(shape, dtype, seed=zlib.crc32(repr((shape, chunk, keep, dtype)).encode()), dist="heavy")
+    x = to_torch(x_np, dtype)
+    Tout = kernels.chunk_summary_len(T, chunk, keep)
+    ref = O.chunk_summarize_kv(x_np, chunk, keep, dtype=odt(dtype))
+    for src in (x, [x[g] for g in range(G)]):
+        out = torch.empty(G, B, H, Tout, D, dtype=x.dtype, device="cuda")
+        kernels.chunk_meanpool(src, out, chunk, keep)
+        assert np.array_equal(bits(out), bits(ref))

@@ -84,3 +84,26 @@ def test_sparse_policies_structure(T, W, P, stride, bs, kpb, budget):
         ts = max(P, T - W)
         assert len(lists[3]) <= P + min(budget, ts - P) + (T - ts)
         assert len(lists[1]) == P + len(range(P, ts, stride)) + (T - ts)
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.tuples(st.integers(1, 3), st.integers(2, 6), st.integers(1, 4), st.integers(1, 9), st.integers(1, 17)),
+       st.integers(0, 2**31 - 1), st.sampled_from([1e-6, 1.0, 300.0]), st.sampled_from([np.float16, np.float32]),
+       st.integers(1, 5))
+def test_split_phase_quantise_is_shard_invariant(shape, seed, scale, dtype, cut):
+    """SURVEY §8e's exchange step on the oracle: for ANY split of the batch rows, the element-wise MAX of the
+    shards' abs-max tables is the whole batch's table, and quantising every shard with it reproduces the
+    un-sharded quantise (q and scales bit for bit) — what the sharded HIP path relies on."""
+    x = _kv(shape, seed, scale, dtype)
+    B = shape[1]
+    cut = min(cut, B - 1)
+    shards = [x[:, :cut], x[:, cut:]]
+    amax = np.maximum(O.absmax_tokens(shards[0]), O.absmax_tokens(shards[1]))
+    assert np.array_equal(amax.view(np.uint32), O.absmax_tokens(x).view(np.uint32))
+    for kind in ("int8", "int4"):
+        q_ref, st_ref, s32_ref = O.quantize_tokens(x, kind)
+        parts = [O.quantize_tokens_with_absmax(sh, amax, kind) for sh in shards]
+        assert np.array_equal(np.concatenate([p[0] for p in parts], axis=1), q_ref)
+        for p in parts:
+            assert np.array_equal(p[2].view(np.uint32), s32_ref.view(np.uint32))
+            assert np.array_equal(np.asarray(p[1]).view(np.uint8), np.asarray(st_ref).view(np.uint8))
