@@ -64,8 +64,11 @@ struct AttnArgs {
 };
 
 // stored tokens this launch attends: the host's count, or the device word of a graph-replayed step
+// (clamped to the host's bound: a count the caller let run past it can make the result wrong, never the accesses)
 __device__ inline uint32_t live_tokens(const AttnArgs& a) {
-  return a.t_dev ? (uint32_t)__builtin_nontemporal_load(a.t_dev) : a.T;
+  if (!a.t_dev) return a.T;
+  const uint32_t t = (uint32_t)__builtin_nontemporal_load(a.t_dev);
+  return t < a.T ? t : a.T;
 }
 
 __device__ inline f16x2 bits_h2(uint32_t u) {
@@ -461,6 +464,40 @@ __device__ inline void transpose4x4(uint32_t a0, uint32_t a1, uint32_t a2, uint3
   c[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
 }
 
+// INT8 K without any conversion: the stored bytes ARE the A operand of v_mfma_i32_16x16x64_i8 (lane (x, g): row x,
+// k = 16 g .. 16 g + 15 of a 64-wide k-block = the 16 bytes the K load of chunk c already holds). The query becomes
+// two int8 planes per head, q ~= aq (q1 + q2 / 254) with aq = max|q| / 127 (error <= max|q| / 64,516 per element,
+// finer than the f16 input's own 2^-11 for all but the smallest elements), so S = aq (K.q1 + K.q2 / 254) with both
+// products exact in int32. Saves the byte -> f16 conversion of K (5 vector instructions per 4 elements).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+struct QPlanes {
+  i32x4 p1, p2;
+};
+// 16 query values = 8 dwords of f16 pairs (already in element order) -> 16 bytes per plane
+__device__ inline QPlanes quantize_q16(const uint32_t (&w)[8], const float inv) {
+  QPlanes o;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    uint32_t b1 = 0u, b2 = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f16x2 h = bits_h2(w[2 * d + (j >> 1)]);
+      const float t = (float)h[j & 1] * inv;
+      const float q1 = rintf(t);
+      const float q2 = rintf((t - q1) * 254.0f);
+      b1 |= ((uint32_t)(int)q1 & 0xFFu) << (8 * j);
+      b2 |= ((uint32_t)(int)q2 & 0xFFu) << (8 * j);
+    }
+    o.p1[d] = (int)b1;
+    o.p2[d] = (int)b2;
+  }
+  return o;
+}
+__device__ inline float absmax_h2(const uint32_t wd) {
+  const f16x2 h = bits_h2(wd & 0x7FFF7FFFu);
+  return fmaxf((float)h[0], (float)h[1]);
+}
+
 // One wave's tile of TC tokens starting at t0 (nt valid ones, 1 <= nt <= TC) of kv head hk, batch row b:
 // on return lane (x, g) holds m (log2 domain) and l of head x, and acc[c][r] = head 4 g + r, element
 // d = DVN x + e(c) (see attn_tile_store) of sum_t p[t] sv[t] v_int[t, d] / svmax. s_ks / s_vs: TC floats of
@@ -468,9 +505,10 @@ __device__ inline void transpose4x4(uint32_t a0, uint32_t a1, uint32_t a2, uint3
 // (Requesting EVERY V step together with the K rows — one round trip for the whole tile — was measured at batch 1,
 // where the launch is a single round of waves and registers are free: 10.5 us vs 9.6 us for the partial kernel,
 // profiles/r02s_attn_b1_vfirst.txt. The staggered requests below stay.)
-template <int KBITS, int VBITS, int TC, int HD>
+template <int KBITS, int VBITS, int TC, int HD, bool KI8 = false>
 struct AttnTile {
   static_assert(HD == 64 || HD == 128, "head_dim of the MFMA kernel");
+  static_assert(!KI8 || KBITS == 8, "the int8 MFMA path is for INT8 keys");
   static constexpr int NT = TC / 16;   // 16-token score tiles
   static constexpr int NS = TC / 32;   // 32-token P V steps
   static constexpr int KS = HD / 32;   // k-steps of the score product
@@ -622,9 +660,40 @@ struct AttnTile {
 #pragma unroll
       for (int c = 0; c < KS; ++c) qb[c] = pack_h8(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
     }
+    QPlanes qi[KI8 ? NL : 1];
+    float aq = 1.0f;
+    if constexpr (KI8) {  // the head's two int8 planes (w is zero for padded heads: planes 0, aq irrelevant)
+      float qm = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4 * KS; ++j) qm = fmaxf(qm, absmax_h2(w[j]));
+      qm = fmaxf(qm, __shfl_xor(qm, 16));
+      qm = fmaxf(qm, __shfl_xor(qm, 32));
+      aq = qm > 0.0f ? qm / 127.0f : 1.0f;
+      const float inv = qm > 0.0f ? 127.0f / qm : 0.0f;
+#pragma unroll
+      for (int c = 0; c < NL; ++c) {
+        uint32_t wc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wc[j] = w[8 * c + j];
+        qi[c] = quantize_q16(wc, inv);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       f32x4 c4 = {0.0f, 0.0f, 0.0f, 0.0f};
+      if constexpr (KI8) {
+        i32x4 c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < NL; ++c) {
+          const i32x4 ka = {(int)raw[i][c][0], (int)raw[i][c][1], (int)raw[i][c][2], (int)raw[i][c][3]};
+          c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ka, qi[c].p1, c1, 0, 0, 0);
+          c2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ka, qi[c].p2, c2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c4[r] = fmaf((float)c2[r], 1.0f / 254.0f, (float)c1[r]) * aq;
+        sc[i] = c4;
+        continue;
+      }
 #pragma unroll
       for (int c = 0; c < NL; ++c) {
         if constexpr (KBITS == 8) {  // two words = 8 elements = one k-step
@@ -750,9 +819,9 @@ struct AttnTile {
   }
 };
 
-template <int KBITS, int VBITS, int TC, int HD>
+template <int KBITS, int VBITS, int TC, int HD, bool KI8 = false>
 __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnArgs a) {
-  typedef AttnTile<KBITS, VBITS, TC, HD> Tile;
+  typedef AttnTile<KBITS, VBITS, TC, HD, KI8> Tile;
   constexpr int DVN = Tile::DVN;
   __shared__ __attribute__((aligned(16))) float s_ks[TC];
   __shared__ __attribute__((aligned(16))) float s_vs[TC];
@@ -793,7 +862,7 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
 // operands, descriptors) is paid once per tpw tiles, and the split partials shrink by tpw.
 // Same operand layouts as AttnTile (see its header). P is scaled by sv[t] / svref with svref the largest
 // V scale seen so far (non-decreasing), the accumulator carries the matching 1 / svref.
-template <int KBITS, int VBITS, int TC, int HD>
+template <int KBITS, int VBITS, int TC, int HD, bool KI8 = false>
 struct AttnStream {
   typedef AttnTile<KBITS, VBITS, TC, HD> TL;
   static constexpr int NT = TL::NT, NS = TL::NS, KS = TL::KS, DVN = TL::DVN, CBK = TL::CBK, NL = TL::NL, SPL = TL::SPL, VB = TL::VB;
@@ -804,6 +873,8 @@ struct AttnStream {
     float ks[SR], vs[SR];
   };
   f16x8 qb[KS];
+  QPlanes qi[KI8 ? NL : 1];  // INT8 K through the int8 MFMA: the query as two int8 planes, aq their scale
+  float aq;
   float m, l, svref;
   f32x4 acc[DVN];
 
@@ -843,6 +914,23 @@ struct AttnStream {
     }
 #pragma unroll
     for (int c = 0; c < KS; ++c) qb[c] = pack_h8(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
+    aq = 1.0f;
+    if constexpr (KI8) {
+      float qm = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4 * KS; ++j) qm = fmaxf(qm, absmax_h2(w[j]));
+      qm = fmaxf(qm, __shfl_xor(qm, 16));
+      qm = fmaxf(qm, __shfl_xor(qm, 32));
+      aq = qm > 0.0f ? qm / 127.0f : 1.0f;
+      const float inv = qm > 0.0f ? 127.0f / qm : 0.0f;
+#pragma unroll
+      for (int c = 0; c < NL; ++c) {
+        uint32_t wc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wc[j] = w[8 * c + j];
+        qi[c] = quantize_q16(wc, inv);
+      }
+    }
     m = -INFINITY;
     l = 0.0f;
     svref = 0.0f;
@@ -925,6 +1013,19 @@ struct AttnStream {
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       f32x4 c4 = {0.0f, 0.0f, 0.0f, 0.0f};
+      if constexpr (KI8) {
+        i32x4 c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < NL; ++c) {
+          const i32x4 ka = {(int)r.k[i][c][0], (int)r.k[i][c][1], (int)r.k[i][c][2], (int)r.k[i][c][3]};
+          c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ka, qi[c].p1, c1, 0, 0, 0);
+          c2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ka, qi[c].p2, c2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c4[q] = fmaf((float)c2[q], 1.0f / 254.0f, (float)c1[q]) * aq;
+        sc[i] = c4;
+        continue;
+      }
 #pragma unroll
       for (int c = 0; c < NL; ++c) {
 #pragma unroll
@@ -1029,9 +1130,9 @@ struct AttnStream {
 
 // Two tiles' worth of raw rows live in registers: 64-token tiles fit 2 waves per SIMD (<= 256 VGPRs),
 // 32-token tiles 3 (<= 168); the second launch-bounds argument is waves per SIMD for one-wave workgroups.
-template <int KBITS, int VBITS, int TC, int HD>
+template <int KBITS, int VBITS, int TC, int HD, bool KI8 = false>
 __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_stream_mfma_k(const AttnArgs a, const uint32_t tpw) {
-  typedef AttnStream<KBITS, VBITS, TC, HD> ST;
+  typedef AttnStream<KBITS, VBITS, TC, HD, KI8> ST;
   constexpr int DVN = ST::DVN;
   __shared__ __attribute__((aligned(16))) float s_ks[TC];
   __shared__ __attribute__((aligned(16))) float s_vs[TC];
@@ -1590,6 +1691,20 @@ static void launch_fused(const AttnArgs& a, const FusedPlan& p, const NewTokenAr
 template <int KBITS, int VBITS>
 static void launch_partial(const AttnArgs& a, hipStream_t st) {
   const dim3 grid(a.nsplit, a.Hkv, a.B);
+  if constexpr (KBITS == 8) {  // INT8 keys: the stored bytes straight into the int8 MFMA (head_dim 128 shapes)
+    // attn_k_i8: -1 (default) = where the query's int8 planes are amortised over several tiles per wave (streaming
+    // kernel: 50.6 vs 52.3 us per call at batch 8), 1 = always, 0 = never (one tile per wave: 52.6 vs 50.5 us)
+    const int64_t ki8 = tunables().attn_k_i8;
+    if (a.mfma && a.D == 128u && (ki8 > 0 || (ki8 < 0 && a.stream_tpw))) {
+      if (a.stream_tpw && stream_tc() == 64)
+        hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128, true>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
+      else if (a.stream_tpw)
+        hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 32, 128, true>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
+      else if (a.TS == 64u) hipLaunchKernelGGL((decode_attn_partial_mfma_k<KBITS, VBITS, 64, 128, true>), grid, dim3(kWave), 0, st, a);
+      else hipLaunchKernelGGL((decode_attn_partial_mfma_k<KBITS, VBITS, kAttnMfmaTC, 128, true>), grid, dim3(kWave), 0, st, a);
+      return;
+    }
+  }
   if (a.mfma && a.stream_tpw) {
     if (stream_tc() == 64) hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
     else hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 32, 128>), grid, dim3(kWave), 0, st, a, a.stream_tpw);

@@ -31,19 +31,24 @@ def main():
         "The future of artificial intelligence is", "Efficient inference for large language models requires"]
     ref_text, _ = bench.generate_with_cache(prompts[0], cfg.max_new_tokens)
     print(f"{'method':<18} {'tok/s':>9} {'KV MB':>9} {'similarity':>11}")
-    for method, fused in (("full_cache", False), ("quant_int8", False), ("quant_mixed", False), ("quant_int4", False),
-                          ("quant_int8", True), ("quant_mixed", True), ("quant_int4", True)):
+    for method, fused, graph in (("full_cache", False, False), ("quant_int8", False, False), ("quant_mixed", False, False),
+                                 ("quant_int4", False, False), ("quant_int8", True, False), ("quant_mixed", True, False),
+                                 ("quant_int4", True, False), ("quant_int8", True, True), ("quant_mixed", True, True),
+                                 ("quant_int4", True, True)):
         # fused: the model attends straight over the INT8 / INT4 store (no fp16 copy of the cache)
+        # graph: the fused decode step captured once into a HIP graph and replayed per token
         bench.fused_attention = fused
+        bench.graph_decode = graph
         res = bench.benchmark_method(prompts, method=method, max_new_tokens=cfg.max_new_tokens)
         if method == "full_cache":
             sim = 1.0
         else:
             text, _, _ = bench.generate_with_quantized_kv(prompts[0], cfg.max_new_tokens, mode=method[6:])
             sim = text_similarity(ref_text, text)
-        label = method + ("+fused" if fused else "")
+        label = method + ("+graph" if graph else "+fused" if fused else "")
         print(f"{label:<18} {res['tokens_per_sec']:>9.1f} {res['est_kv_cache_mb_avg']:>9.3f} {sim:>11.3f}")
     bench.fused_attention = False
+    bench.graph_decode = False
 
 
 if __name__ == "__main__":

@@ -307,14 +307,14 @@ FUSED_SHAPES = [(128, 4), (128, 8), (64, 8), (32, 16)]  # (tokens per wave, wave
 @pytest.fixture
 def tunable():
     from efficient_llm_inference_amd import _lib
-    touched = []
+    touched = {}
 
     def set_(key, value):
-        touched.append(key)
+        touched.setdefault(key, _lib.get_tunable(key))  # restore what the library shipped with, not 0
         _lib.set_tunable(key, value)
     yield set_
-    for key in touched:
-        _lib.set_tunable(key, 0)
+    for key, old in touched.items():
+        _lib.set_tunable(key, old)
 
 
 @pytest.mark.parametrize("shape", FUSED_SHAPES)
@@ -511,3 +511,20 @@ def test_decode_step_dev_reads_token_count_from_device(K, shape, kinds):
         K.decode_step_dev(plan, qt, kn, vn, t_dev, cap, out, ws, sm)  # bound outside the store
     with pytest.raises(KvqError):
         K.decode_step_dev(plan, qt, kn, vn, t_dev.long(), bound, out, ws, sm)  # not int32
+
+
+@pytest.mark.parametrize("stream", [(-1, 64), (2, 64), (3, 32)])
+def test_decode_attn_int8_keys_through_int8_mfma(K, tunable, stream):
+    """attn_k_i8: INT8 keys go into v_mfma_i32_16x16x64_i8 as stored (no byte -> f16 conversion), the query as two
+    int8 planes. One-tile and streaming kernels, INT8 and INT4 values, fp16 and bf16, padded heads, peaked softmax."""
+    tunable("attn_k_i8", 1)
+    tunable("attn_stream_tpw", stream[0])
+    tunable("attn_stream_tc", stream[1])
+    for case in [(1, 32, 8, 1000, 128), (2, 6, 2, 200, 128), (1, 16, 1, 300, 128), (1, 32, 8, 5000, 128), (3, 8, 2, 1, 128),
+                 (1, 8, 2, 513, 128), (2, 32, 8, 2048, 128)]:
+        for vk in ("int4", "int8"):
+            _run_case(K, *case, "int8", vk, "f16", True)
+        _run_case(K, *case, "int8", "int4", "bf16", True)
+        _run_case(K, *case, "int8", "int4", "f16", False)
+    _run_case(K, 1, 8, 2, 900, 128, "int8", "int8", "f16", True, q_scale=8.0)
+    _run_case(K, 1, 8, 2, 900, 128, "int8", "int4", "f16", True, q_scale=1e-3)
