@@ -194,6 +194,20 @@ def run_decode(args, rank, world, dev):
     sharding.barrier()
     res = sharding.benchmark_sharded(bm, prompts, method, max_new_tokens=n_new)
     base = sharding.benchmark_sharded(bm, prompts, "full_cache", max_new_tokens=n_new)
+    extra = {}
+    if method.startswith("quant_") and not bm.fused_attention:
+        # the same method with the model attending over the store directly, eager and as a replayed HIP graph
+        # (tolerance-level logits instead of the bit-exact staged path: reported beside `value`, never as it)
+        try:
+            bm.fused_attention = True
+            extra["fused_attention_tokens_per_sec"] = round(sharding.benchmark_sharded(bm, prompts, method, max_new_tokens=n_new)["tokens_per_sec"], 2)
+            bm.graph_decode = True
+            extra["graph_decode_tokens_per_sec"] = round(sharding.benchmark_sharded(bm, prompts, method, max_new_tokens=n_new)["tokens_per_sec"], 2)
+        except RuntimeError as exc:  # head_dim / attention variant the fused kernel does not serve
+            extra["fused_attention_unavailable"] = str(exc)[:200]
+        finally:
+            bm.fused_attention = bool(args.fused_attention or args.graph_decode)
+            bm.graph_decode = bool(args.graph_decode)
     if rank == 0:
         cfg = model.config
         print(json.dumps({
@@ -214,7 +228,7 @@ def run_decode(args, rank, world, dev):
             "est_kv_cache_mb": round(res["est_kv_cache_mb_avg"], 3),
             "full_cache_tokens_per_sec": round(base["tokens_per_sec"], 2),
             "vs_full_cache": round(res["tokens_per_sec"] / base["tokens_per_sec"], 3),
-            "gpu_peak_mb": res["gpu_peak_mb"],
+            "gpu_peak_mb": res["gpu_peak_mb"], **extra,
         }), flush=True)
 
 
