@@ -46,6 +46,13 @@ DECODE_DEFAULT = ("gpt2", "quant_int8", 512, 512)  # arch, method, prompt tokens
 # BASELINE.json configs[4]: Llama-3-8B sliding_window + chunk_summary, seq 32K, batch 64 sharded
 # over 8 GPUs = 8 batch rows per GPU: per-rank KV [L=32, 2, B=8, H=8, T=32768, D=128] fp16 = 32 GiB
 EVICT = {"llama3_8b_evict_seq32k": (32, 8, 8, 32768, 128, 256, 64, 256)}  # L,B,H,T,D,window,chunk,keep_last
+# SURVEY §8e's one exchange step: ONE batched [B=64,H,T,D] slice per layer whose batch rows are split over the ranks
+# (strong scaling: the global batch is fixed): abs-max of the local rows -> all_reduce(MAX) of the [G,T] table ->
+# quantise with the whole batch's scales. T = 1 is a decode step's append, T = 512 a prefill chunk.
+SHARDQ = {  # name: (L, B_global, H, T, D)
+    "llama3_8b_batch64_sharded_append": (32, 64, 8, 1, 128),
+    "llama3_8b_batch64_sharded_prefill512": (32, 64, 8, 512, 128),
+}
 # scope row N1 (second form): one decode step's attention over the quantised store, all layers
 ATTN = {  # name: (L, B, Hq, Hkv, T, D, mode)
     "llama3_8b_decode_attn_seq16k": (32, 1, 32, 8, 16384, 128, "mixed"),
@@ -65,7 +72,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="llama3_8b_mixed_seq16k",
                     help="one of %s, or decode:<arch>:<method>[:<prompt_tokens>:<new_tokens>] "
-                         "(e.g. decode:gpt2:quant_int8:512:512; steps = prompts per rank)" % sorted(list(WORKLOADS) + list(ATTN) + list(EVICT)))
+                         "(e.g. decode:gpt2:quant_int8:512:512; steps = prompts per rank)" % sorted(list(WORKLOADS) + list(ATTN) + list(EVICT) + list(SHARDQ)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rotate-caches", type=int, default=2,
                     help="independent quantised caches visited round-robin by consecutive steps, so that no "
@@ -296,6 +303,49 @@ def run_evict(args, rank, world, dev):
         }), flush=True)
 
 
+def run_sharded_quant(args, rank, world, dev):
+    """One STEP = quantise_tokens_batch_sharded of the K set (INT8) and the V set (INT4) of every layer: two abs-max
+    launches, two all_reduce(MAX) of a [L,T] fp32 table (the ONLY collective that carries path data), two quantise
+    launches. Each rank holds B_global / world batch rows."""
+    from efficient_llm_inference_amd import sharding
+    L, Bg, H, T, D = SHARDQ[args.workload]
+    rows = sharding.shard_batch_rows(Bg)
+    Bl = len(rows)
+    torch.manual_seed(42 + rank)
+    k = torch.randn(L, Bl, H, T, D, device=dev, dtype=torch.float16)
+    v = torch.randn(L, Bl, H, T, D, device=dev, dtype=torch.float16)
+    step_bytes = L * Bg * H * T * D * (BYTES_PER_ELT["int8"] + BYTES_PER_ELT["int4"])  # whole job, single-pass bytes
+
+    def step():
+        sharding.quantize_tokens_batch_sharded(k, "int8")
+        sharding.quantize_tokens_batch_sharded(v, "int4")
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "batch-sharded KV quantise step (INT8 K + INT4 V, one scale per token across the WHOLE batch), GB/s",
+            "value": round(step_bytes / (elapsed / args.steps) / 1e9, 2), "unit": "GB/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "shape_L_Bglobal_H_T_D": [L, Bg, H, T, D], "batch_rows_per_rank": Bl,
+                       "step": "kvq_absmax_tokens -> all_reduce(MAX) [L,T] fp32 -> kvq_quant_tokens_from_absmax, K then V",
+                       "collective_bytes_per_step": 2 * L * T * 4,
+                       "parallelism": f"batch rows sharded x{world}; one all_reduce(MAX) per set and step",
+                       "timing_reduction_backend": sharding.backend()},
+        }), flush=True)
+
+
 def _traffic(workload, key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), or None"""
     try:
@@ -523,6 +573,8 @@ def main():
             run_attn(args, rank, world, dev)
         elif args.workload in EVICT:
             run_evict(args, rank, world, dev)
+        elif args.workload in SHARDQ:
+            run_sharded_quant(args, rank, world, dev)
         elif args.workload in WORKLOADS:
             run_dequant(args, rank, world, dev, backend)
         else:

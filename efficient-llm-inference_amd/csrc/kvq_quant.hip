@@ -554,54 +554,62 @@ __global__ __launch_bounds__(kBlock) void quant_tokens_generic_k(const QuantArgs
 // A [B>1,H,1,D] slice whose batch rows are split over ranks still has ONE scale per token (ops.py:27,48:
 // abs().max() of the whole slice), so the fused kernels above cannot be used: the abs-max table must
 // cross ranks between the reduction and the quantisation (one all_reduce(MAX) of [G,T] fp32).
-//   absmax_tokens_vec_k   local rows -> absmax[g,t] (atomic max on the bit pattern of a non-negative float;
-//                         the table is zeroed by the launch function)
-//   quant_tokens_scaled_vec_k   quantise with the GIVEN abs-max values; same quotient / pack / scale code as
-//                         the fused kernels, so a 1-rank run is bit-identical with them
-// 16-byte vectors; shapes that do not qualify take the generic pair (same arithmetic, scalar accesses).
+//   absmax_tokens_tile_k        local rows -> absmax[g,t]
+//   quant_tokens_scaled_tile_k  quantise with the GIVEN abs-max values; same quotient / pack / scale code as
+//                               the fused kernels, so a 1-rank run is bit-identical with them
+// 16-byte vectors; shapes that do not qualify (D % 8, D/8 not a power of two or > 64, token rows not contiguous,
+// unaligned) take the generic pair (same arithmetic, scalar accesses; its abs-max table is zeroed first).
+// Tile ownership as in the fused kernels: a workgroup owns TT tokens of one group (TT * D/8 = tvec vectors per row run,
+// a power of two <= 256) and walks the R = B*H rows, nrs = 256 / tvec of them side by side. The abs-max kernel needs
+// no global atomics (the tile's tokens are nobody else's: register max over the rows, DPP over the D/8 lanes of a
+// token, LDS max across the side-by-side rows); the quantise kernel computes scale and reciprocal once per lane.
 template <int IDT>
-__global__ __launch_bounds__(kBlock) void absmax_tokens_vec_k(const QuantArgs a, uint32_t vecs_per_g) {
-  const uint32_t g = blockIdx.y;
-  const uint32_t DV = a.D >> 3;
-  const char* in = reinterpret_cast<const char*>(a.in.p[g]);
-  uint32_t* amax = reinterpret_cast<uint32_t*>(a.absmax_ws) + (int64_t)g * a.T;
-  for (uint64_t it = (uint64_t)blockIdx.x * kBlock + threadIdx.x; it < vecs_per_g; it += (uint64_t)gridDim.x * kBlock) {
-    const uint32_t v = (uint32_t)it;
-    const uint32_t dv = v % DV;
-    uint32_t r = v / DV;
-    const uint32_t t = r % a.T;
-    r /= a.T;
-    const uint32_t h = r % a.H, b = r / a.H;
-    Vec8<IDT> x;
-    x.load(in + ((int64_t)b * a.is.b + (int64_t)h * a.is.h + (int64_t)t * a.is.t + (int64_t)dv * 8) * Elem<IDT>::size);
-    atomicMax(amax + t, __float_as_uint(Vec8<IDT>::bits_to_f32(x.absmax_bits())));
+__global__ __launch_bounds__(kBlock) void absmax_tokens_tile_k(const QuantArgs a) {
+  __shared__ uint32_t s_amax[kBlock];
+  const uint32_t tid = threadIdx.x, g = blockIdx.y;
+  const uint32_t tvec = 1u << a.vshift, nrs = kBlock >> a.vshift;
+  const uint32_t rs = tid >> a.vshift, wv = tid & (tvec - 1u), tl = wv >> a.dvshift;
+  const uint32_t t0 = blockIdx.x * a.TT;
+  const bool ok = t0 + tl < a.T;
+  const char* in = reinterpret_cast<const char*>(a.in.p[g]) + ((int64_t)t0 * a.is.t + (int64_t)wv * 8) * Elem<IDT>::size;
+  if (tid < a.TT) s_amax[tid] = 0u;
+  __syncthreads();
+  uint32_t m = 0u;
+  if (ok) {
+    for (uint32_t r = rs; r < a.R; r += nrs) {
+      Vec8<IDT> x;
+      x.load(in + ((int64_t)(r / a.H) * a.is.b + (int64_t)(r % a.H) * a.is.h) * Elem<IDT>::size);
+      m = max(m, x.absmax_bits());
+    }
   }
+  m = group_umax(m, a.dvshift);
+  if (ok && (wv & ((1u << a.dvshift) - 1u)) == 0u) atomicMax(&s_amax[tl], m);
+  __syncthreads();
+  if (tid < a.TT && t0 + tid < a.T) a.absmax_ws[(int64_t)g * a.T + t0 + tid] = Vec8<IDT>::bits_to_f32(s_amax[tid]);
 }
 
 template <int IDT, int BITS>
-__global__ __launch_bounds__(kBlock) void quant_tokens_scaled_vec_k(const QuantArgs a, uint32_t vecs_per_g) {
-  const uint32_t g = blockIdx.y;
-  const uint32_t DV = a.D >> 3;
-  const char* in = reinterpret_cast<const char*>(a.in.p[g]);
-  uint8_t* qg = a.q + (int64_t)g * a.qs.g;
-  const float* amax = a.absmax_ws + (int64_t)g * a.T;
+__global__ __launch_bounds__(kBlock) void quant_tokens_scaled_tile_k(const QuantArgs a) {
+  const uint32_t tid = threadIdx.x, g = blockIdx.y;
+  const uint32_t tvec = 1u << a.vshift, nrs = kBlock >> a.vshift;
+  const uint32_t rs = tid >> a.vshift, wv = tid & (tvec - 1u), tl = wv >> a.dvshift;
+  const uint32_t t0 = blockIdx.x * a.TT;
+  if (t0 + tl >= a.T) return;
   constexpr int QV = BITS;
-  for (uint64_t it = (uint64_t)blockIdx.x * kBlock + threadIdx.x; it < vecs_per_g; it += (uint64_t)gridDim.x * kBlock) {
-    const uint32_t v = (uint32_t)it;
-    const uint32_t dv = v % DV;
-    uint32_t r = v / DV;
-    const uint32_t t = r % a.T;
-    r /= a.T;
-    const uint32_t h = r % a.H, b = r / a.H;
+  const char* in = reinterpret_cast<const char*>(a.in.p[g]) + ((int64_t)t0 * a.is.t + (int64_t)wv * 8) * Elem<IDT>::size;
+  uint8_t* q = a.q + (int64_t)g * a.qs.g + (int64_t)(t0 + tl) * a.qs.t + (int64_t)(wv & ((1u << a.dvshift) - 1u)) * QV;
+  const float s32 = fmaxf(a.absmax_ws[(int64_t)g * a.T + t0 + tl] / QRange<BITS>::qmax, a.eps);
+  const float rcp = 1.0f / s32;
+  if (rs == 0u && (wv & ((1u << a.dvshift) - 1u)) == 0u) a.scales[(int64_t)g * a.ssg + t0 + tl] = Elem<IDT>::round_trip(s32);
+  for (uint32_t r = rs; r < a.R; r += nrs) {
+    const uint32_t b = r / a.H, h = r % a.H;
     Vec8<IDT> x;
-    x.load(in + ((int64_t)b * a.is.b + (int64_t)h * a.is.h + (int64_t)t * a.is.t + (int64_t)dv * 8) * Elem<IDT>::size);
-    const float s32 = fmaxf(amax[t] / QRange<BITS>::qmax, a.eps);
+    x.load(in + ((int64_t)b * a.is.b + (int64_t)h * a.is.h) * Elem<IDT>::size);
     uint32_t qb[8];
-    quotient_bits8<BITS>(x, s32, 1.0f / s32, qb);
-    uint8_t* qp = qg + (int64_t)b * a.qs.b + (int64_t)h * a.qs.h + (int64_t)t * a.qs.t + (int64_t)dv * QV;
+    quotient_bits8<BITS>(x, s32, rcp, qb);
+    uint8_t* qp = q + (int64_t)b * a.qs.b + (int64_t)h * a.qs.h;
     if constexpr (BITS == 8) *reinterpret_cast<u32x2*>(qp) = pack_i8(qb);
     else *reinterpret_cast<uint32_t*>(qp) = pack_i4(qb);
-    if (b == 0u && h == 0u && dv == 0u) a.scales[(int64_t)g * a.ssg + t] = Elem<IDT>::round_trip(s32);
   }
 }
 
@@ -929,9 +937,6 @@ static int split_phase(const char* name, int bits, const void* in_base, const vo
     return KVQ_E_DIMS;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (PHASE == 1 && d->G * d->T > 0 &&
-      hipMemsetAsync(absmax, 0, sizeof(float) * (size_t)(d->G * d->T), st) != hipSuccess)  // +0.0f: the identity of max over |x|
-    return check_launch(name);
   if (d->G * d->B * d->H * d->T * d->D == 0) return 0;
   const int esz = in_dtype == KVQ_F32 ? 4 : 2;
   QuantArgs a = {};
@@ -942,11 +947,18 @@ static int split_phase(const char* name, int bits, const void* in_base, const vo
   a.B = (uint32_t)d->B; a.H = (uint32_t)d->H; a.T = (uint32_t)d->T; a.D = (uint32_t)d->D;
   a.R = (uint32_t)(d->B * d->H);
   const int64_t qvec = bits == 8 ? 8 : 4;
-  const int64_t vecs = d->B * d->H * d->T * (d->D / 8);
-  bool vec = d->D % 8 == 0 && vecs < (int64_t(1) << 32) && (a.is.b * esz) % 16 == 0 && (a.is.h * esz) % 16 == 0 &&
-             (a.is.t * esz) % 16 == 0;
+  const int dvshift = d->D % 8 == 0 ? ilog2_exact(d->D / 8) : -1;
+  bool vec = dvshift >= 0 && dvshift <= 6 && (d->T == 1 || a.is.t == d->D) && (a.is.b * esz) % 16 == 0 &&
+             (a.is.h * esz) % 16 == 0 && (a.is.t * esz) % 16 == 0;
   if (PHASE == 2)
     vec = vec && a.qs.g % qvec == 0 && a.qs.b % qvec == 0 && a.qs.h % qvec == 0 && a.qs.t % qvec == 0 && aligned(q, qvec);
+  if (vec) {  // tile = TT tokens (power of two) x D/8 vectors <= 256 vectors per row run
+    uint32_t tt = pow2_floor((uint64_t)(kBlock >> dvshift));
+    while (tt > 1 && tt / 2 >= (uint64_t)d->T) tt /= 2;
+    a.TT = tt;
+    a.dvshift = dvshift;
+    a.vshift = dvshift + ilog2_exact(tt);
+  }
   for (int64_t g0 = 0; g0 < d->G; g0 += kPtrsPerLaunch) {
     const int64_t gn = d->G - g0 < kPtrsPerLaunch ? d->G - g0 : kPtrsPerLaunch;
     bool vec_here = vec;
@@ -965,17 +977,16 @@ static int split_phase(const char* name, int bits, const void* in_base, const vo
       a.q = q + g0 * a.qs.g;
       a.scales = scales + g0 * ssg;
     }
-    int64_t blocks = vec_here ? (vecs + kBlock - 1) / kBlock : 0;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    const dim3 grid((unsigned)blocks, (unsigned)gn);
+    const dim3 grid(vec_here ? (unsigned)((d->T + a.TT - 1) / a.TT) : 1u, (unsigned)gn);
 #define KVQ_BY_DTYPE(EXPR_F16, EXPR_BF16, EXPR_F32) \
   switch (in_dtype) { case KVQ_F16: EXPR_F16; break; case KVQ_BF16: EXPR_BF16; break; default: EXPR_F32; break; }
     if (PHASE == 1) {
       if (vec_here) {
-        KVQ_BY_DTYPE(hipLaunchKernelGGL((absmax_tokens_vec_k<KVQ_F16>), grid, dim3(kBlock), 0, st, a, (uint32_t)vecs),
-                     hipLaunchKernelGGL((absmax_tokens_vec_k<KVQ_BF16>), grid, dim3(kBlock), 0, st, a, (uint32_t)vecs),
-                     hipLaunchKernelGGL((absmax_tokens_vec_k<KVQ_F32>), grid, dim3(kBlock), 0, st, a, (uint32_t)vecs))
+        KVQ_BY_DTYPE(hipLaunchKernelGGL((absmax_tokens_tile_k<KVQ_F16>), grid, dim3(kBlock), 0, st, a),
+                     hipLaunchKernelGGL((absmax_tokens_tile_k<KVQ_BF16>), grid, dim3(kBlock), 0, st, a),
+                     hipLaunchKernelGGL((absmax_tokens_tile_k<KVQ_F32>), grid, dim3(kBlock), 0, st, a))
       } else {
+        if (hipMemsetAsync(a.absmax_ws, 0, sizeof(float) * (size_t)(gn * d->T), st) != hipSuccess) return check_launch(name);
         const int64_t RD = (int64_t)a.R * a.D, chunk_elems = (int64_t)kBlock * 16;
         const uint32_t cpt = (uint32_t)((RD + chunk_elems - 1) / chunk_elems);
         const dim3 ggrid((unsigned)(a.T * cpt), (unsigned)gn);
@@ -985,13 +996,13 @@ static int split_phase(const char* name, int bits, const void* in_base, const vo
       }
     } else if (vec_here) {
       if (bits == 8) {
-        KVQ_BY_DTYPE(hipLaunchKernelGGL((quant_tokens_scaled_vec_k<KVQ_F16, 8>), grid, dim3(kBlock), 0, st, a, (uint32_t)vecs),
-                     hipLaunchKernelGGL((quant_tokens_scaled_vec_k<KVQ_BF16, 8>), grid, dim3(kBlock), 0, st, a, (uint32_t)vecs),
-                     hipLaunchKernelGGL((quant_tokens_scaled_vec_k<KVQ_F32, 8>), grid, dim3(kBlock), 0, st, a, (uint32_t)vecs))
+        KVQ_BY_DTYPE(hipLaunchKernelGGL((quant_tokens_scaled_tile_k<KVQ_F16, 8>), grid, dim3(kBlock), 0, st, a),
+                     hipLaunchKernelGGL((quant_tokens_scaled_tile_k<KVQ_BF16, 8>), grid, dim3(kBlock), 0, st, a),
+                     hipLaunchKernelGGL((quant_tokens_scaled_tile_k<KVQ_F32, 8>), grid, dim3(kBlock), 0, st, a))
       } else {
-        KVQ_BY_DTYPE(hipLaunchKernelGGL((quant_tokens_scaled_vec_k<KVQ_F16, 4>), grid, dim3(kBlock), 0, st, a, (uint32_t)vecs),
-                     hipLaunchKernelGGL((quant_tokens_scaled_vec_k<KVQ_BF16, 4>), grid, dim3(kBlock), 0, st, a, (uint32_t)vecs),
-                     hipLaunchKernelGGL((quant_tokens_scaled_vec_k<KVQ_F32, 4>), grid, dim3(kBlock), 0, st, a, (uint32_t)vecs))
+        KVQ_BY_DTYPE(hipLaunchKernelGGL((quant_tokens_scaled_tile_k<KVQ_F16, 4>), grid, dim3(kBlock), 0, st, a),
+                     hipLaunchKernelGGL((quant_tokens_scaled_tile_k<KVQ_BF16, 4>), grid, dim3(kBlock), 0, st, a),
+                     hipLaunchKernelGGL((quant_tokens_scaled_tile_k<KVQ_F32, 4>), grid, dim3(kBlock), 0, st, a))
       }
     } else {
       const int64_t Dq = bits == 8 ? d->D : (d->D + 1) / 2;

@@ -19,7 +19,10 @@ back) — never a mix that would hang at the next collective.
 """
 from __future__ import annotations
 
+import contextlib
 import datetime
+import os
+import sys
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -27,6 +30,21 @@ import torch.distributed as dist
 
 # the group + device every reduction of this module uses; None = torch's default group
 _STATE = {"group": None, "device": None, "backend": None}
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """File descriptor 1 points at stderr for the duration: gloo / RCCL print connection chatter ("[Gloo] Rank 0 is
+    connected to ...") to STDOUT from C++ while a group comes up, and a benchmark's stdout is its one JSON line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 class RcclUnavailable(RuntimeError):
@@ -43,7 +61,10 @@ def init_distributed(rank: int, world_size: int, device: Optional[torch.device],
     than GPUs (a rehearsal on a small box) — RCCL refuses duplicate devices, so it is not tried.
     RCCL failing on ANY rank raises `RcclUnavailable` on EVERY rank unless ``allow_gloo``."""
     timeout = datetime.timedelta(seconds=timeout_s)
-    dist.init_process_group("gloo", rank=rank, world_size=world_size, timeout=timeout)
+    with _stdout_to_stderr():
+        dist.init_process_group("gloo", rank=rank, world_size=world_size, timeout=timeout)
+        probe = torch.zeros(1)
+        dist.all_reduce(probe)  # gloo connects its pairs lazily: do it (and its chatter) here
     _STATE.update(group=None, device=None, backend="gloo")
     if device is None or device.type != "cuda":
         return "gloo"
@@ -52,10 +73,11 @@ def init_distributed(rank: int, world_size: int, device: Optional[torch.device],
         ok, why = 0, "several ranks share one GPU (RCCL refuses duplicate devices)"
     else:
         try:
-            group = dist.new_group(backend="nccl", timeout=timeout, device_id=device)
-            warm = torch.zeros(1, device=device)
-            dist.all_reduce(warm, group=group)  # RCCL initialises lazily: surface its errors here
-            torch.cuda.synchronize(device)
+            with _stdout_to_stderr():
+                group = dist.new_group(backend="nccl", timeout=timeout, device_id=device)
+                warm = torch.zeros(1, device=device)
+                dist.all_reduce(warm, group=group)  # RCCL initialises lazily: surface its errors here
+                torch.cuda.synchronize(device)
         except Exception as exc:  # noqa: BLE001 - any RCCL / IPC / driver failure
             ok, why = 0, repr(exc)
     flag = torch.tensor([ok], dtype=torch.int32)
