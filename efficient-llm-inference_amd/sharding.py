@@ -68,28 +68,35 @@ def init_distributed(rank: int, world_size: int, device: Optional[torch.device],
     _STATE.update(group=None, device=None, backend="gloo")
     if device is None or device.type != "cuda":
         return "gloo"
-    ok, why, group = 1, "", None
+    group, why = None, ""
     if ranks_share_device:
-        ok, why = 0, "several ranks share one GPU (RCCL refuses duplicate devices)"
+        why = "several ranks share one GPU (RCCL refuses duplicate devices)"
     else:
-        try:
-            with _stdout_to_stderr():
-                group = dist.new_group(backend="nccl", timeout=timeout, device_id=device)
-                warm = torch.zeros(1, device=device)
-                dist.all_reduce(warm, group=group)  # RCCL initialises lazily: surface its errors here
-                torch.cuda.synchronize(device)
-        except Exception as exc:  # noqa: BLE001 - any RCCL / IPC / driver failure
-            ok, why = 0, repr(exc)
-    flag = torch.tensor([ok], dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # over gloo: every rank learns the same answer
-    if int(flag.item()) == 1:
+        # two attempts, every rank in lockstep (new_group is itself a collective over the gloo group): eager
+        # communicator creation bound to this rank's device first, torch's lazy initialisation second
+        for kwargs in ({"device_id": device}, {}):
+            ok, g = 1, None
+            try:
+                with _stdout_to_stderr():
+                    g = dist.new_group(backend="nccl", timeout=timeout, **kwargs)
+                    warm = torch.zeros(1, device=device)
+                    dist.all_reduce(warm, group=g)  # RCCL initialises lazily: surface its errors here
+                    torch.cuda.synchronize(device)
+            except Exception as exc:  # noqa: BLE001 - any RCCL / IPC / driver failure
+                ok, why = 0, (why + "; " if why else "") + repr(exc)
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # over gloo: every rank learns the same answer
+            if int(flag.item()) == 1:
+                group = g
+                break
+            if g is not None and ok:  # it worked here but not everywhere: drop it and stay in lockstep
+                try:
+                    dist.destroy_process_group(g)
+                except Exception:  # noqa: BLE001
+                    pass
+    if group is not None:
         _STATE.update(group=group, device=device, backend="nccl")
         return "nccl"
-    if group is not None and ok:
-        try:
-            dist.destroy_process_group(group)
-        except Exception:  # noqa: BLE001
-            pass
     if not allow_gloo:
         msg = (f"rank {rank}: RCCL is not usable on every rank"
                + (f" (this rank: {why})" if why else " (it failed on another rank)")

@@ -154,3 +154,30 @@ def test_sharded_batch_two_processes_share_gpu():
             assert np.array_equal(got, q_ref), (dtype, kind)
             for r in range(2):
                 assert np.array_equal(out[r][2][(dtype, kind)][1].view(np.uint32), s32_ref.view(np.uint32)), (dtype, kind, r)
+
+
+def _rccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from efficient_llm_inference_amd import sharding
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    backend = sharding.init_distributed(0, 1, dev)  # no allow_gloo: RCCL must really come up
+    t = torch.full((4,), 3.0, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=sharding._STATE["group"])
+    sharding.barrier()
+    q.put((backend, sharding.backend(), t.cpu().tolist()))
+    sharding.shutdown()
+
+
+@pytest.mark.gpu
+def test_rccl_group_comes_up_on_one_rank():
+    """The RCCL branch of sharding.init_distributed on the real stack (one rank is all a 1-GPU box offers):
+    gloo control group + an RCCL group bound to the device, a reduction through it, barrier, shutdown."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    backend, reported, vals = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and backend == reported == "nccl" and vals == [3.0] * 4
