@@ -640,21 +640,26 @@ def run_dequant(args, rank, world, dev, backend):
     bytes_v = n_elts * BYTES_PER_ELT[vk]
     step_bytes = bytes_k + bytes_v
 
+    from efficient_llm_inference_amd import _lib as _l
+
     def step(i, evs=None):
         ko, vo = outs[i & 1]
         c = caches[i % len(caches)]
         c._k.dequant(torch.float16, out=ko)  # all layers of K: one launch
         if evs is not None:
-            evs[0].record()
-        c._v.dequant(torch.float16, out=vo)  # all layers of V: one launch (the roofline kernel, bracketed by events)
-        if evs is not None:
-            evs[1].record()
+            _l.time_next_launch(evs[0], evs[1])  # the INT4 launch's own start / stop timestamps
+        c._v.dequant(torch.float16, out=vo)  # all layers of V: one launch (the roofline kernel)
 
     for i in range(args.warmup):
         step(i)
-    # Two events per step, around the INT4 launch only: an event record is a barrier packet on the queue (several
-    # microseconds), so bracketing every launch would slow the very step whose wall time is `value`.
+    # Two HIP events per step, bound to the INT4 launch itself (kvq_time_next_launch -> hipExtLaunchKernelGGL): they
+    # carry the dispatch's start / stop timestamps — what rocprofv3's kernel trace reports — and put no barrier
+    # packets on the queue (hipEventRecord around the launch costs several microseconds of the very step whose wall
+    # time is `value`, and includes the queue gap in the interval).
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps)]
+    for e in events:  # torch creates the underlying event at its first record()
+        e[0].record()
+        e[1].record()
     torch.cuda.synchronize()
     sharding.barrier()
     torch.cuda.synchronize()
@@ -723,7 +728,7 @@ def run_dequant(args, rank, world, dev, backend):
                 "algorithmic_bytes_per_launch": int(target_bytes),
                 "avg_launch_ms": round(target_ms, 4), "median_launch_ms": round(v_each[len(v_each) // 2], 4),
                 "min_launch_ms": round(v_each[0], 4), "max_launch_ms": round(v_each[-1], 4),
-                "timer": "HIP events on the launch stream around every INT4 launch of the timed region",
+                "timer": "HIP events bound to every INT4 launch of the timed region (hipExtLaunchKernelGGL start / stop timestamps)",
             },
             "roofline_k": {
                 "kernel": f"dequant_tokens_fast_k<{kk}>", "bound": "hbm",

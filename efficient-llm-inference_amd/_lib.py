@@ -44,6 +44,7 @@ EXPORTS = (
     "kvq_decode_step",
     "kvq_decode_step_dev",
     "kvq_decode_step_layers",
+    "kvq_time_next_launch",
     "kvq_set_tunable",
     "kvq_get_tunable",
 )
@@ -127,6 +128,8 @@ def _declare(lib):
                                            c_float, P, c_int64, AD, P]
     lib.kvq_chunk_summary_len.restype = c_int64
     lib.kvq_chunk_summary_len.argtypes = [c_int64, c_int64, c_int64]
+    lib.kvq_time_next_launch.restype = c_int
+    lib.kvq_time_next_launch.argtypes = [P, P]
     lib.kvq_set_tunable.restype = c_int
     lib.kvq_set_tunable.argtypes = [c_char_p, c_int64]
     lib.kvq_get_tunable.restype = c_int64
@@ -187,6 +190,12 @@ def dims5(G, B, H, T, D) -> KvqDims:
 def ptr_array(ptrs):
     arr = (c_void_p * len(ptrs))(*ptrs)
     return arr
+
+
+def time_next_launch(start: "torch.cuda.Event", stop: "torch.cuda.Event") -> None:
+    """The next token-table dequantise launch records its own start / stop timestamps into these two events
+    (kvq_time_next_launch). Both must have been recorded once before (torch creates the HIP event lazily)."""
+    check(load().kvq_time_next_launch(c_void_p(start.cuda_event), c_void_p(stop.cuda_event)), "time_next_launch")
 
 
 def set_tunable(key: str, value: int) -> None:

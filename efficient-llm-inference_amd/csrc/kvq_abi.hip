@@ -26,6 +26,13 @@ int check_launch(const char* what) {
   return 0;
 }
 
+static thread_local TimingEvents g_timing = {nullptr, nullptr};
+TimingEvents take_timing_events() {
+  const TimingEvents e = g_timing;
+  g_timing = TimingEvents{nullptr, nullptr};
+  return e;
+}
+
 Tunables& tunables() {
   static Tunables t = [] {
     Tunables d = {};  // every knob 0 unless named here
@@ -86,6 +93,11 @@ extern "C" {
 int kvq_version(void) { return KVQ_VERSION; }
 
 const char* kvq_last_error_string(void) { return kvq::g_err; }
+
+int kvq_time_next_launch(void* start_event, void* stop_event) {
+  kvq::g_timing = kvq::TimingEvents{reinterpret_cast<hipEvent_t>(start_event), reinterpret_cast<hipEvent_t>(stop_event)};
+  return 0;
+}
 
 int kvq_set_tunable(const char* key, int64_t value) {
   if (!key) return KVQ_E_NULL;

@@ -33,6 +33,14 @@ struct PtrTable {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// kvq_time_next_launch: HIP events the NEXT token-table dequantise launch of the calling thread binds to its own
+// dispatch (hipExtLaunchKernelGGL start / stop timestamps): the kernel's duration without queue gaps. Taken (and
+// cleared) by the launch; {nullptr, nullptr} = plain launch.
+struct TimingEvents {
+  hipEvent_t start, stop;
+};
+TimingEvents take_timing_events();
+
 struct Tunables {
   int64_t dequant_variant;       // -1 = shipped default
   int64_t dequant_grid;          // 0 = one chunk per workgroup

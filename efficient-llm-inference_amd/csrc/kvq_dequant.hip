@@ -11,6 +11,8 @@
 // q = int8, or (nibble - 8) where the EVEN element of a byte pair is the HIGH nibble
 // (ops.py:61-63, extensions.py:61). The product is formed as (float)(int) * s — not as an
 // fma against -8*s — so that the sign of a zero result matches (q<0, stored fp16 scale 0).
+#include <hip/hip_ext.h>
+
 #include "kvq_common.h"
 
 namespace kvq {
@@ -263,7 +265,12 @@ constexpr int kDefaultVariantI8 = 23;
 
 template <int ODT, int BITS, int LE, int UNROLL, bool NT, bool LDS_SC, bool NTL = false, int BLK = kBlock>
 static void launch_fast(const DequantArgs& a, unsigned grid, hipStream_t st) {
-  hipLaunchKernelGGL((dequant_tokens_fast_k<ODT, BITS, LE, UNROLL, NT, LDS_SC, NTL, BLK>), dim3(grid), dim3(BLK), 0, st, a);
+  const TimingEvents ev = take_timing_events();
+  if (ev.start || ev.stop)  // kvq_time_next_launch: the dispatch's own start / stop timestamps
+    hipExtLaunchKernelGGL((dequant_tokens_fast_k<ODT, BITS, LE, UNROLL, NT, LDS_SC, NTL, BLK>), dim3(grid), dim3(BLK), 0, st, ev.start,
+                          ev.stop, 0, a);
+  else
+    hipLaunchKernelGGL((dequant_tokens_fast_k<ODT, BITS, LE, UNROLL, NT, LDS_SC, NTL, BLK>), dim3(grid), dim3(BLK), 0, st, a);
 }
 
 template <int ODT, int BITS>

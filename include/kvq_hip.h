@@ -260,6 +260,12 @@ int kvq_decode_step_layers(int64_t n_layers, int append, const void* const* q, i
                            float eps, float* workspace, int64_t workspace_floats, const kvq_attn_dims_t* dims,
                            void* stream);
 
+/* Measurement aid: the NEXT kvq_dequant_i8_tokens / kvq_dequant_i4_tokens call of the calling thread that takes the
+ * vectorised kernel binds these two hipEvent_t (already created; either may be NULL) to its own dispatch
+ * (hipExtLaunchKernelGGL): stop - start is then the kernel's duration as a profiler sees it, without the queue gaps
+ * that two hipEventRecord calls around the launch include. One-shot: cleared by that launch. */
+int kvq_time_next_launch(void* start_event, void* stop_event);
+
 /* ---- tuning knobs (benchmarks only; defaults are what ships) ----------------------------- */
 
 /* key: "dequant_variant" (0..30, -1 = shipped default), "dequant_grid" (workgroups, 0 = one chunk
