@@ -23,6 +23,9 @@ LLAMA_ARCH = {  # grouped-query Llama-family shapes (random init): the grouping 
                        num_key_value_heads=2, head_dim=128, vocab_size=260, max_position_embeddings=4096),
     "llama-8b-4layers": dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=4, num_attention_heads=32,
                              num_key_value_heads=8, head_dim=128, vocab_size=260, max_position_embeddings=32768),
+    # the whole Llama-3-8B architecture (16 GB of random fp16 weights; vocabulary as published, byte tokens used)
+    "llama-8b": dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32,
+                     num_key_value_heads=8, head_dim=128, vocab_size=128256, max_position_embeddings=32768),
 }
 
 
@@ -80,7 +83,16 @@ def load_model(name_or_path: str = "gpt2", device: str = "cuda", dtype: torch.dt
         a = LLAMA_ARCH[name_or_path]
         torch.manual_seed(seed)
         cfg = LlamaConfig(bos_token_id=0, eos_token_id=256, pad_token_id=None, tie_word_embeddings=False, **a)
-        model = LlamaForCausalLM(cfg).to(device=device, dtype=dtype).eval()
+        if a["num_hidden_layers"] * a["hidden_size"] > 32 * 1024:  # full-size: initialise on the device, in `dtype`
+            prev = torch.get_default_dtype()
+            torch.set_default_dtype(dtype)
+            try:
+                with torch.device(device):
+                    model = LlamaForCausalLM(cfg).eval()
+            finally:
+                torch.set_default_dtype(prev)
+        else:
+            model = LlamaForCausalLM(cfg).to(device=device, dtype=dtype).eval()
         return model, RepeatTokenizer(vocab_size=a["vocab_size"])
     if name_or_path not in ARCH:
         raise ValueError(f"unknown architecture '{name_or_path}' (known: {sorted(list(ARCH) + list(LLAMA_ARCH))}); "

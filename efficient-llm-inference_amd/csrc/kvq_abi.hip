@@ -44,6 +44,7 @@ Tunables& tunables() {
     d.attn_mfma_tc = 128;
     d.nt_loads = 1;
     d.attn_k_i8 = -1;
+    d.attn_merge_fast = 1;
     return d;
   }();
   return t;
@@ -74,6 +75,7 @@ static const TunableKey kTunableKeys[] = {
     {"attn_mfma_tc", &Tunables::attn_mfma_tc},
     {"attn_fused", &Tunables::attn_fused},
     {"attn_k_i8", &Tunables::attn_k_i8},
+    {"attn_merge_fast", &Tunables::attn_merge_fast},
     {"attn_stream_tpw", &Tunables::attn_stream_tpw},
     {"attn_stream_slots", &Tunables::attn_stream_slots},
     {"attn_stream_tc", &Tunables::attn_stream_tc},

@@ -563,6 +563,8 @@ struct AttnTile {
   };
   // mixed mode (INT8 K, INT4 V): every later step fits the registers the K rows free (3 waves per SIMD
   // either way); the other kind pairs keep one step of look-ahead
+  // (requesting EVERY V row up front, behind the K rows, measured slower at batch 1 — 10.3 vs 9.7 us per launch:
+  // the V requests queue in front of other waves' K rows, which the score product waits for)
   constexpr bool V_EARLY = KBITS == 8 && VBITS == 4;
   VRaw vr[V_EARLY ? NS : 2][8];
 
@@ -1565,6 +1567,126 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_k(const AttnArgs
   }
 }
 
+// ---------------------------------------------------------------------------- merge, one round trip
+// The merge above is a chain of dependent round trips (new-token dot -> (m, l) -> (m, l) again -> rows in two
+// batches -> new-token V): at batch 1 nothing hides them and a call costs 5 us for 2 MB (9 us inside a decode
+// step, where every operand was written by the kernel before and is cold in this XCD's L2). This variant, for up
+// to kAttnBlock splits, REQUESTS everything the workgroup reads before it waits for anything — the device-side
+// token count, its (m, l) pair, the new token's q / k / v elements and the first kMergePF partial rows of each
+// thread (rows past the live splits are read too: the workspace holds them, their values are never used) — and
+// synchronises its waves with LDS-only barriers (`__syncthreads()` would drain the outstanding global loads).
+// Same arithmetic in the same order as decode_attn_merge_k: bit-identical results.
+constexpr int kMergePF = 16;
+__device__ __forceinline__ void lds_barrier() {  // this workgroup's LDS traffic only; global loads stay in flight
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// (has_new: without a new token the host points kn / vn at the query, so that the three loads need no branch)
+__global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_fast_k(const AttnArgs a, const NewTokenArgs nt, const int fuse_quant,
+                                                                       const int has_new_i) {
+  __shared__ float s_red[3][kAttnBlock / kWave];
+  if (blockIdx.x >= a.Hq) {
+    if (fuse_quant && blockIdx.y == 0u) {
+      NewTokenArgs slot = nt;
+      if (a.t_dev) {
+        const int64_t T = (int64_t)live_tokens(a);
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          slot.q[w] += T * nt.qs_t[w];
+          slot.scale[w] += T;
+        }
+      }
+      if (a.dtype == KVQ_F16) quant_new_token_block<KVQ_F16>(slot, blockIdx.x - a.Hq, s_red[0]);
+      else quant_new_token_block<KVQ_BF16>(slot, blockIdx.x - a.Hq, s_red[0]);
+    }
+    return;
+  }
+  __shared__ float s_wt[kAttnBlock];
+  __shared__ __attribute__((aligned(16))) float s_out[kAttnBlock * 4];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const uint32_t tid = threadIdx.x;
+  const uint32_t hq = blockIdx.x, b = blockIdx.y;
+  const uint32_t hk = hq / a.nq;
+  const bool has_new = has_new_i != 0;
+  const uint32_t wave = tid >> 6, lane = tid & 63u;
+  const uint32_t nb = a.nsplit;  // 1 ... kAttnBlock (host); the row stride of the partials
+  const uint32_t dv = a.D >> 2;
+  const uint32_t groups = kAttnBlock / dv;  // 32, 16, 8 or 4
+  const uint32_t g = tid / dv, d4 = tid - g * dv;
+  const float* ml = a.ws + ((int64_t)b * a.Hq + hq) * nb * 2;
+  const f32x4* src = reinterpret_cast<const f32x4*>(a.ws + a.acc_off + ((int64_t)b * a.Hq + hq) * nb * a.D) + d4;
+
+  // ---- requests: straight-line code (clamped indices, selected addresses), nothing waits before the fence -------
+  uint32_t t_raw;  // the device-side token count: a scalar load the compiler does not know about (waited for below)
+  {
+    const int* tp = a.t_dev ? a.t_dev : reinterpret_cast<const int*>(a.ws);
+    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(t_raw) : "s"(tp));
+  }
+  const f32x2 ml_raw = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(ml) + (tid < nb ? tid : nb - 1u));
+  const uint32_t di = tid < a.D ? tid : a.D - 1u;
+  const uint16_t qb_raw = reinterpret_cast<const uint16_t*>(a.q)[(int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + di];
+  const uint16_t kb = reinterpret_cast<const uint16_t*>(a.kn)[(int64_t)b * a.kn_sb + (int64_t)hk * a.kn_sh + di];
+  const uint16_t vb = reinterpret_cast<const uint16_t*>(a.vn)[(int64_t)b * a.vn_sb + (int64_t)hk * a.vn_sh + di];
+  f32x4 x[kMergePF];
+#pragma unroll
+  for (int u = 0; u < kMergePF; ++u) {
+    const uint32_t s = g + (uint32_t)u * groups;
+    x[u] = __builtin_nontemporal_load(src + (int64_t)(s < nb ? s : nb - 1u) * dv);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t_raw));
+  const uint32_t T = a.t_dev ? (t_raw < a.T ? t_raw : a.T) : a.T;
+  const uint16_t qb = (has_new && tid < a.D) ? qb_raw : (uint16_t)0;  // the dot product runs over d < D
+  f32x2 mlv = ml_raw;
+
+  // ---- weights ---------------------------------------------------------------------------------------------
+  uint32_t ns = a.t_dev ? (T + a.TS - 1u) / a.TS : nb;
+  ns = ns < nb ? ns : nb;
+  if (tid >= ns) mlv = f32x2{-INFINITY, 0.0f};
+  auto widen = [&](uint16_t h) { return a.dtype == KVQ_F16 ? Elem<KVQ_F16>::widen(h) : Elem<KVQ_BF16>::widen(h); };
+  {
+    const float part = wave_fsum(widen(qb) * widen(kb));  // zero beyond D and without a new token
+    const float mw = wave_fmax(mlv[0]);
+    if (lane == 0u) {
+      s_red[0][wave] = part;
+      s_red[1][wave] = mw;
+    }
+  }
+  lds_barrier();
+  const float s_tok = has_new ? ((s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3])) * a.sm_scale : -INFINITY;
+  const float M = fmaxf(fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3])), s_tok);
+  {
+    const float w = tid < ns ? __expf(mlv[0] - M) : 0.0f;
+    s_wt[tid] = w;
+    const float lw = wave_fsum(tid < ns ? mlv[1] * w : 0.0f);
+    if (lane == 0u) s_red[2][wave] = lw;
+  }
+  lds_barrier();  // also publishes s_wt
+  const float w_new = has_new ? __expf(s_tok - M) : 0.0f;
+  const float L = ((s_red[2][0] + s_red[2][1]) + (s_red[2][2] + s_red[2][3])) + w_new;
+  const float inv = 1.0f / L;
+
+  // ---- weighted sum: thread = (split group g, 4 elements at d4) ---------------------------------------------
+  f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int u = 0; u < kMergePF; ++u) {
+    const uint32_t s = g + (uint32_t)u * groups;
+    if (s < ns) o += x[u] * s_wt[s];
+  }
+  for (uint32_t s = g + (uint32_t)kMergePF * groups; s < ns; s += groups) o += src[(int64_t)s * dv] * s_wt[s];
+  *reinterpret_cast<f32x4*>(&s_out[tid * 4]) = o;  // [g][d]
+  lds_barrier();
+  if (tid < a.D) {
+    float t = 0.0f;
+    for (uint32_t k = 0; k < groups; ++k) t += s_out[k * a.D + tid];
+    if (has_new) t = fmaf(w_new, widen(vb), t);
+    t *= inv;
+    const int64_t oi = (int64_t)b * a.o_sb + (int64_t)hq * a.o_sh + tid;
+    if (a.dtype == KVQ_F16) reinterpret_cast<f16*>(a.out)[oi] = (f16)t;
+    else reinterpret_cast<__bf16*>(a.out)[oi] = (__bf16)t;
+  }
+}
+
 // tokens per workgroup: one loop iteration (D/16 lanes per token, kAttnUnroll tokens per lane) while
 // the grid stays below ~4096 workgroups, whole multiples of it beyond; never more than
 // kAttnMaxSplit splits
@@ -1858,8 +1980,19 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
     if (rc) return rc;
   }
   NewTokenArgs none = {};
-  hipLaunchKernelGGL(decode_attn_merge_k, dim3(a.Hq + (nt ? 2u : 0u), a.B), dim3(kAttnBlock), 0, st, a, nt ? *nt : none,
-                     nt ? 1 : 0);
+  if (a.nsplit >= 1u && a.nsplit <= (uint32_t)kAttnBlock && a.D <= (uint32_t)kAttnBlock && tunables().attn_merge_fast)
+  {
+    AttnArgs af = a;
+    if (!a.kn) {  // no new token: valid addresses for the kernel's unconditional loads (values unused)
+      af.kn = af.vn = a.q;
+      af.kn_sb = af.vn_sb = a.q_sb;
+      af.kn_sh = af.vn_sh = 0;
+    }
+    hipLaunchKernelGGL(decode_attn_merge_fast_k, dim3(a.Hq + (nt ? 2u : 0u), a.B), dim3(kAttnBlock), 0, st, af, nt ? *nt : none,
+                       nt ? 1 : 0, a.kn ? 1 : 0);
+  } else
+    hipLaunchKernelGGL(decode_attn_merge_k, dim3(a.Hq + (nt ? 2u : 0u), a.B), dim3(kAttnBlock), 0, st, a, nt ? *nt : none,
+                       nt ? 1 : 0);
   return check_launch(name);
 }
 
@@ -1874,9 +2007,13 @@ int64_t kvq_decode_attn_workspace_cap(const kvq_attn_dims_t* d) {
   uint32_t ts, ns, ns_max = 1;
   if (!plan(&t, &ts, &ns)) return -1;
   ns_max = ns > ns_max ? ns : ns_max;
+  // kvq_decode_step_dev (device-side token count) always takes the one-tile plan, which can split finer than the
+  // streaming plan a large batch gets: the capacity covers both
+  if (plan_onetile(&t, &ts, &ns) && ns > ns_max) ns_max = ns;
   for (int64_t tt = 32; tt < d->T; tt += 32) {  // + 1 below covers a change of split size between two probes
     t.T = tt;
     if (plan(&t, &ts, &ns) && ns > ns_max) ns_max = ns;
+    if (plan_onetile(&t, &ts, &ns) && ns > ns_max) ns_max = ns;
   }
   const int64_t rows = d->B * d->Hq * (int64_t)(ns_max + 1);
   const int64_t legacy = (rows * 2 + 3) / 4 * 4 + rows * d->D;

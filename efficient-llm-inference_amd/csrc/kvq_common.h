@@ -2,6 +2,7 @@
 // CDNA4 only: wave64, 16-byte vector memory ops, no portability layer.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/kvq_hip.h"
@@ -40,6 +41,11 @@ struct TimingEvents {
   hipEvent_t start, stop;
 };
 TimingEvents take_timing_events();
+template <typename Kern, typename... Args>
+inline void launch_with_events(Kern kernel, dim3 grid, dim3 block, hipStream_t st, const TimingEvents& ev, Args... args) {
+  if (ev.start || ev.stop) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, ev.start, ev.stop, 0, args...);
+  else hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
+}
 
 struct Tunables {
   int64_t dequant_variant;       // -1 = shipped default
@@ -61,6 +67,7 @@ struct Tunables {
   int64_t attn_stream_tpw;       // streaming MFMA kernel: 64-token tiles per wave; 0 = by size (only when tiles exceed wave slots), -1 = never
   int64_t attn_stream_tc;        // tokens per tile of the streaming kernel: 64 (default) or 32
   int64_t attn_stream_slots;     // wave slots the streaming plan fills in one round (default 3072 = 3 per SIMD)
+  int64_t attn_merge_fast;       // 1 (default) = merge kernel that requests everything up front (<= 256 splits); 0 = the chained one
   int64_t attn_k_i8;             // INT8 keys at head_dim 128: stored bytes straight into v_mfma_i32_16x16x64_i8 (query as two int8 planes): -1 = streaming kernel only (default), 0 = never, 1 = always
   int64_t attn_fused;            // 1 = decode attention as ONE launch (decode_attn_fused_mfma_k) where it applies; default 0: partial + merge measured faster
   int64_t attn_fused_tc;         // fused launch, head_dim 128: tokens per wave 128 | 64 | 32 (with attn_fused_nw 4 or 8 | 8 | 16); 0 = by batch size

@@ -11,8 +11,6 @@
 // q = int8, or (nibble - 8) where the EVEN element of a byte pair is the HIGH nibble
 // (ops.py:61-63, extensions.py:61). The product is formed as (float)(int) * s — not as an
 // fma against -8*s — so that the sign of a zero result matches (q<0, stored fp16 scale 0).
-#include <hip/hip_ext.h>
-
 #include "kvq_common.h"
 
 namespace kvq {
@@ -264,49 +262,44 @@ constexpr int kDefaultVariantI4 = 21;
 constexpr int kDefaultVariantI8 = 23;
 
 template <int ODT, int BITS, int LE, int UNROLL, bool NT, bool LDS_SC, bool NTL = false, int BLK = kBlock>
-static void launch_fast(const DequantArgs& a, unsigned grid, hipStream_t st) {
-  const TimingEvents ev = take_timing_events();
-  if (ev.start || ev.stop)  // kvq_time_next_launch: the dispatch's own start / stop timestamps
-    hipExtLaunchKernelGGL((dequant_tokens_fast_k<ODT, BITS, LE, UNROLL, NT, LDS_SC, NTL, BLK>), dim3(grid), dim3(BLK), 0, st, ev.start,
-                          ev.stop, 0, a);
-  else
-    hipLaunchKernelGGL((dequant_tokens_fast_k<ODT, BITS, LE, UNROLL, NT, LDS_SC, NTL, BLK>), dim3(grid), dim3(BLK), 0, st, a);
+static void launch_fast(const DequantArgs& a, unsigned grid, hipStream_t st, const TimingEvents& ev) {
+  launch_with_events((dequant_tokens_fast_k<ODT, BITS, LE, UNROLL, NT, LDS_SC, NTL, BLK>), dim3(grid), dim3(BLK), st, ev, a);
 }
 
 template <int ODT, int BITS>
-static bool launch_fast_variant(int v, const DequantArgs& a, unsigned grid, hipStream_t st) {
+static bool launch_fast_variant(int v, const DequantArgs& a, unsigned grid, hipStream_t st, const TimingEvents& ev) {
   switch (v) {
-    case 0: launch_fast<ODT, BITS, 8, 4, false, true>(a, grid, st); return true;
-    case 1: launch_fast<ODT, BITS, 8, 4, true, true>(a, grid, st); return true;
-    case 2: launch_fast<ODT, BITS, 16, 2, false, true>(a, grid, st); return true;
-    case 3: launch_fast<ODT, BITS, 16, 2, true, true>(a, grid, st); return true;
-    case 4: launch_fast<ODT, BITS, 32, 1, false, true>(a, grid, st); return true;
-    case 5: launch_fast<ODT, BITS, 32, 1, true, true>(a, grid, st); return true;
-    case 6: launch_fast<ODT, BITS, 8, 8, false, true>(a, grid, st); return true;
-    case 7: launch_fast<ODT, BITS, 8, 4, false, false>(a, grid, st); return true;
-    case 8: launch_fast<ODT, BITS, 8, 2, false, true>(a, grid, st); return true;
-    case 9: launch_fast<ODT, BITS, 8, 8, true, true>(a, grid, st); return true;
-    case 10: launch_fast<ODT, BITS, 16, 4, false, true>(a, grid, st); return true;
-    case 11: launch_fast<ODT, BITS, 32, 2, false, true>(a, grid, st); return true;
-    case 12: launch_fast<ODT, BITS, 8, 2, true, true>(a, grid, st); return true;
-    case 13: launch_fast<ODT, BITS, 8, 1, true, true>(a, grid, st); return true;
-    case 14: launch_fast<ODT, BITS, 8, 4, true, false>(a, grid, st); return true;
-    case 15: launch_fast<ODT, BITS, 8, 1, false, true>(a, grid, st); return true;
-    case 16: launch_fast<ODT, BITS, 8, 4, true, true, true>(a, grid, st); return true;
-    case 17: launch_fast<ODT, BITS, 8, 2, true, true, true>(a, grid, st); return true;
-    case 18: launch_fast<ODT, BITS, 8, 1, true, false>(a, grid, st); return true;
-    case 19: launch_fast<ODT, BITS, 8, 2, true, false>(a, grid, st); return true;
-    case 20: launch_fast<ODT, BITS, 8, 1, true, false, true>(a, grid, st); return true;
-    case 21: launch_fast<ODT, BITS, 8, 4, true, true, false, 64>(a, grid, st); return true;
-    case 22: launch_fast<ODT, BITS, 8, 8, true, true, false, 64>(a, grid, st); return true;
-    case 23: launch_fast<ODT, BITS, 8, 2, true, true, true, 64>(a, grid, st); return true;
-    case 24: launch_fast<ODT, BITS, 8, 4, true, true, true, 64>(a, grid, st); return true;
-    case 25: launch_fast<ODT, BITS, 8, 16, true, true, false, 64>(a, grid, st); return true;
-    case 26: launch_fast<ODT, BITS, 8, 2, true, true, false, 64>(a, grid, st); return true;
-    case 27: launch_fast<ODT, BITS, 8, 1, true, true, false, 64>(a, grid, st); return true;
-    case 28: launch_fast<ODT, BITS, 8, 1, true, true, true, 64>(a, grid, st); return true;
-    case 29: launch_fast<ODT, BITS, 8, 4, true, true, false, 128>(a, grid, st); return true;
-    case 30: launch_fast<ODT, BITS, 8, 2, true, true, true, 128>(a, grid, st); return true;
+    case 0: launch_fast<ODT, BITS, 8, 4, false, true>(a, grid, st, ev); return true;
+    case 1: launch_fast<ODT, BITS, 8, 4, true, true>(a, grid, st, ev); return true;
+    case 2: launch_fast<ODT, BITS, 16, 2, false, true>(a, grid, st, ev); return true;
+    case 3: launch_fast<ODT, BITS, 16, 2, true, true>(a, grid, st, ev); return true;
+    case 4: launch_fast<ODT, BITS, 32, 1, false, true>(a, grid, st, ev); return true;
+    case 5: launch_fast<ODT, BITS, 32, 1, true, true>(a, grid, st, ev); return true;
+    case 6: launch_fast<ODT, BITS, 8, 8, false, true>(a, grid, st, ev); return true;
+    case 7: launch_fast<ODT, BITS, 8, 4, false, false>(a, grid, st, ev); return true;
+    case 8: launch_fast<ODT, BITS, 8, 2, false, true>(a, grid, st, ev); return true;
+    case 9: launch_fast<ODT, BITS, 8, 8, true, true>(a, grid, st, ev); return true;
+    case 10: launch_fast<ODT, BITS, 16, 4, false, true>(a, grid, st, ev); return true;
+    case 11: launch_fast<ODT, BITS, 32, 2, false, true>(a, grid, st, ev); return true;
+    case 12: launch_fast<ODT, BITS, 8, 2, true, true>(a, grid, st, ev); return true;
+    case 13: launch_fast<ODT, BITS, 8, 1, true, true>(a, grid, st, ev); return true;
+    case 14: launch_fast<ODT, BITS, 8, 4, true, false>(a, grid, st, ev); return true;
+    case 15: launch_fast<ODT, BITS, 8, 1, false, true>(a, grid, st, ev); return true;
+    case 16: launch_fast<ODT, BITS, 8, 4, true, true, true>(a, grid, st, ev); return true;
+    case 17: launch_fast<ODT, BITS, 8, 2, true, true, true>(a, grid, st, ev); return true;
+    case 18: launch_fast<ODT, BITS, 8, 1, true, false>(a, grid, st, ev); return true;
+    case 19: launch_fast<ODT, BITS, 8, 2, true, false>(a, grid, st, ev); return true;
+    case 20: launch_fast<ODT, BITS, 8, 1, true, false, true>(a, grid, st, ev); return true;
+    case 21: launch_fast<ODT, BITS, 8, 4, true, true, false, 64>(a, grid, st, ev); return true;
+    case 22: launch_fast<ODT, BITS, 8, 8, true, true, false, 64>(a, grid, st, ev); return true;
+    case 23: launch_fast<ODT, BITS, 8, 2, true, true, true, 64>(a, grid, st, ev); return true;
+    case 24: launch_fast<ODT, BITS, 8, 4, true, true, true, 64>(a, grid, st, ev); return true;
+    case 25: launch_fast<ODT, BITS, 8, 16, true, true, false, 64>(a, grid, st, ev); return true;
+    case 26: launch_fast<ODT, BITS, 8, 2, true, true, false, 64>(a, grid, st, ev); return true;
+    case 27: launch_fast<ODT, BITS, 8, 1, true, true, false, 64>(a, grid, st, ev); return true;
+    case 28: launch_fast<ODT, BITS, 8, 1, true, true, true, 64>(a, grid, st, ev); return true;
+    case 29: launch_fast<ODT, BITS, 8, 4, true, true, false, 128>(a, grid, st, ev); return true;
+    case 30: launch_fast<ODT, BITS, 8, 2, true, true, true, 128>(a, grid, st, ev); return true;
   }
   return false;
 }
@@ -315,6 +308,9 @@ template <int BITS>
 static int dequant_tokens(const uint8_t* q, const kvq_strides_t* q_st, const float* scales, int64_t ssg,
                           void* out, const kvq_strides_t* out_st, int out_dtype, const kvq_dims_t* d,
                           void* stream, const char* name) {
+  // kvq_time_next_launch is one-shot: whatever this call does (either kernel, an empty table, an error), the
+  // pending events are taken here and never reach a later launch
+  const TimingEvents ev = take_timing_events();
   if (!q || !q_st || !scales || !out || !out_st || !d) {
     set_error("%s: NULL argument", name);
     return KVQ_E_NULL;
@@ -373,9 +369,9 @@ static int dequant_tokens(const uint8_t* q, const kvq_strides_t* q_st, const flo
     const unsigned grid = grid_for(a.total_items, cap);
     bool ok = false;
     switch (out_dtype) {
-      case KVQ_F16: ok = launch_fast_variant<KVQ_F16, BITS>(v, a, grid, st); break;
-      case KVQ_BF16: ok = launch_fast_variant<KVQ_BF16, BITS>(v, a, grid, st); break;
-      case KVQ_F32: ok = launch_fast_variant<KVQ_F32, BITS>(v, a, grid, st); break;
+      case KVQ_F16: ok = launch_fast_variant<KVQ_F16, BITS>(v, a, grid, st, ev); break;
+      case KVQ_BF16: ok = launch_fast_variant<KVQ_BF16, BITS>(v, a, grid, st, ev); break;
+      case KVQ_F32: ok = launch_fast_variant<KVQ_F32, BITS>(v, a, grid, st, ev); break;
     }
     if (!ok) {
       set_error("%s: no such variant %d", name, v);
@@ -396,9 +392,9 @@ static int dequant_tokens(const uint8_t* q, const kvq_strides_t* q_st, const flo
   a.xcd_group = 0;
   const unsigned grid = grid_for((total + kBlock - 1) / kBlock, 256 * 32);
   switch (out_dtype) {
-    case KVQ_F16: hipLaunchKernelGGL((dequant_tokens_generic_k<KVQ_F16, BITS>), dim3(grid), dim3(kBlock), 0, st, a, total); break;
-    case KVQ_BF16: hipLaunchKernelGGL((dequant_tokens_generic_k<KVQ_BF16, BITS>), dim3(grid), dim3(kBlock), 0, st, a, total); break;
-    case KVQ_F32: hipLaunchKernelGGL((dequant_tokens_generic_k<KVQ_F32, BITS>), dim3(grid), dim3(kBlock), 0, st, a, total); break;
+    case KVQ_F16: launch_with_events((dequant_tokens_generic_k<KVQ_F16, BITS>), dim3(grid), dim3(kBlock), st, ev, a, total); break;
+    case KVQ_BF16: launch_with_events((dequant_tokens_generic_k<KVQ_BF16, BITS>), dim3(grid), dim3(kBlock), st, ev, a, total); break;
+    case KVQ_F32: launch_with_events((dequant_tokens_generic_k<KVQ_F32, BITS>), dim3(grid), dim3(kBlock), st, ev, a, total); break;
   }
   return check_launch(name);
 }

@@ -155,9 +155,10 @@ def dequant_tokens(q: torch.Tensor, scales: torch.Tensor, out: torch.Tensor, kin
         raise _lib.KvqError(f"kvq: q must be {(G, B, H, T, Dq)} {QDTYPE[kind]}, got {tuple(q.shape)} {q.dtype}")
     if tuple(scales.shape) != (G, T) or scales.dtype != torch.float32 or (T > 1 and scales.stride(1) != 1):
         raise _lib.KvqError(f"kvq: scales must be fp32 {(G, T)} with unit token stride")
-    if G * B * H * T * D == 0:
-        return
     lib = _lib.load()
+    if G * B * H * T * D == 0:
+        lib.kvq_time_next_launch(None, None)  # one-shot: an empty table takes pending timing events with it
+        return
     fn = lib.kvq_dequant_i8_tokens if bits == 8 else lib.kvq_dequant_i4_tokens
     rc = fn(c_void_p(q.data_ptr()), byref(strides4(q)), c_void_p(scales.data_ptr()), scales.stride(0),
             c_void_p(out.data_ptr()), byref(strides4(out)), dtype_code(out.dtype),

@@ -260,16 +260,31 @@ int kvq_decode_step_layers(int64_t n_layers, int append, const void* const* q, i
                            float eps, float* workspace, int64_t workspace_floats, const kvq_attn_dims_t* dims,
                            void* stream);
 
-/* Measurement aid: the NEXT kvq_dequant_i8_tokens / kvq_dequant_i4_tokens call of the calling thread that takes the
- * vectorised kernel binds these two hipEvent_t (already created; either may be NULL) to its own dispatch
- * (hipExtLaunchKernelGGL): stop - start is then the kernel's duration as a profiler sees it, without the queue gaps
- * that two hipEventRecord calls around the launch include. One-shot: cleared by that launch. */
+/* Measurement aid: the NEXT kvq_dequant_i8_tokens / kvq_dequant_i4_tokens call of the calling thread binds these
+ * two hipEvent_t (already created; either may be NULL) to its kernel's own dispatch (hipExtLaunchKernelGGL):
+ * stop - start is then the kernel's duration as a profiler sees it, without the queue gaps that two hipEventRecord
+ * calls around the launch include. One-shot: that call takes them whatever it does (either kernel, an empty table,
+ * an error return), so they never reach a later launch. */
 int kvq_time_next_launch(void* start_event, void* stop_event);
 
 /* ---- tuning knobs (benchmarks only; defaults are what ships) ----------------------------- */
 
-/* key: "dequant_variant" (0..30, -1 = shipped default), "dequant_grid" (workgroups, 0 = one chunk
- * each), "quant_force_two_pass" (0/1), "quant_direct_stores" (0/1), "pool_grid" (workgroup cap, 0 = none), "nt_loads" (0/1), "quant_block" (64|128|256), "quant_nv" (8|4|16), "quant_lds_pad" (bytes of unused dynamic LDS, occupancy A-B), "quant_tpw" (tiles per wave of the pipelined one-wave quantise kernel: 0 = one tile per wave, 2 | 4 | 8), "quant_no_regmax" (0/1), "pool_block" (64|128|256), "attn_force_valu" (0/1), "attn_mfma_min_nq" (default 3), "attn_mfma_tc" (128|64), "attn_fused" (0/1: decode attention as one launch where it applies; default 0 = partial + merge launches, measured faster), "attn_fused_tc" / "attn_fused_nw" (tokens per wave / waves per workgroup of the fused launch: 128/4, 128/8, 64/8 or 32/16; 0 = by batch size).
+/* Keys (every one changes speed only, never results, except where noted):
+ *   dequantise  "dequant_variant" (0..30, -1 = shipped default), "dequant_grid" (workgroups, 0 = one chunk each),
+ *               "dequant_xcd_group" (consecutive chunks per XCD, 0 = round robin), "nt_loads" (0/1)
+ *   quantise    "quant_force_two_pass" (0/1), "quant_direct_stores" (0/1), "quant_block" (64|128|256),
+ *               "quant_nv" (8|4|16), "quant_lds_pad" (bytes of unused dynamic LDS: occupancy A-B),
+ *               "quant_tpw" (tiles per wave of the pipelined one-wave kernel: 0 = one tile, 2|4|8),
+ *               "quant_no_regmax" (0/1), "quant_xcd_group" (consecutive tiles per XCD, 0 = round robin)
+ *   eviction    "pool_grid" (workgroup cap, 0 = none), "pool_block" (64|128|256)
+ *   attention   "attn_force_valu" (0/1), "attn_mfma_min_nq" (default 3), "attn_mfma_tc" (128|64),
+ *               "attn_merge_fast" (1 = merge kernel that requests all operands up front, default; 0 = chained merge;
+ *               equal output bits), "attn_stream_tpw" (tiles per wave of the streaming kernel: -1 never, 0 by size,
+ *               > 0 that many), "attn_stream_tc" (64|32), "attn_stream_slots" (wave slots one round fills),
+ *               "attn_k_i8" (INT8 keys through the int8 MFMA: -1 streaming kernel only, 0 never, 1 always;
+ *               tolerance-level difference), "attn_fused" (0/1: one launch per call where it applies; default 0 =
+ *               partial + merge launches, measured faster), "attn_fused_tc" / "attn_fused_nw" (tokens per wave /
+ *               waves per workgroup of the fused launch: 128/4, 128/8, 64/8, 32/16; 0 = by batch size).
  * Returns 0, or KVQ_E_DIMS for an unknown key. Process-global. */
 int kvq_set_tunable(const char* key, int64_t value);
 int64_t kvq_get_tunable(const char* key);

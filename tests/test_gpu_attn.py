@@ -528,3 +528,50 @@ def test_decode_attn_int8_keys_through_int8_mfma(K, tunable, stream):
         _run_case(K, *case, "int8", "int4", "f16", False)
     _run_case(K, 1, 8, 2, 900, 128, "int8", "int8", "f16", True, q_scale=8.0)
     _run_case(K, 1, 8, 2, 900, 128, "int8", "int4", "f16", True, q_scale=1e-3)
+
+
+@pytest.mark.parametrize("case", [(1, 32, 8, 16384, 128), (8, 32, 8, 4100, 128), (1, 12, 12, 300, 64), (1, 4, 4, 200, 256),
+                                  (2, 6, 2, 130, 32), (3, 4, 2, 1, 64), (1, 32, 8, 32768, 128), (1, 32, 8, 700, 64)])
+def test_merge_one_round_trip_equals_chained_merge(K, tunable, case):
+    """attn_merge_fast (default): the merge kernel that requests all its operands up front computes the same
+    arithmetic in the same order as the chained one — equal output BITS, with and without a new token, fp16 and
+    bf16, and with a device-side token count whose dead splits hold NaN in the workspace."""
+    B, Hq, Hkv, T, D = case
+    g = torch.Generator(device="cuda").manual_seed(T + D)
+    for dtype in (torch.float16, torch.bfloat16):
+        k_store = torch.randint(-127, 128, (B, Hkv, T + 130, D), dtype=torch.int8, device="cuda", generator=g)
+        v_store = torch.randint(0, 256, (B, Hkv, T + 130, D // 2), dtype=torch.uint8, device="cuda", generator=g)
+        k_sc = torch.rand(T + 130, device="cuda", generator=g) * 0.02 + 1e-3
+        v_sc = torch.rand(T + 130, device="cuda", generator=g) * 0.2 + 1e-3
+        q = torch.randn(B, Hq, D, device="cuda", generator=g).to(dtype)
+        kn = torch.randn(B, Hkv, D, device="cuda", generator=g).to(dtype)
+        vn = torch.randn(B, Hkv, D, device="cuda", generator=g).to(dtype)
+        ws = torch.empty(K.decode_attn_workspace_cap(B, Hq, Hkv, T + 130, D), dtype=torch.float32, device="cuda")
+        for with_new in (True, False):
+            outs = []
+            for fast in (1, 0):
+                tunable("attn_merge_fast", fast)
+                out = torch.full((B, Hq, D), float("nan"), dtype=dtype, device="cuda")
+                ws.fill_(float("nan"))
+                K.decode_attn(q, k_store, k_sc, "int8", v_store, v_sc, "int4", T, out, ws, D ** -0.5,
+                              kn if with_new else None, vn if with_new else None)
+                torch.cuda.synchronize()
+                assert torch.isfinite(out.float()).all()
+                outs.append(out)
+            assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), (dtype, with_new)
+        if dtype == torch.float16:  # device-side count below the host's bound: the splits past it are dead
+            t_dev = torch.full((1,), T, dtype=torch.int32, device="cuda")
+            outs = []
+            for fast in (1, 0):
+                tunable("attn_merge_fast", fast)
+                ks, vs = k_store.clone(), v_store.clone()
+                ksc, vsc = k_sc.clone(), v_sc.clone()
+                plan = K.DecodeStepPlan(q, ks, ksc, "int8", vs, vsc, "int4", 1e-8)
+                out = torch.full((B, Hq, D), float("nan"), dtype=dtype, device="cuda")
+                ws.fill_(float("nan"))
+                K.decode_step_dev(plan, q, kn, vn, t_dev, T + 129, out, ws, D ** -0.5)
+                torch.cuda.synchronize()
+                assert torch.isfinite(out.float()).all()
+                outs.append((out, ks, vs, ksc, vsc))
+            for a, b in zip(outs[0], outs[1]):  # output, both stores and both scale tables (slot T written by the step)
+                assert torch.equal(a, b)

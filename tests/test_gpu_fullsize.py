@@ -185,3 +185,18 @@ def test_time_next_launch_binds_events_to_the_dequant_dispatch(K):
     K.dequant_tokens(q, s, out, "int4")
     torch.cuda.synchronize()
     assert ev[0].elapsed_time(ev[1]) == before
+    # the element-wise kernel (head_dim not a multiple of 8) is bound the same way
+    q8 = torch.randint(-127, 128, (2, 1, 4, 4096, 100), dtype=torch.int8, device="cuda", generator=g)
+    s8 = torch.rand(2, 4096, device="cuda", generator=g) * 0.01 + 1e-4
+    o8 = torch.empty(2, 1, 4, 4096, 100, dtype=torch.float16, device="cuda")
+    _lib.time_next_launch(ev[0], ev[1])
+    K.dequant_tokens(q8, s8, o8, "int8")
+    torch.cuda.synchronize()
+    small = ev[0].elapsed_time(ev[1])
+    assert 0.0 < small < before
+    # an empty table takes the pending events with it: the launch after it is a plain one
+    _lib.time_next_launch(ev[0], ev[1])
+    K.dequant_tokens(q8[:, :, :, :0], s8[:, :0], o8[:, :, :, :0], "int8")
+    K.dequant_tokens(q, s, out, "int4")
+    torch.cuda.synchronize()
+    assert ev[0].elapsed_time(ev[1]) == small
