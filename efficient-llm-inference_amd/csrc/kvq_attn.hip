@@ -1580,12 +1580,88 @@ constexpr int kMergePF = 16;
 __device__ __forceinline__ void lds_barrier() {  // this workgroup's LDS traffic only; global loads stay in flight
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+// The new token's K (w = 0) / V (w = 1) slice quantised into slot T of its store by ONE workgroup, as
+// quant_new_token_block does, but in one round trip: every element pair is requested up front (with the device-side
+// slot number), stays in registers between the abs-max and the stores, and the workgroup meets at ONE LDS-only
+// barrier. Same expressions per element (IEEE divide, round-half-even), so the stored bytes and scale are the
+// generic routine's. Uniform precondition (checked by the caller): even D, 2-element-aligned rows, at most
+// 2 * kAttnBlock * kNewPairs elements.
+constexpr int kNewPairs = 16;
+__device__ inline bool new_token_fits_registers(const NewTokenArgs& a, uint32_t w) {
+  return (a.D & 1u) == 0u && (uint64_t)a.B * a.H * a.D <= 2ull * kAttnBlock * kNewPairs && ((a.xs_b[w] | a.xs_h[w]) & 1) == 0 &&
+         (reinterpret_cast<uintptr_t>(a.x[w]) & 3u) == 0u;
+}
+template <int IDT>
+__device__ inline void quant_new_token_regs(const NewTokenArgs& a, const uint32_t w, float* s_red, const int* t_dev, const uint32_t t_bound,
+                                            const void* valid) {
+  const uint32_t tid = threadIdx.x;
+  const uint32_t np = a.B * a.H * a.D / 2u;  // element pairs
+  uint32_t t_raw;
+  {
+    const int* tp = t_dev ? t_dev : reinterpret_cast<const int*>(valid);
+    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(t_raw) : "s"(tp));
+  }
+  const uint16_t* x = reinterpret_cast<const uint16_t*>(a.x[w]);
+  uint32_t raw[kNewPairs];
+  uint32_t row[kNewPairs], col[kNewPairs];  // (b, h) row and element offset of the pair
+#pragma unroll
+  for (int k = 0; k < kNewPairs; ++k) {
+    const uint32_t p = tid + (uint32_t)k * kAttnBlock;
+    const uint32_t e = 2u * (p < np ? p : np - 1u);
+    row[k] = e / a.D;
+    col[k] = e - row[k] * a.D;
+    const int64_t off = (int64_t)(row[k] / a.H) * a.xs_b[w] + (int64_t)(row[k] % a.H) * a.xs_h[w] + col[k];
+    raw[k] = *reinterpret_cast<const uint32_t*>(x + off);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t_raw));
+  const int64_t slot = t_dev ? (int64_t)(t_raw < t_bound ? t_raw : t_bound) : 0;  // host-side T: a.q / a.scale point at the slot already
+  float lo[kNewPairs], hi[kNewPairs];
+  float m = 0.0f;
+#pragma unroll
+  for (int k = 0; k < kNewPairs; ++k) {
+    lo[k] = Elem<IDT>::widen((uint16_t)(raw[k] & 0xFFFFu));
+    hi[k] = Elem<IDT>::widen((uint16_t)(raw[k] >> 16));
+    if (tid + (uint32_t)k * kAttnBlock < np) m = fmaxf(m, fmaxf(fabsf(lo[k]), fabsf(hi[k])));
+  }
+  m = wave_fmax(m);
+  if ((tid & 63u) == 0u) s_red[tid >> 6] = m;
+  lds_barrier();
+  m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  uint8_t* qbase = a.q[w] + slot * a.qs_t[w];
+  if (a.bits[w] == 8) {
+    const float s32 = fmaxf(m / QRange<8>::qmax, a.eps);
+    if (tid == 0u) a.scale[w][slot] = Elem<IDT>::round_trip(s32);
+#pragma unroll
+    for (int k = 0; k < kNewPairs; ++k) {
+      if (tid + (uint32_t)k * kAttnBlock < np) {
+        uint8_t* dst = qbase + (int64_t)(row[k] / a.H) * a.qs_b[w] + (int64_t)(row[k] % a.H) * a.qs_h[w] + col[k];
+        dst[0] = (uint8_t)(int8_t)quant1<8>(lo[k], s32);
+        dst[1] = (uint8_t)(int8_t)quant1<8>(hi[k], s32);
+      }
+    }
+  } else {
+    const float s32 = fmaxf(m / QRange<4>::qmax, a.eps);
+    if (tid == 0u) a.scale[w][slot] = Elem<IDT>::round_trip(s32);
+#pragma unroll
+    for (int k = 0; k < kNewPairs; ++k) {
+      if (tid + (uint32_t)k * kAttnBlock < np) {
+        const int h4 = quant1<4>(lo[k], s32) + 8, l4 = quant1<4>(hi[k], s32) + 8;  // even index -> high nibble
+        qbase[(int64_t)(row[k] / a.H) * a.qs_b[w] + (int64_t)(row[k] % a.H) * a.qs_h[w] + (col[k] >> 1)] = (uint8_t)(((h4 & 0xF) << 4) | (l4 & 0xF));
+      }
+    }
+  }
+}
+
 // (has_new: without a new token the host points kn / vn at the query, so that the three loads need no branch)
 __global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_fast_k(const AttnArgs a, const NewTokenArgs nt, const int fuse_quant,
                                                                        const int has_new_i) {
   __shared__ float s_red[3][kAttnBlock / kWave];
   if (blockIdx.x >= a.Hq) {
-    if (fuse_quant && blockIdx.y == 0u) {
+    if (fuse_quant && blockIdx.y == 0u && new_token_fits_registers(nt, blockIdx.x - a.Hq)) {
+      if (a.dtype == KVQ_F16) quant_new_token_regs<KVQ_F16>(nt, blockIdx.x - a.Hq, s_red[0], a.t_dev, a.T, a.q);
+      else quant_new_token_regs<KVQ_BF16>(nt, blockIdx.x - a.Hq, s_red[0], a.t_dev, a.T, a.q);
+    } else if (fuse_quant && blockIdx.y == 0u) {
       NewTokenArgs slot = nt;
       if (a.t_dev) {
         const int64_t T = (int64_t)live_tokens(a);
