@@ -575,3 +575,53 @@ def test_merge_one_round_trip_equals_chained_merge(K, tunable, case):
                 outs.append((out, ks, vs, ksc, vsc))
             for a, b in zip(outs[0], outs[1]):  # output, both stores and both scale tables (slot T written by the step)
                 assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("kinds", [("int8", "int4"), ("int8", "int8"), ("int4", "int4")])
+@pytest.mark.parametrize("shape", [(1, 32, 8, 16384, 128), (8, 32, 8, 16384, 128), (1, 16, 16, 4096, 64)])
+def test_decode_attn_full_size_against_float64_attention_on_the_device(K, shape, kinds):
+    """The benchmark shapes against an independent computation (the CPU oracle does not finish at this size): the
+    stores dequantised to fp16 by the token-table kernel (bit-exact with the reference, test_gpu_fullsize), then plain
+    float64 softmax(q K^T) V with torch ops on the GPU — the oracle's definition of the attention, at
+    Llama-3-8B seq 16K (batch 1 and 8) and gpt2-medium seq 4K. Peaked and flat softmax rows both occur (K scales
+    spread over a decade). Same tolerance as the small-shape oracle tests."""
+    B, Hq, Hkv, T, D = shape
+    g = torch.Generator(device="cuda").manual_seed(T + D + B)
+
+    def store(kind):
+        if kind == "int8":
+            return torch.randint(-127, 128, (B, Hkv, T, D), dtype=torch.int8, device="cuda", generator=g)
+        return torch.randint(0, 256, (B, Hkv, T, D // 2), dtype=torch.uint8, device="cuda", generator=g)
+
+    k_store, v_store = store(kinds[0]), store(kinds[1])
+    qmax = {"int8": 127.0, "int4": 7.0}
+    k_sc = (10.0 ** (torch.rand(T, device="cuda", generator=g) - 1.0)) * (4.0 / qmax[kinds[0]])
+    v_sc = (torch.rand(T, device="cuda", generator=g) * 0.9 + 0.1) * (3.0 / qmax[kinds[1]])
+    k_sc, v_sc = k_sc.half().float(), v_sc.half().float()  # stored scales are fp16 values (reference: scale.to(x.dtype))
+    q = torch.randn(B, Hq, D, device="cuda", generator=g).half()
+    kn = torch.randn(B, Hkv, D, device="cuda", generator=g).half()
+    vn = torch.randn(B, Hkv, D, device="cuda", generator=g).half()
+    sm = D ** -0.5
+    out = torch.full((B, Hq, D), float("nan"), dtype=torch.float16, device="cuda")
+    ws = torch.empty(K.decode_attn_workspace(B, Hq, Hkv, T, D), dtype=torch.float32, device="cuda")
+    K.decode_attn(q, k_store, k_sc, kinds[0], v_store, v_sc, kinds[1], T, out, ws, sm, kn, vn)
+
+    kd = torch.empty(1, B, Hkv, T, D, dtype=torch.float16, device="cuda")
+    vd = torch.empty(1, B, Hkv, T, D, dtype=torch.float16, device="cuda")
+    K.dequant_tokens(k_store.unsqueeze(0), k_sc.unsqueeze(0), kd, kinds[0])
+    K.dequant_tokens(v_store.unsqueeze(0), v_sc.unsqueeze(0), vd, kinds[1])
+    nq = Hq // Hkv
+    ref = torch.empty(B, Hq, D, dtype=torch.float64, device="cuda")
+    for b in range(B):  # one batch row at a time: float64 copies of one row's K / V only
+        kf = torch.cat([kd[0, b], kn[b].unsqueeze(1)], dim=1).double()  # [Hkv, T + 1, D]
+        vf = torch.cat([vd[0, b], vn[b].unsqueeze(1)], dim=1).double()
+        qf = q[b].double().view(Hkv, nq, D)
+        s = torch.einsum("hqd,htd->hqt", qf, kf) * sm
+        p = torch.softmax(s, dim=-1)
+        ref[b] = torch.einsum("hqt,htd->hqd", p, vf).reshape(Hq, D)
+        del kf, vf, s, p
+    torch.cuda.synchronize()
+    got = out.double()
+    assert torch.isfinite(got).all()
+    bound = TOL["f16"] * (ref.abs() + ref.abs().max())
+    assert bool(((got - ref).abs() <= bound).all()), float(((got - ref).abs() / bound).max())
