@@ -23,7 +23,7 @@ from __future__ import annotations
 
 import math
 import time
-from typing import Callable, Optional, Tuple
+from typing import Callable, Tuple
 
 import torch
 

@@ -45,6 +45,7 @@ Tunables& tunables() {
     d.nt_loads = 1;
     d.attn_k_i8 = -1;
     d.attn_merge_fast = 1;
+    d.attn_stream_roll = 1;
     return d;
   }();
   return t;
@@ -76,6 +77,7 @@ static const TunableKey kTunableKeys[] = {
     {"attn_fused", &Tunables::attn_fused},
     {"attn_k_i8", &Tunables::attn_k_i8},
     {"attn_merge_fast", &Tunables::attn_merge_fast},
+    {"attn_stream_roll", &Tunables::attn_stream_roll},
     {"attn_stream_tpw", &Tunables::attn_stream_tpw},
     {"attn_stream_slots", &Tunables::attn_stream_slots},
     {"attn_stream_tc", &Tunables::attn_stream_tc},

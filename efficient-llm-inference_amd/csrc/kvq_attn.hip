@@ -864,7 +864,14 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
 // operands, descriptors) is paid once per tpw tiles, and the split partials shrink by tpw.
 // Same operand layouts as AttnTile (see its header). P is scaled by sv[t] / svref with svref the largest
 // V scale seen so far (non-decreasing), the accumulator carries the matching 1 / svref.
-template <int KBITS, int VBITS, int TC, int HD, bool KI8 = false>
+// ROLL: the registers of the tile being reduced are re-requested piece by piece for the tile after next as soon as
+// each piece has been consumed (K rows per 16-token group after its score MFMAs, V rows after their byte images are
+// built, scales after they are staged): close to two tiles per wave stay in flight instead of one, which is what
+// the bytes in flight the HBM needs at this bandwidth ask for (Little's law: 6 TB/s x ~5 us under load = 30 MB; one
+// 12 KB tile per wave x 2048 waves is 24 MB). Batch 8, 16 K tokens: 49.4 -> 44.8 us per call.
+// (Also measured: the INT4 V tile as 16-byte loads redistributed through an LDS image — 4 load instructions instead
+// of 16: 2 us faster with the arithmetic removed, nothing with it, slower together with ROLL; not kept.)
+template <int KBITS, int VBITS, int TC, int HD, bool KI8 = false, bool ROLL = false>
 struct AttnStream {
   typedef AttnTile<KBITS, VBITS, TC, HD> TL;
   static constexpr int NT = TL::NT, NS = TL::NS, KS = TL::KS, DVN = TL::DVN, CBK = TL::CBK, NL = TL::NL, SPL = TL::SPL, VB = TL::VB;
@@ -940,58 +947,105 @@ struct AttnStream {
     for (int n = 0; n < DVN; ++n) acc[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
 
-  // request every byte of the tile [t0, t0 + nt): nothing waits here
-  __device__ __forceinline__ void issue(const AttnArgs& a, const uint32_t b, const uint32_t hk, const uint32_t t0, const uint32_t nt, Raw& r) const {
+  // where a tile's rows come from: buffer descriptors over its valid rows (nt == 0: every load returns zeros and
+  // touches no memory — the "tile" past a wave's last one)
+  struct Src {
+    __amdgpu_buffer_rsrc_t k, v;
+    uint32_t t0, nt;
+  };
+  __device__ __forceinline__ Src src(const AttnArgs& a, const uint32_t b, const uint32_t hk, const uint32_t t0, const uint32_t nt) const {
+    Src s;
+    s.k = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.k + (int64_t)b * a.k_sb + (int64_t)hk * a.k_sh + (int64_t)t0 * a.k_st), 0,
+                                            (int)(nt * (uint32_t)a.k_st), 0x00020000);
+    s.v = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.v + (int64_t)b * a.v_sb + (int64_t)hk * a.v_sh + (int64_t)t0 * a.v_st), 0,
+                                            (int)(nt * (uint32_t)a.v_st), 0x00020000);
+    s.t0 = t0;
+    s.nt = nt;
+    return s;
+  }
+  // the pieces of a tile's request; nothing waits here
+  __device__ __forceinline__ void issue_k(const AttnArgs& a, const Src& s, const int i, Raw& r) const {  // 16-token group i
     const uint32_t lane = threadIdx.x & 63u, x = lane & 15u, g = lane >> 4;
-    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t*>(a.k + (int64_t)b * a.k_sb + (int64_t)hk * a.k_sh + (int64_t)t0 * a.k_st), 0, (int)(nt * (uint32_t)a.k_st), 0x00020000);
-    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t*>(a.v + (int64_t)b * a.v_sb + (int64_t)hk * a.v_sh + (int64_t)t0 * a.v_st), 0, (int)(nt * (uint32_t)a.v_st), 0x00020000);
     const uint32_t k_lane = x * (uint32_t)a.k_st + (uint32_t)CBK * g;
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+    for (int c = 0; c < NL; ++c) {
+      const uint32_t off = k_lane + 16 * i * (uint32_t)a.k_st + 4 * CBK * c;
+      if constexpr (CBK == 16) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(s.k, off, 0, 2);
 #pragma unroll
-      for (int c = 0; c < NL; ++c) {
-        const uint32_t off = k_lane + 16 * i * (uint32_t)a.k_st + 4 * CBK * c;
-        if constexpr (CBK == 16) {
-          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, off, 0, 2);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) r.k[i][c][j] = v[j];
-        } else {
-          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(k_rsrc, off, 0, 2);
-          r.k[i][c][0] = v[0];
-          r.k[i][c][1] = v[1];
-        }
+        for (int j = 0; j < 4; ++j) r.k[i][c][j] = v[j];
+      } else {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(s.k, off, 0, 2);
+        r.k[i][c][0] = v[0];
+        r.k[i][c][1] = v[1];
       }
+    }
+  }
+  __device__ __forceinline__ void issue_v(const AttnArgs& a, const Src& s, const int sidx, Raw& r) const {  // 32-token step sidx
+    const uint32_t lane = threadIdx.x & 63u, x = lane & 15u, g = lane >> 4;
     const uint32_t v_lane = 4u * g * (uint32_t)a.v_st + (uint32_t)VB * x;
 #pragma unroll
-    for (int sidx = 0; sidx < NS; ++sidx)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const uint32_t row = 32 * sidx + 16 * (j >> 2) + (j & 3);  // + 4 g from the lane offset
-        const uint32_t off = v_lane + row * (uint32_t)a.v_st;
-        if constexpr (VB == 8) {
-          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(v_rsrc, off, 0, 2);
-          r.v[sidx][j][0] = v[0];
-          r.v[sidx][j][1] = v[1];
-        } else if constexpr (VB == 4) {
-          r.v[sidx][j][0] = __builtin_amdgcn_raw_buffer_load_b32(v_rsrc, off, 0, 2);
-        } else {
-          r.v[sidx][j][0] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(v_rsrc, off, 0, 2);
-        }
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t row = 32 * sidx + 16 * (j >> 2) + (j & 3);  // + 4 g from the lane offset
+      const uint32_t off = v_lane + row * (uint32_t)a.v_st;
+      if constexpr (VB == 8) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(s.v, off, 0, 2);
+        r.v[sidx][j][0] = v[0];
+        r.v[sidx][j][1] = v[1];
+      } else if constexpr (VB == 4) {
+        r.v[sidx][j][0] = __builtin_amdgcn_raw_buffer_load_b32(s.v, off, 0, 2);
+      } else {
+        r.v[sidx][j][0] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(s.v, off, 0, 2);
       }
+    }
+  }
+  __device__ __forceinline__ void issue_scales(const AttnArgs& a, const Src& s, Raw& r) const {
+    const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
     for (int q = 0; q < SR; ++q) {
       const uint32_t i = q * kWave + lane;
-      const uint32_t ic = i < nt ? i : nt - 1u;
-      r.ks[q] = a.k_scale[t0 + ic];
-      r.vs[q] = i < nt ? a.v_scale[t0 + ic] : 0.0f;
+      const uint32_t ic = i < s.nt ? i : (s.nt ? s.nt - 1u : 0u);
+      r.ks[q] = a.k_scale[s.t0 + ic];
+      r.vs[q] = i < s.nt ? a.v_scale[s.t0 + ic] : 0.0f;
     }
+  }
+  __device__ __forceinline__ void issue(const AttnArgs& a, const Src& s, Raw& r) const {  // the whole tile
+#pragma unroll
+    for (int i = 0; i < NT; ++i) issue_k(a, s, i, r);
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) issue_v(a, s, sidx, r);
+    issue_scales(a, s, r);
   }
 
   // fold one loaded tile into the running (m, l, acc); s_ks / s_vs: TC floats each, s_al: 16 floats (this wave's)
-  __device__ __forceinline__ void consume(const AttnArgs& a, const uint32_t nt, const Raw& r, float* s_ks, float* s_vs, float* s_al) {
+  // nx (ROLL): the tile after next, whose rows take over r's registers as this tile's pieces are consumed
+  __device__ __forceinline__ void consume(const AttnArgs& a, const uint32_t nt, Raw& r, const Src& nx, float* s_ks, float* s_vs, float* s_al) {
     const uint32_t lane = threadIdx.x & 63u, x = lane & 15u, g = lane >> 4;
+#ifdef KVQ_ATTN_CALIB  // calibration build (`make calib_attn`, never shipped): every loaded word is consumed, nothing is
+    {                  // computed — the time of the kernel's own load pattern and prefetch depth (inexact results)
+      uint32_t xr = 0u;
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int c = 0; c < NL; ++c)
+#pragma unroll
+          for (int j = 0; j < CBK / 4; ++j) xr ^= r.k[i][c][j];
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr ^= r.v[s][j][0] ^ (VB == 8 ? r.v[s][j][VB == 8 ? 1 : 0] : 0u);
+      float fs = 0.0f;
+#pragma unroll
+      for (int q = 0; q < SR; ++q) fs += r.ks[q] + r.vs[q];
+      acc[0][0] += __uint_as_float(xr & 0x007FFFFFu) + fs;
+      m = 0.0f;
+      l = 1.0f;
+      svref = 1.0f;
+      (void)x; (void)g; (void)s_ks; (void)s_vs; (void)s_al; (void)nt;
+      if constexpr (ROLL) issue(a, nx, r);
+      return;
+    }
+#endif
     const bool full = nt == (uint32_t)TC;  // uniform
     // ---- scales: K side with sm_scale log2(e) folded in, V side relative to the running reference ----------
     float svmax = 0.0f;
@@ -1010,6 +1064,7 @@ struct AttnStream {
         s_vs[i] = r.vs[q] * svn;
       }
     }
+    if constexpr (ROLL) issue_scales(a, nx, r);
     // ---- S = K Q^T ------------------------------------------------------------------------------------------
     f32x4 sc[NT];
 #pragma unroll
@@ -1026,6 +1081,7 @@ struct AttnStream {
 #pragma unroll
         for (int q = 0; q < 4; ++q) c4[q] = fmaf((float)c2[q], 1.0f / 254.0f, (float)c1[q]) * aq;
         sc[i] = c4;
+        if constexpr (ROLL) issue_k(a, nx, i, r);
         continue;
       }
 #pragma unroll
@@ -1044,6 +1100,7 @@ struct AttnStream {
         }
       }
       sc[i] = c4;
+      if constexpr (ROLL) issue_k(a, nx, i, r);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // s_ks / s_vs written above by this wave's lanes
     __builtin_amdgcn_wave_barrier();
@@ -1106,6 +1163,7 @@ struct AttnStream {
           img[0][j] = ((w0 >> 4) & 0x0F0Fu) | ((w0 & 0x0F0Fu) << 16);
         }
       }
+      if constexpr (ROLL) issue_v(a, nx, sidx, r);
       const f16x8 pa = pack_h8(Elem<KVQ_F16>::pack2(sc[2 * sidx][0], sc[2 * sidx][1]), Elem<KVQ_F16>::pack2(sc[2 * sidx][2], sc[2 * sidx][3]),
                                Elem<KVQ_F16>::pack2(sc[2 * sidx + 1][0], sc[2 * sidx + 1][1]),
                                Elem<KVQ_F16>::pack2(sc[2 * sidx + 1][2], sc[2 * sidx + 1][3]));
@@ -1132,9 +1190,9 @@ struct AttnStream {
 
 // Two tiles' worth of raw rows live in registers: 64-token tiles fit 2 waves per SIMD (<= 256 VGPRs),
 // 32-token tiles 3 (<= 168); the second launch-bounds argument is waves per SIMD for one-wave workgroups.
-template <int KBITS, int VBITS, int TC, int HD, bool KI8 = false>
+template <int KBITS, int VBITS, int TC, int HD, bool KI8 = false, bool ROLL = false>
 __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_stream_mfma_k(const AttnArgs a, const uint32_t tpw) {
-  typedef AttnStream<KBITS, VBITS, TC, HD, KI8> ST;
+  typedef AttnStream<KBITS, VBITS, TC, HD, KI8, ROLL> ST;
   constexpr int DVN = ST::DVN;
   __shared__ __attribute__((aligned(16))) float s_ks[TC];
   __shared__ __attribute__((aligned(16))) float s_vs[TC];
@@ -1144,19 +1202,36 @@ __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_stream_mf
   const uint32_t ntiles = (a.T + (uint32_t)TC - 1u) / (uint32_t)TC;
   const uint32_t first = split * tpw;
   const uint32_t last = first + tpw < ntiles ? first + tpw : ntiles;  // host: first < ntiles for every split
-  auto tok0 = [&](uint32_t t) { return t * (uint32_t)TC; };
-  auto ntok = [&](uint32_t t) { return a.T - t * (uint32_t)TC < (uint32_t)TC ? a.T - t * (uint32_t)TC : (uint32_t)TC; };
   ST st;
+  // The wave's k-th tile, or the empty tile (nothing is read) past its last one. (Starting every wave at a different
+  // tile of its range — the online softmax does not care about the order — measured 1-2 % slower: the waves' regions
+  // do not alias onto the same HBM channels as they are.)
+  const uint32_t n = last - first;
+  auto tile = [&](uint32_t k) {
+    const uint32_t tt = first + (k < n ? k : 0u);
+    const uint32_t cnt = a.T - tt * (uint32_t)TC < (uint32_t)TC ? a.T - tt * (uint32_t)TC : (uint32_t)TC;
+    return st.src(a, b, hk, tt * (uint32_t)TC, k < n ? cnt : 0u);
+  };
   typename ST::Raw ra, rb;
-  st.issue(a, b, hk, tok0(first), ntok(first), ra);
-  st.init(a, b, hk);
-  for (uint32_t t = first; t < last; t += 2u) {
-    const bool two = t + 1u < last;  // uniform
-    if (two) st.issue(a, b, hk, tok0(t + 1u), ntok(t + 1u), rb);
-    st.consume(a, ntok(t), ra, s_ks, s_vs, s_al);
-    if (two) {
-      if (t + 2u < last) st.issue(a, b, hk, tok0(t + 2u), ntok(t + 2u), ra);
-      st.consume(a, ntok(t + 1u), rb, s_ks, s_vs, s_al);
+  if constexpr (ROLL) {  // two tiles requested up front; every consume re-requests its registers for the tile after next
+    st.issue(a, tile(0u), ra);
+    st.issue(a, tile(1u), rb);
+    st.init(a, b, hk);
+    for (uint32_t k = 0; k < n; k += 2u) {
+      st.consume(a, tile(k).nt, ra, tile(k + 2u), s_ks, s_vs, s_al);
+      if (k + 1u < n) st.consume(a, tile(k + 1u).nt, rb, tile(k + 3u), s_ks, s_vs, s_al);
+    }
+  } else {
+    st.issue(a, tile(0u), ra);
+    st.init(a, b, hk);
+    for (uint32_t k = 0; k < n; k += 2u) {
+      const bool two = k + 1u < n;  // uniform
+      if (two) st.issue(a, tile(k + 1u), rb);
+      st.consume(a, tile(k).nt, ra, tile(k), s_ks, s_vs, s_al);
+      if (two) {
+        if (k + 2u < n) st.issue(a, tile(k + 2u), ra);
+        st.consume(a, tile(k + 1u).nt, rb, tile(k + 1u), s_ks, s_vs, s_al);
+      }
     }
   }
   // ---- workspace: (m, l) per head, acc[heads][D] — the layout decode_attn_merge_k reads ---------------------
@@ -1894,7 +1969,9 @@ static void launch_partial(const AttnArgs& a, hipStream_t st) {
     // kernel: 50.6 vs 52.3 us per call at batch 8), 1 = always, 0 = never (one tile per wave: 52.6 vs 50.5 us)
     const int64_t ki8 = tunables().attn_k_i8;
     if (a.mfma && a.D == 128u && (ki8 > 0 || (ki8 < 0 && a.stream_tpw))) {
-      if (a.stream_tpw && stream_tc() == 64)
+      if (a.stream_tpw && stream_tc() == 64 && tunables().attn_stream_roll)
+        hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128, true, true>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
+      else if (a.stream_tpw && stream_tc() == 64)
         hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128, true>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
       else if (a.stream_tpw)
         hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 32, 128, true>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
@@ -1904,7 +1981,9 @@ static void launch_partial(const AttnArgs& a, hipStream_t st) {
     }
   }
   if (a.mfma && a.stream_tpw) {
-    if (stream_tc() == 64) hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
+    if (stream_tc() == 64 && tunables().attn_stream_roll)
+      hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128, false, true>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
+    else if (stream_tc() == 64) hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
     else hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 32, 128>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
     return;
   }

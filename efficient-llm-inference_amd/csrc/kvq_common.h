@@ -67,6 +67,7 @@ struct Tunables {
   int64_t attn_stream_tpw;       // streaming MFMA kernel: 64-token tiles per wave; 0 = by size (only when tiles exceed wave slots), -1 = never
   int64_t attn_stream_tc;        // tokens per tile of the streaming kernel: 64 (default) or 32
   int64_t attn_stream_slots;     // wave slots the streaming plan fills in one round (default 3072 = 3 per SIMD)
+  int64_t attn_stream_roll;      // streaming kernel, 64-token tiles: re-request a tile's registers piece by piece for the tile after next (1) or whole tiles between reductions (0)
   int64_t attn_merge_fast;       // 1 (default) = merge kernel that requests everything up front (<= 256 splits); 0 = the chained one
   int64_t attn_k_i8;             // INT8 keys at head_dim 128: stored bytes straight into v_mfma_i32_16x16x64_i8 (query as two int8 planes): -1 = streaming kernel only (default), 0 = never, 1 = always
   int64_t attn_fused;            // 1 = decode attention as ONE launch (decode_attn_fused_mfma_k) where it applies; default 0: partial + merge measured faster

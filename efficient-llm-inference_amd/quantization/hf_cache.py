@@ -18,8 +18,6 @@ Needs transformers >= 4.54 / 5.x (``DynamicLayer``); ``available()`` says whethe
 """
 from __future__ import annotations
 
-from typing import Optional
-
 import torch
 
 try:

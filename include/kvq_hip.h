@@ -281,6 +281,8 @@ int kvq_time_next_launch(void* start_event, void* stop_event);
  *               "attn_merge_fast" (1 = merge kernel that requests all operands up front, default; 0 = chained merge;
  *               equal output bits), "attn_stream_tpw" (tiles per wave of the streaming kernel: -1 never, 0 by size,
  *               > 0 that many), "attn_stream_tc" (64|32), "attn_stream_slots" (wave slots one round fills),
+ *               "attn_stream_roll" (1 = a tile's registers are re-requested piece by piece for the tile after next,
+ *               default; 0 = whole tiles between reductions; equal output bits),
  *               "attn_k_i8" (INT8 keys through the int8 MFMA: -1 streaming kernel only, 0 never, 1 always;
  *               tolerance-level difference), "attn_fused" (0/1: one launch per call where it applies; default 0 =
  *               partial + merge launches, measured faster), "attn_fused_tc" / "attn_fused_nw" (tokens per wave /

@@ -625,3 +625,37 @@ def test_decode_attn_full_size_against_float64_attention_on_the_device(K, shape,
     assert torch.isfinite(got).all()
     bound = TOL["f16"] * (ref.abs() + ref.abs().max())
     assert bool(((got - ref).abs() <= bound).all()), float(((got - ref).abs() / bound).max())
+
+
+@pytest.mark.parametrize("tpw", [1, 2, 3, 8])
+@pytest.mark.parametrize("ki8", [0, 1])
+def test_streaming_kernel_rolling_requests_equal_whole_tile_requests(K, tunable, tpw, ki8):
+    """attn_stream_roll (default): a tile's registers are re-requested piece by piece for the tile after next while
+    the tile is being reduced. Only the load schedule changes: output bits equal the whole-tile schedule's — odd and
+    even tile counts, a ragged last tile, waves with one tile, every kind pair, both key paths."""
+    tunable("attn_stream_tpw", tpw)
+    tunable("attn_stream_tc", 64)
+    tunable("attn_k_i8", ki8)
+    for B, Hq, Hkv, T, D in [(1, 32, 8, 1000, 128), (2, 6, 2, 200, 128), (8, 32, 8, 4100, 128), (1, 8, 2, 64, 128), (3, 8, 2, 1, 128)]:
+        g = torch.Generator(device="cuda").manual_seed(T + tpw)
+        for kinds in (("int8", "int4"), ("int4", "int8"), ("int8", "int8"), ("int4", "int4")):
+            def store(kind):
+                if kind == "int8":
+                    return torch.randint(-127, 128, (B, Hkv, T + 3, D), dtype=torch.int8, device="cuda", generator=g)
+                return torch.randint(0, 256, (B, Hkv, T + 3, D // 2), dtype=torch.uint8, device="cuda", generator=g)
+            k_store, v_store = store(kinds[0]), store(kinds[1])
+            k_sc = torch.rand(T + 3, device="cuda", generator=g) * 0.02 + 1e-3
+            v_sc = torch.rand(T + 3, device="cuda", generator=g) * 0.2 + 1e-3
+            k_sc[T:] = float("nan")  # guard rows past T are never read into the result
+            v_sc[T:] = float("nan")
+            q = torch.randn(B, Hq, D, device="cuda", generator=g).half()
+            ws = torch.empty(K.decode_attn_workspace(B, Hq, Hkv, T, D), dtype=torch.float32, device="cuda")
+            outs = []
+            for roll in (1, 0):
+                tunable("attn_stream_roll", roll)
+                out = torch.full((B, Hq, D), float("nan"), dtype=torch.float16, device="cuda")
+                K.decode_attn(q, k_store, k_sc, kinds[0], v_store, v_sc, kinds[1], T, out, ws, D ** -0.5, None, None)
+                torch.cuda.synchronize()
+                assert torch.isfinite(out.float()).all()
+                outs.append(out)
+            assert torch.equal(outs[0], outs[1]), (B, Hq, Hkv, T, D, kinds)
