@@ -5,7 +5,9 @@
 #   --kernel-trace), the N = 2 rehearsal of bench.py's self-launcher, smoke().
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
-O=$PWD/gpurun_out/r02p
+TAG=${TAG:-r02p}
+export TAG
+O=$PWD/gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
 log() { echo "== $*" | tee -a $O/steps.log; }
@@ -42,7 +44,7 @@ timeout -k 10 200 python3 bench.py --gpus 2 --steps 3 --warmup 1 --share-gpu > $
 log "summaries"
 python3 - <<'PY'
 import csv, glob, json, os, collections
-O = os.path.join(os.getcwd(), "gpurun_out", "r02p")
+O = os.path.join(os.getcwd(), "gpurun_out", os.environ.get("TAG", "r02p"))
 def stats(d):
     f = glob.glob(os.path.join(O, d, "**", "*kernel_stats.csv"), recursive=True)
     return f[0] if f else None
