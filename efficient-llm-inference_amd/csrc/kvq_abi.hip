@@ -43,6 +43,7 @@ Tunables& tunables() {
     d.attn_mfma_min_nq = 3;
     d.attn_mfma_tc = 128;
     d.nt_loads = 1;
+    d.quant_nt_stores = -1;
     d.attn_k_i8 = -1;
     d.attn_merge_fast = 1;
     d.attn_stream_roll = 1;
@@ -71,6 +72,7 @@ static const TunableKey kTunableKeys[] = {
     {"quant_nv", &Tunables::quant_nv},
     {"quant_lds_pad", &Tunables::quant_lds_pad},
     {"quant_tpw", &Tunables::quant_tpw},
+    {"quant_nt_stores", &Tunables::quant_nt_stores},
     {"attn_force_valu", &Tunables::attn_force_valu},
     {"attn_mfma_min_nq", &Tunables::attn_mfma_min_nq},
     {"attn_mfma_tc", &Tunables::attn_mfma_tc},

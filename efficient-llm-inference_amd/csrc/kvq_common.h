@@ -59,6 +59,7 @@ struct Tunables {
   int64_t quant_block;           // fused quantise kernel workgroup: 64 (default, one wave per tile), 128 or 256 (measured: 241 / 261 / 270 us)
   int64_t quant_nv;              // 4 = 2048-element one-wave tiles (A-B), else 8
   int64_t quant_no_regmax;       // 1 = keep the LDS abs-max in one-wave tiles (A-B)
+  int64_t quant_nt_stores;       // quantise kernels: non-temporal output stores (1), write-back stores (0), follow nt_loads (-1, default)
   int64_t quant_tpw;             // tiles per wave of the pipelined one-wave quantise kernel (2 | 4 | 8); 0 = one tile per wave
   int64_t quant_lds_pad;         // A-B: bytes of unused dynamic LDS on the one-wave quantise launch (caps waves per CU)
   int64_t attn_force_valu;       // 1 = decode attention never takes the MFMA kernel (tests / A-B)

@@ -254,6 +254,11 @@ static const Variant kVariants[] = {
     {8, 1, true, true, 64},   // 28: 27 + NT loads
     {8, 4, true, true, 128},  // 29
     {8, 2, true, true, 128},  // 30: NT loads
+    {8, 4, false, true, 64},  // 31: as 21 with write-back (not non-temporal) stores
+    {8, 4, false, true, 64},  // 32: 31 + NT loads
+    {8, 2, false, true, 64},  // 33: as 23 with write-back stores (NT loads)
+    {8, 8, false, true, 64},  // 34: 8 KiB of output per wave, write-back stores, NT loads
+    {8, 2, false, true, 64},  // 35: 33 without NT loads
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 // shipped defaults (profiles/r01_microbench.txt): contiguous 1 KiB stores per wave instruction;
@@ -300,6 +305,11 @@ static bool launch_fast_variant(int v, const DequantArgs& a, unsigned grid, hipS
     case 28: launch_fast<ODT, BITS, 8, 1, true, true, true, 64>(a, grid, st, ev); return true;
     case 29: launch_fast<ODT, BITS, 8, 4, true, true, false, 128>(a, grid, st, ev); return true;
     case 30: launch_fast<ODT, BITS, 8, 2, true, true, true, 128>(a, grid, st, ev); return true;
+    case 31: launch_fast<ODT, BITS, 8, 4, false, true, false, 64>(a, grid, st, ev); return true;
+    case 32: launch_fast<ODT, BITS, 8, 4, false, true, true, 64>(a, grid, st, ev); return true;
+    case 33: launch_fast<ODT, BITS, 8, 2, false, true, true, 64>(a, grid, st, ev); return true;
+    case 34: launch_fast<ODT, BITS, 8, 8, false, true, true, 64>(a, grid, st, ev); return true;
+    case 35: launch_fast<ODT, BITS, 8, 2, false, true, false, 64>(a, grid, st, ev); return true;
   }
   return false;
 }

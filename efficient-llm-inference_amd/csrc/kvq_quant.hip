@@ -50,6 +50,7 @@ struct QuantArgs {
   uint32_t vpr;      // sweep kernel, same case: TT * D/8 vectors per row run
   uint32_t t_begin;  // first token of this launch's first tile
   int32_t nt_loads;  // non-temporal input loads
+  int32_t nt_stores; // non-temporal output stores (tunable quant_nt_stores; -1 = follow nt_loads)
   int32_t blk;       // workgroup size of the fused kernel (256, or 64 = one wave per tile)
   int32_t nv;        // vectors per lane per tile (8, or 4 for the small one-wave tile)
   int32_t bh_contig; // rows addressable as r * stride_h on both sides
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
       if (off < valid_bytes) {
 #endif
         const u32x4 w = *reinterpret_cast<const u32x4*>(&s_out[k >> 2]);
-        if (a.nt_loads) __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off));
+        if (a.nt_stores) __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off));
         else *reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off) = w;
       }
     }
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(kWave) void quant_tokens_pipe_k(const QuantArgs a) 
     for (uint32_t k = lane * 16u; k < (uint32_t)R * kRowBytes; k += 64u * 16u) {
       const uint32_t r = k / kRowBytes, off = k % kRowBytes;
       const u32x4 w = *reinterpret_cast<const u32x4*>(&s_out[k >> 2]);
-      if (a.nt_loads) __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off));
+      if (a.nt_stores) __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off));
       else *reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off) = w;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next tile's staging writes stay below these reads
@@ -804,6 +805,7 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
   a.blk = kBlock;
   a.nv = kNVMax;
   a.nt_loads = (int32_t)tunables().nt_loads;
+  a.nt_stores = tunables().quant_nt_stores < 0 ? a.nt_loads : (int32_t)(tunables().quant_nt_stores != 0);
   a.bh_contig = bh_contig ? 1 : 0;
   a.xcd_group = (uint32_t)(tunables().quant_xcd_group > 1 ? tunables().quant_xcd_group : 0);
   if (fused && anydv) {

@@ -66,6 +66,47 @@ __global__ __launch_bounds__(256) void read16_k(const u32x4* __restrict__ in, ui
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc ^= in[i];
   if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
 }
+// Does a workgroup read faster from SOME addresses than from others? One-wave workgroups, workgroup w reads the
+// contiguous chunk (w + shift) mod n of VEC 16-byte vectors: the dispatcher deals workgroups round robin over the 8
+// XCDs, so `shift` moves every XCD's chunks by shift * chunk bytes relative to the identity map.
+template <int VEC>
+__global__ __launch_bounds__(64) void read_chunk_shift_k(const u32x4* __restrict__ in, uint32_t* sink, uint32_t n_chunks, uint32_t shift) {
+  uint32_t c = blockIdx.x + shift;
+  if (c >= n_chunks) c -= n_chunks;
+  const u32x4* p = in + (int64_t)c * VEC + threadIdx.x;
+  u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < VEC / 64; ++i) acc ^= __builtin_nontemporal_load(p + i * 64);
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
+}
+// write ceiling with the launch shape of the dequantise kernel: one-wave workgroup w fills the contiguous chunk w of
+// VEC 16-byte vectors (non-temporal or write-back stores)
+template <int VEC, bool NT>
+__global__ __launch_bounds__(64) void fill_chunk_k(u32x4* __restrict__ out, uint32_t v) {
+  u32x4* p = out + (int64_t)blockIdx.x * VEC + threadIdx.x;
+  const u32x4 x = {v, v + 1, v + 2, v + 3};
+#pragma unroll
+  for (int i = 0; i < VEC / 64; ++i) {
+    if (NT) __builtin_nontemporal_store(x, p + i * 64);
+    else p[i * 64] = x;
+  }
+}
+// The quantise tile's read pattern without anything else: one-wave workgroup w reads S segments of LVEC 16-byte
+// vectors, segment s at s * seg_stride + w * LVEC (S = 8 heads 4 MiB apart, L = tokens per tile * 256 B). All loads
+// of the workgroup are in flight together (non-temporal).
+template <int S, int LVEC>
+__global__ __launch_bounds__(64) void read_segments_k(const u32x4* __restrict__ in, uint32_t* sink, int64_t seg_stride_vec) {
+  const u32x4* p = in + (int64_t)blockIdx.x * LVEC + threadIdx.x;
+  u32x4 x[S * (LVEC / 64)];
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+#pragma unroll
+    for (int i = 0; i < LVEC / 64; ++i) x[s * (LVEC / 64) + i] = __builtin_nontemporal_load(p + (int64_t)s * seg_stride_vec + i * 64);
+  u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < S * (LVEC / 64); ++k) acc ^= x[k];
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
+}
 // copy recipes: U independent 16-byte loads per thread, then U stores (NT optional); one tile per block
 template <int BLOCK, int U, bool NT>
 __global__ __launch_bounds__(BLOCK) void copy16_tile_k(const u32x4* __restrict__ in, u32x4* __restrict__ out, int64_t n) {
@@ -253,6 +294,55 @@ int main(int argc, char** argv) {
   kvq_strides_t s_full = {B * H * T * D, H * T * D, T * D, D};
   kvq_strides_t s_half = {B * H * T * D / 2, H * T * D / 2, T * D / 2, D / 2};
 
+  if (what == "affinity") {  // read bandwidth vs the offset between a workgroup's XCD and its chunk's address
+    const int64_t bytes = N * 2;
+#define RUN_AFF(VEC)                                                                                              \
+  for (uint32_t shift : {0u, 1u, 2u, 3u, 4u, 5u, 6u, 7u, 8u, 64u}) {                                              \
+    const uint32_t n_chunks = (uint32_t)(bytes / ((int64_t)VEC * 16));                                            \
+    double best = 1e9;                                                                                            \
+    for (int rep = 0; rep < 3; ++rep) {                                                                           \
+      const double ms = tm.ms_per([&] { rotate(); read_chunk_shift_k<VEC><<<n_chunks, 64>>>((const u32x4*)in16, (uint32_t*)ws, n_chunks, shift); }, iters); \
+      best = ms < best ? ms : best;                                                                               \
+    }                                                                                                             \
+    printf("calib affinity chunk=%6d B shift=%2u chunks  %8.3f ms  %8.1f GB/s (r)\n", VEC * 16, shift, best, 1.0 * bytes / best / 1e6); \
+  }
+    RUN_AFF(64) RUN_AFF(128) RUN_AFF(256) RUN_AFF(512) RUN_AFF(1024)
+#undef RUN_AFF
+  }
+  if (what == "fillchunk") {  // write-only ceiling, one-wave workgroups, one contiguous chunk each
+    const int64_t bytes = N * 2;
+#define RUN_FILL(VEC, NT)                                                                                         \
+  {                                                                                                               \
+    const unsigned grid = (unsigned)(bytes / ((int64_t)(VEC) * 16));                                              \
+    double best = 1e9;                                                                                            \
+    for (int rep = 0; rep < 3; ++rep) {                                                                           \
+      const double ms = tm.ms_per([&] { rotate(); fill_chunk_k<VEC, NT><<<grid, 64>>>((u32x4*)out, 7u); }, iters);  \
+      best = ms < best ? ms : best;                                                                               \
+    }                                                                                                             \
+    printf("calib fillchunk chunk=%6d B nt=%d  %8.3f ms  %8.1f GB/s (w)\n", (VEC) * 16, (int)(NT), best, 1.0 * bytes / best / 1e6); \
+  }
+    RUN_FILL(64, true) RUN_FILL(128, true) RUN_FILL(256, true) RUN_FILL(512, true) RUN_FILL(1024, true)
+    RUN_FILL(64, false) RUN_FILL(128, false) RUN_FILL(256, false) RUN_FILL(512, false) RUN_FILL(1024, false)
+#undef RUN_FILL
+  }
+  if (what == "segread") {  // S strided segments per one-wave workgroup (the quantise tile) vs one contiguous chunk
+    const int64_t bytes = N * 2;
+#define RUN_SEG(S, LVEC)                                                                                          \
+  {                                                                                                               \
+    const int64_t seg_stride_vec = bytes / 16 / (S);                                                              \
+    const unsigned grid = (unsigned)(seg_stride_vec / (LVEC));                                                    \
+    double best = 1e9;                                                                                            \
+    for (int rep = 0; rep < 3; ++rep) {                                                                           \
+      const double ms = tm.ms_per([&] { rotate(); read_segments_k<S, LVEC><<<grid, 64>>>((const u32x4*)in16, (uint32_t*)ws, seg_stride_vec); }, iters); \
+      best = ms < best ? ms : best;                                                                               \
+    }                                                                                                             \
+    printf("calib segread S=%2d L=%6d B (%6d B per workgroup)  %8.3f ms  %8.1f GB/s (r)\n", S, (LVEC) * 16, (S) * (LVEC) * 16, best, 1.0 * bytes / best / 1e6); \
+  }
+    RUN_SEG(1, 256) RUN_SEG(1, 512) RUN_SEG(1, 1024)
+    RUN_SEG(2, 128) RUN_SEG(2, 256) RUN_SEG(4, 64) RUN_SEG(4, 128) RUN_SEG(4, 256)
+    RUN_SEG(8, 64) RUN_SEG(8, 128) RUN_SEG(8, 256) RUN_SEG(16, 64) RUN_SEG(16, 128)
+#undef RUN_SEG
+  }
   if (what == "readpat") {  // read patterns of the chunk mean-pool kernel, no arithmetic
     const int64_t n_chunks = N * 2 / 16384;
     const int grid = (int)((n_chunks * 16 + 255) / 256);
@@ -357,6 +447,28 @@ int main(int argc, char** argv) {
     KVQ_OK(kvq_set_tunable("dequant_variant", -1));
     KVQ_OK(kvq_set_tunable("dequant_grid", 0));
   };
+  if (what == "dqstores") {  // one-wave workgroups: non-temporal vs write-back output stores, interleaved rounds
+    for (int round = 0; round < 3; ++round) {
+      for (int bits : {4, 8}) {
+        const double bytes = bits == 4 ? N * 2.5 : N * 3.0;
+        for (int v : {21, 24, 31, 32, 22, 34, 23, 26, 33, 35}) {
+          KVQ_OK(kvq_set_tunable("dequant_variant", v));
+          const double ms = tm.ms_per(
+              [&] {
+                rotate();
+                if (bits == 4)
+                  KVQ_OK(kvq_dequant_i4_tokens((const uint8_t*)q4, &s_half, scales, T, out, &s_full, KVQ_F16, &dims, 0));
+                else
+                  KVQ_OK(kvq_dequant_i8_tokens((const int8_t*)q8, &s_full, scales, T, out, &s_full, KVQ_F16, &dims, 0));
+              },
+              iters);
+          printf("dqstores round=%d dequant_i%d variant=%2d  %8.3f ms  %8.1f GB/s  frac8T=%.3f\n", round, bits, v, ms, bytes / ms / 1e6,
+                 bytes / ms / 1e6 / 8000.0);
+        }
+      }
+    }
+    KVQ_OK(kvq_set_tunable("dequant_variant", -1));
+  }
   if (what == "dequant4" || what == "all") sweep_dequant(4);
   if (what == "dequant8" || what == "all") sweep_dequant(8);
 

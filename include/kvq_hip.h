@@ -270,12 +270,13 @@ int kvq_time_next_launch(void* start_event, void* stop_event);
 /* ---- tuning knobs (benchmarks only; defaults are what ships) ----------------------------- */
 
 /* Keys (every one changes speed only, never results, except where noted):
- *   dequantise  "dequant_variant" (0..30, -1 = shipped default), "dequant_grid" (workgroups, 0 = one chunk each),
+ *   dequantise  "dequant_variant" (0..35, -1 = shipped default), "dequant_grid" (workgroups, 0 = one chunk each),
  *               "dequant_xcd_group" (consecutive chunks per XCD, 0 = round robin), "nt_loads" (0/1)
  *   quantise    "quant_force_two_pass" (0/1), "quant_direct_stores" (0/1), "quant_block" (64|128|256),
  *               "quant_nv" (8|4|16), "quant_lds_pad" (bytes of unused dynamic LDS: occupancy A-B),
  *               "quant_tpw" (tiles per wave of the pipelined one-wave kernel: 0 = one tile, 2|4|8),
- *               "quant_no_regmax" (0/1), "quant_xcd_group" (consecutive tiles per XCD, 0 = round robin)
+ *               "quant_no_regmax" (0/1), "quant_xcd_group" (consecutive tiles per XCD, 0 = round robin),
+ *               "quant_nt_stores" (1 non-temporal / 0 write-back output stores, -1 = as nt_loads, default)
  *   eviction    "pool_grid" (workgroup cap, 0 = none), "pool_block" (64|128|256)
  *   attention   "attn_force_valu" (0/1), "attn_mfma_min_nq" (default 3), "attn_mfma_tc" (128|64),
  *               "attn_merge_fast" (1 = merge kernel that requests all operands up front, default; 0 = chained merge;

@@ -222,7 +222,7 @@ def test_dequant_all_variants_bit_exact(E, kind, od):
     ref = O.dequantize_tokens(q_ref, s32_ref, kind, 128, od)
     q, sc = to_torch(q_ref), to_torch(s32_ref)
     try:
-        for v in range(31):
+        for v in range(36):
             for grid in (0, 7):
                 _lib.set_tunable("dequant_variant", v)
                 _lib.set_tunable("dequant_grid", grid)
