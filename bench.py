@@ -584,6 +584,19 @@ def main():
             sharding.shutdown()
 
 
+READ_CEIL_GBPS, WRITE_CEIL_GBPS = 7000.0, 6900.0  # profiles/r02ae_microbench_read_write_ceilings.txt
+
+
+def _mix_bound(n_elts, kind, measured_ms):
+    """Lower bound of a dequantise launch when reads and writes each run at this chip's measured ceiling and add."""
+    rd = n_elts * (1.0 if kind == "int8" else 0.5)
+    wr = n_elts * 2.0
+    ms = (rd / READ_CEIL_GBPS + wr / WRITE_CEIL_GBPS) / 1e6
+    return {"read_ceiling": READ_CEIL_GBPS, "write_ceiling": WRITE_CEIL_GBPS, "unit": "GB/s", "bound_ms": round(ms, 4),
+            "frac_of_bound": round(ms / measured_ms, 4),
+            "source": "profiles/r02ae_microbench_read_write_ceilings.txt (one-wave workgroups; reads and writes add)"}
+
+
 def run_dequant(args, rank, world, dev, backend):
     """The headline workload (module docstring): one STEP = to_past_key_values() of the quantised cache."""
     import efficient_llm_inference_amd as E
@@ -729,6 +742,10 @@ def run_dequant(args, rank, world, dev, backend):
                 "avg_launch_ms": round(target_ms, 4), "median_launch_ms": round(v_each[len(v_each) // 2], 4),
                 "min_launch_ms": round(v_each[0], 4), "max_launch_ms": round(v_each[-1], 4),
                 "timer": "HIP events bound to every INT4 launch of the timed region (hipExtLaunchKernelGGL start / stop timestamps)",
+                # informational, beside the contract's frac: what this chip moves for THIS read / write mix. Reads and
+                # writes add on its memory system; the two rates are the one-wave-workgroup ceilings measured with
+                # kvq_microbench segread / fillchunk (profiles/r02ae_microbench_read_write_ceilings.txt), not this run's.
+                "mix_bound": _mix_bound(n_elts, vk, target_ms),
             },
             "roofline_k": {
                 "kernel": f"dequant_tokens_fast_k<{kk}>", "bound": "hbm",

@@ -531,7 +531,8 @@ def test_decode_attn_int8_keys_through_int8_mfma(K, tunable, stream):
 
 
 @pytest.mark.parametrize("case", [(1, 32, 8, 16384, 128), (8, 32, 8, 4100, 128), (1, 12, 12, 300, 64), (1, 4, 4, 200, 256),
-                                  (2, 6, 2, 130, 32), (3, 4, 2, 1, 64), (1, 32, 8, 32768, 128), (1, 32, 8, 700, 64)])
+                                  (2, 6, 2, 130, 32), (3, 4, 2, 1, 64), (1, 32, 8, 32768, 128), (1, 32, 8, 700, 64),
+                                  (16, 8, 8, 300, 128)])  # last: a new token too large for the register-resident quantise
 def test_merge_one_round_trip_equals_chained_merge(K, tunable, case):
     """attn_merge_fast (default): the merge kernel that requests all its operands up front computes the same
     arithmetic in the same order as the chained one — equal output BITS, with and without a new token, fp16 and
