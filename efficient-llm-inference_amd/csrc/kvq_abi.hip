@@ -38,6 +38,7 @@ Tunables& tunables() {
     Tunables d = {};  // every knob 0 unless named here
     d.dequant_variant = -1;
     d.pool_block = 64;
+    d.pool_wave = 1;
     d.quant_block = 64;
     d.quant_nv = 8;
     d.attn_mfma_min_nq = 3;
@@ -68,6 +69,7 @@ static const TunableKey kTunableKeys[] = {
     {"nt_loads", &Tunables::nt_loads},
     {"quant_block", &Tunables::quant_block},
     {"pool_block", &Tunables::pool_block},
+    {"pool_wave", &Tunables::pool_wave},
     {"quant_no_regmax", &Tunables::quant_no_regmax},
     {"quant_nv", &Tunables::quant_nv},
     {"quant_lds_pad", &Tunables::quant_lds_pad},

@@ -55,6 +55,7 @@ struct Tunables {
   int64_t quant_force_two_pass;  // 1 = generic two-pass quantise for every shape (tests)
   int64_t quant_direct_stores;   // 1 = skip the LDS-staged 16 B stores (tests / A-B)
   int64_t pool_grid;             // benchmarks: cap the chunk mean-pool grid (256-thread equivalents); 0 = one item per thread
+  int64_t pool_wave;             // chunk mean-pool: one wave per output row when the shape allows (1, default) or the per-lane-group walk (0)
   int64_t pool_block;            // chunk mean-pool workgroup size: 64 (default, +7 %), 128 or 256
   int64_t quant_block;           // fused quantise kernel workgroup: 64 (default, one wave per tile), 128 or 256 (measured: 241 / 261 / 270 us)
   int64_t quant_nv;              // 4 = 2048-element one-wave tiles (A-B), else 8

@@ -190,6 +190,87 @@ __global__ __launch_bounds__(kBlock) void chunk_pool_vec_k(const PoolArgs a, uin
   }
 }
 
+// One-wave workgroup = ONE output row (b, h, j): a pooled chunk or a copied tail row. The 64 lanes are G groups of
+// DV = D / 8 lanes; group g owns rows RPG g .. RPG g + RPG - 1 of the chunk (chunk = G RPG rows), so the wave's RPG
+// load instructions, ALL in flight at once, cover the chunk's chunk * D * 2 contiguous bytes exactly once and the
+// wave ends — the access shape this memory system reads fastest (kvq_microbench poolpat: 7.1 TB/s against 5.8 for
+// chunk_pool_vec_k's four-chunks-per-wave walk). The fp32 sum stays SEQUENTIAL in t, bit for bit the order of
+// chunk_pool_vec_k and the oracle: G phases; in phase p every group adds its RPG rows to the sum it receives from the
+// group below it (ds_bpermute), so after phase p group p holds the exact chain over rows 0 .. RPG (p + 1) - 1 (the other
+// groups' values of that phase are never used), and group G - 1 ends with the whole chunk. Rows past a ragged last
+// chunk's end enter as +0.0, which leaves an fp32 sum that started at +0.0 unchanged (the reference zero-pads too).
+// (A variant without the redundant phases — 64 v_permlane16/32_swap instructions transpose the chunk so that every
+// lane sums ONE dword of all 64 rows — was bit-identical and no faster: 5.76-5.85 vs 5.63-5.69 ms on the same box.)
+template <int DT, int G, int RPG>
+__global__ __launch_bounds__(64) void chunk_pool_wave_k(const PoolArgs a) {
+  static_assert(DT != KVQ_F32, "16-bit element types");
+  constexpr uint32_t DV = 64 / G;
+  const uint32_t g = blockIdx.y;
+  uint32_t r = blockIdx.x;
+  const uint32_t j = r % a.Tout;
+  r /= a.Tout;
+  const uint32_t h = r % a.H, b = r / a.H;
+  const uint32_t lane = threadIdx.x, lg = lane / DV, dv = lane % DV;
+  const int64_t tstride = a.is.t * 2;
+  const char* in = reinterpret_cast<const char*>(a.in.p[g]) + ((int64_t)b * a.is.b + (int64_t)h * a.is.h + (int64_t)dv * 8) * 2;
+  char* out = reinterpret_cast<char*>(a.out) +
+              ((int64_t)g * a.os.g + (int64_t)b * a.os.b + (int64_t)h * a.os.h + (int64_t)j * a.os.t + (int64_t)dv * 8) * 2;
+  if (j >= a.n_chunks) {  // recent tail: exact copy (wave-uniform branch)
+    if (lg == 0u)
+      *reinterpret_cast<u32x4*>(out) = *reinterpret_cast<const u32x4*>(in + (int64_t)(a.old_len + (j - a.n_chunks)) * tstride);
+    return;
+  }
+  const uint32_t t0 = j * a.chunk;
+  uint32_t n = a.old_len - t0;
+  if (n > a.chunk) n = a.chunk;  // >= 1
+  const char* p = in + (int64_t)t0 * tstride;
+  u32x4 raw[RPG];
+#pragma unroll
+  for (int i = 0; i < RPG; ++i) {  // unconditional loads (a clamped row), all in flight; rows past the end become zeros below
+    const uint32_t row = lg * RPG + i;
+    raw[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + (int64_t)(row < n ? row : n - 1u) * tstride));
+  }
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 acc2[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc2[k] = f32x2{0.0f, 0.0f};
+  // widen once, then packed fp32 adds (IEEE per component: the same sums as scalar adds, half the instructions —
+  // with scalar adds the kernel measured 5.58-5.74 ms at config 5, packed 5.21 ms; widening inside every phase
+  // instead, to save registers: 5.45 ms)
+  f32x2 xf[RPG][4];
+#pragma unroll
+  for (int i = 0; i < RPG; ++i) {
+    const bool ok = lg * RPG + i < n;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t w = ok ? raw[i][k] : 0u;
+      xf[i][k] = f32x2{Elem<DT>::widen((uint16_t)(w & 0xFFFFu)), Elem<DT>::widen((uint16_t)(w >> 16))};
+    }
+  }
+#pragma unroll
+  for (int ph = 0; ph < G; ++ph) {
+    if (ph) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc2[k] = f32x2{__shfl_up(acc2[k][0], DV), __shfl_up(acc2[k][1], DV)};
+    }
+#pragma unroll
+    for (int i = 0; i < RPG; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc2[k] += xf[i][k];
+  }
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    acc[2 * k] = acc2[k][0];
+    acc[2 * k + 1] = acc2[k][1];
+  }
+  if (lg == (uint32_t)(G - 1)) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = acc[k] / a.chunk_f;
+    store8<DT, false>(out, acc);
+  }
+}
+
 // Generic path: any D / strides / alignment; one thread per output element.
 template <int DT>
 __global__ __launch_bounds__(kBlock) void chunk_pool_generic_k(const PoolArgs a, int64_t items_per_g) {
@@ -406,7 +487,28 @@ int kvq_chunk_meanpool(const void* in_base, const void* const* in_ptrs, const kv
                (a.os.g * esz) % 16 == 0 && (a.os.b * esz) % 16 == 0 && (a.os.h * esz) % 16 == 0 &&
                (a.os.t * esz) % 16 == 0;
     for (int64_t i = 0; i < gn && vec; ++i) vec = aligned(a.in.p[i], 16);
-    if (vec) {
+    // one wave per output row when a chunk is exactly the wave's G x RPG rows (16-bit types, D = 64 / 128 / 256)
+    const int64_t lane_groups = d->D == 256 ? 2 : d->D == 128 ? 4 : d->D == 64 ? 8 : 0;
+    const int64_t rpg = lane_groups ? chunk_size / lane_groups : 0;
+    const bool wave = vec && dtype != KVQ_F32 && tunables().pool_wave && lane_groups && chunk_size % lane_groups == 0 &&
+                      (rpg == 8 || rpg == 16) && d->B * d->H * Tout < (int64_t(1) << 31);
+    if (wave) {
+      const dim3 grid((unsigned)(d->B * d->H * Tout), (unsigned)gn);
+#define KVQ_POOL_WAVE(DT_, G_, R_) hipLaunchKernelGGL((chunk_pool_wave_k<DT_, G_, R_>), grid, dim3(64), 0, st, a)
+#define KVQ_POOL_WAVE_DT(G_, R_)                  \
+  do {                                            \
+    if (dtype == KVQ_F16) KVQ_POOL_WAVE(KVQ_F16, G_, R_); \
+    else KVQ_POOL_WAVE(KVQ_BF16, G_, R_);         \
+  } while (0)
+      if (lane_groups == 4 && rpg == 16) KVQ_POOL_WAVE_DT(4, 16);
+      else if (lane_groups == 4) KVQ_POOL_WAVE_DT(4, 8);
+      else if (lane_groups == 8 && rpg == 16) KVQ_POOL_WAVE_DT(8, 16);
+      else if (lane_groups == 8) KVQ_POOL_WAVE_DT(8, 8);
+      else if (rpg == 16) KVQ_POOL_WAVE_DT(2, 16);
+      else KVQ_POOL_WAVE_DT(2, 8);
+#undef KVQ_POOL_WAVE_DT
+#undef KVQ_POOL_WAVE
+    } else if (vec) {
       // Launch shape (measured on a config-5-shaped launch, 64-thread workgroups): one item per
       // thread 6.04 TB/s, persistent grids of 2048 / 4096 / 16384 workgroups 5.85 / 5.94 / 6.00.
       const int64_t blk = tunables().pool_block == 256 || tunables().pool_block == 128 ? tunables().pool_block : 64;

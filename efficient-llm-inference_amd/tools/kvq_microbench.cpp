@@ -79,6 +79,33 @@ __global__ __launch_bounds__(64) void read_chunk_shift_k(const u32x4* __restrict
   for (int i = 0; i < VEC / 64; ++i) acc ^= __builtin_nontemporal_load(p + i * 64);
   if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
 }
+// what v_permlane16_swap / v_permlane32_swap do to (a = lane, b = 100 + lane): printed by `permprobe`
+__global__ void perm_probe_k(uint32_t* out) {
+  typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+  const uint32_t l = threadIdx.x;
+  const u32x2_t r16 = __builtin_amdgcn_permlane16_swap(l, 100u + l, false, false);
+  const u32x2_t r32 = __builtin_amdgcn_permlane32_swap(l, 100u + l, false, false);
+  out[l] = r16[0];
+  out[64 + l] = r16[1];
+  out[128 + l] = r32[0];
+  out[192 + l] = r32[1];
+}
+// candidate read pattern for the chunk mean-pool: one-wave workgroup = ONE 16 KiB chunk (64 rows of 256 B); lane
+// group g = lane / 16 owns rows 16 g .. 16 g + 15, so load instruction i fetches rows {i, 16 + i, 32 + i, 48 + i}
+// (four 256-byte segments 4 KiB apart) and the wave's 16 instructions, all in flight, cover the chunk exactly once.
+// ROWQ: instruction i fetches rows 4 i .. 4 i + 3 instead (1 KiB contiguous).
+template <bool ROWQ>
+__global__ __launch_bounds__(64) void read_chunk_rows_k(const u32x4* __restrict__ in, uint32_t* sink) {
+  const uint32_t lane = threadIdx.x, g = lane >> 4, dv = lane & 15u;
+  const u32x4* p = in + (int64_t)blockIdx.x * 1024 + dv;
+  u32x4 x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = __builtin_nontemporal_load(p + (ROWQ ? (4 * i + g) : (16 * g + i)) * 16);
+  u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc ^= x[i];
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
+}
 // write ceiling with the launch shape of the dequantise kernel: one-wave workgroup w fills the contiguous chunk w of
 // VEC 16-byte vectors (non-temporal or write-back stores)
 template <int VEC, bool NT>
@@ -308,6 +335,29 @@ int main(int argc, char** argv) {
   }
     RUN_AFF(64) RUN_AFF(128) RUN_AFF(256) RUN_AFF(512) RUN_AFF(1024)
 #undef RUN_AFF
+  }
+  if (what == "permprobe") {
+    perm_probe_k<<<1, 64>>>((uint32_t*)ws);
+    uint32_t h[256];
+    HIP_OK(hipMemcpy(h, ws, sizeof(h), hipMemcpyDeviceToHost));
+    const char* names[4] = {"permlane16_swap[0]", "permlane16_swap[1]", "permlane32_swap[0]", "permlane32_swap[1]"};
+    for (int k = 0; k < 4; ++k) {
+      printf("permprobe %s:", names[k]);
+      for (int l = 0; l < 64; l += 8) printf(" l%d=%u", l, h[64 * k + l]);
+      printf("\n");
+    }
+  }
+  if (what == "poolpat") {  // one chunk per one-wave workgroup vs the shipped kernel's pattern
+    const int64_t n_chunks = N * 2 / 16384;
+    for (int rep = 0; rep < 3; ++rep) {
+      double ms = tm.ms_per([&] { rotate(); read_chunk_rows_k<false><<<(unsigned)n_chunks, 64>>>((const u32x4*)in16, (uint32_t*)ws); }, iters);
+      printf("calib chunkrows group-owns-16-rows  %8.3f ms  %8.1f GB/s (r, one 16 KiB chunk per wave, 4 x 256 B per load)\n", ms, 1.0 * N * 2 / ms / 1e6);
+      ms = tm.ms_per([&] { rotate(); read_chunk_rows_k<true><<<(unsigned)n_chunks, 64>>>((const u32x4*)in16, (uint32_t*)ws); }, iters);
+      printf("calib chunkrows row-quads           %8.3f ms  %8.1f GB/s (r, one 16 KiB chunk per wave, 1 KiB per load)\n", ms, 1.0 * N * 2 / ms / 1e6);
+      const int grid = (int)((n_chunks * 16 + 255) / 256);
+      ms = tm.ms_per([&] { rotate(); read_seg_k<16><<<grid, 256>>>((const u32x4*)in16, (uint32_t*)ws, n_chunks); }, iters);
+      printf("calib readseg  batch=16 block=256   %8.3f ms  %8.1f GB/s (r, the shipped kernel's pattern)\n", ms, 1.0 * N * 2 / ms / 1e6);
+    }
   }
   if (what == "fillchunk") {  // write-only ceiling, one-wave workgroups, one contiguous chunk each
     const int64_t bytes = N * 2;

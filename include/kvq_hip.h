@@ -277,7 +277,8 @@ int kvq_time_next_launch(void* start_event, void* stop_event);
  *               "quant_tpw" (tiles per wave of the pipelined one-wave kernel: 0 = one tile, 2|4|8),
  *               "quant_no_regmax" (0/1), "quant_xcd_group" (consecutive tiles per XCD, 0 = round robin),
  *               "quant_nt_stores" (1 non-temporal / 0 write-back output stores, -1 = as nt_loads, default)
- *   eviction    "pool_grid" (workgroup cap, 0 = none), "pool_block" (64|128|256)
+ *   eviction    "pool_grid" (workgroup cap, 0 = none), "pool_block" (64|128|256), "pool_wave" (1 = one wave per
+ *               output row where the shape allows, default; 0 = per-lane-group walk; equal output bits)
  *   attention   "attn_force_valu" (0/1), "attn_mfma_min_nq" (default 3), "attn_mfma_tc" (128|64),
  *               "attn_merge_fast" (1 = merge kernel that requests all operands up front, default; 0 = chained merge;
  *               equal output bits), "attn_stream_tpw" (tiles per wave of the streaming kernel: -1 never, 0 by size,

@@ -479,3 +479,42 @@ def test_chunk_pool_head_dim_128_bit_exact(E, shape, chunk, keep, dtype):
         out = torch.empty(G, B, H, Tout, D, dtype=x.dtype, device="cuda")
         kernels.chunk_meanpool(src, out, chunk, keep)
         assert np.array_equal(bits(out), bits(ref))
+
+
+@pytest.mark.parametrize("shape,chunk,keep", [
+    ((2, 1, 8, 1000, 128), 64, 256),   # 4 lane groups x 16 rows (the default policy at the Llama row shape), ragged last chunk
+    ((2, 2, 3, 520, 128), 32, 8),      # 4 x 8
+    ((2, 1, 4, 700, 64), 64, 17),      # 8 x 8 (gpt2 head_dim)
+    ((2, 1, 2, 900, 64), 128, 0),      # 8 x 16
+    ((2, 1, 2, 300, 256), 32, 5),      # 2 x 16
+    ((2, 2, 1, 130, 256), 16, 1),      # 2 x 8
+    ((2, 1, 2, 64, 128), 64, 0),       # exactly one chunk
+    ((2, 1, 2, 65, 128), 64, 0),       # one row in the last chunk
+    ((2, 1, 2, 400, 128), 128, 3),     # 32 rows per group: not a wave shape, the per-lane-group kernel
+])
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_chunk_pool_one_wave_per_chunk_kernel(E, shape, chunk, keep, dtype):
+    """pool_wave (default): one wave per output row, the chunk's rows split over lane groups, the sequential fp32 sum
+    handed from group to group. Every (lane groups, rows per group) instantiation against the oracle and against the
+    per-lane-group kernel (pool_wave = 0): equal bits; strided (windowed) inputs too."""
+    from efficient_llm_inference_amd import _lib, kernels
+    G, B, H, T, D = shape
+    x_np = seeded_kv(shape, dtype, seed=zlib.crc32(repr((shape, chunk, keep, dtype, "wave")).encode()), dist="heavy")
+    x = to_torch(x_np, dtype)
+    Tout = kernels.chunk_summary_len(T, chunk, keep)
+    ref = O.chunk_summarize_kv(x_np, chunk, keep, dtype=odt(dtype))
+    big = torch.zeros(G, B, H, T + 11, D, dtype=x.dtype, device="cuda")
+    big[:, :, :, 3:T + 3] = x
+    outs = {}
+    shipped = _lib.get_tunable("pool_wave")
+    try:
+        for wave in (1, 0):
+            _lib.set_tunable("pool_wave", wave)
+            for name, src in (("buffer", x), ("list", [x[g] for g in range(G)]), ("window", big[:, :, :, 3:T + 3])):
+                out = torch.full((G, B, H, Tout, D), float("nan"), dtype=x.dtype, device="cuda")
+                kernels.chunk_meanpool(src, out, chunk, keep)
+                assert np.array_equal(bits(out), bits(ref)), (wave, name)
+                outs[(wave, name)] = out
+    finally:
+        _lib.set_tunable("pool_wave", shipped)
+    assert torch.equal(outs[(1, "buffer")].view(torch.int16), outs[(0, "buffer")].view(torch.int16))
