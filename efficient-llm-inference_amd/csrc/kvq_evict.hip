@@ -223,13 +223,14 @@ __global__ __launch_bounds__(64) void chunk_pool_wave_k(const PoolArgs a) {
   const uint32_t t0 = j * a.chunk;
   uint32_t n = a.old_len - t0;
   if (n > a.chunk) n = a.chunk;  // >= 1
-  const char* p = in + (int64_t)t0 * tstride;
+  // the chunk's valid rows as a buffer: rows past a ragged chunk's end are out of range and load as zeros
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(a.in.p[g]) + ((int64_t)b * a.is.b + (int64_t)h * a.is.h) * 2 + (int64_t)t0 * tstride), 0,
+      (int)(n * (uint32_t)tstride), 0x00020000);
   u32x4 raw[RPG];
 #pragma unroll
-  for (int i = 0; i < RPG; ++i) {  // unconditional loads (a clamped row), all in flight; rows past the end become zeros below
-    const uint32_t row = lg * RPG + i;
-    raw[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + (int64_t)(row < n ? row : n - 1u) * tstride));
-  }
+  for (int i = 0; i < RPG; ++i)  // all in flight
+    raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (lg * RPG + i) * (uint32_t)tstride + dv * 16u, 0, 2);
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x2 acc2[4];
 #pragma unroll
@@ -239,14 +240,10 @@ __global__ __launch_bounds__(64) void chunk_pool_wave_k(const PoolArgs a) {
   // instead, to save registers: 5.45 ms)
   f32x2 xf[RPG][4];
 #pragma unroll
-  for (int i = 0; i < RPG; ++i) {
-    const bool ok = lg * RPG + i < n;
+  for (int i = 0; i < RPG; ++i)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t w = ok ? raw[i][k] : 0u;
-      xf[i][k] = f32x2{Elem<DT>::widen((uint16_t)(w & 0xFFFFu)), Elem<DT>::widen((uint16_t)(w >> 16))};
-    }
-  }
+    for (int k = 0; k < 4; ++k)
+      xf[i][k] = f32x2{Elem<DT>::widen((uint16_t)(raw[i][k] & 0xFFFFu)), Elem<DT>::widen((uint16_t)(raw[i][k] >> 16))};
 #pragma unroll
   for (int ph = 0; ph < G; ++ph) {
     if (ph) {
@@ -491,7 +488,8 @@ int kvq_chunk_meanpool(const void* in_base, const void* const* in_ptrs, const kv
     const int64_t lane_groups = d->D == 256 ? 2 : d->D == 128 ? 4 : d->D == 64 ? 8 : 0;
     const int64_t rpg = lane_groups ? chunk_size / lane_groups : 0;
     const bool wave = vec && dtype != KVQ_F32 && tunables().pool_wave && lane_groups && chunk_size % lane_groups == 0 &&
-                      (rpg == 8 || rpg == 16) && d->B * d->H * Tout < (int64_t(1) << 31);
+                      (rpg == 8 || rpg == 16) && d->B * d->H * Tout < (int64_t(1) << 31) &&
+                      chunk_size * a.is.t * 2 < (int64_t(1) << 31);  // 32-bit offsets inside a chunk
     if (wave) {
       const dim3 grid((unsigned)(d->B * d->H * Tout), (unsigned)gn);
 #define KVQ_POOL_WAVE(DT_, G_, R_) hipLaunchKernelGGL((chunk_pool_wave_k<DT_, G_, R_>), grid, dim3(64), 0, st, a)
