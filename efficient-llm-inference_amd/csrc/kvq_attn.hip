@@ -20,9 +20,15 @@
 //                               elements per lane per token: 16-byte (INT8) / 8-byte (INT4) loads
 //   decode_attn_partial_mfma_k  head_dim 64 / 128 with 3..16 query heads per kv head: both products on the
 //                               matrix cores, one wave per 128-token split (see its header below)
-//   both write (m, l) and acc[D] per (batch, query head, split) to the caller's workspace
-//   decode_attn_merge_k         grid (query head, batch): log-sum-exp merge of the splits and of the
-//                               exact new token
+//   decode_attn_stream_mfma_k   the same tile arithmetic for larger batches (more 64-token tiles than wave slots):
+//                               one wave walks several tiles, online softmax, ONE partial per wave; the registers
+//                               of the tile being reduced are re-requested for the tile after next (ROLL)
+//   all write (m, l) and acc[D] per (batch, query head, split) to the caller's workspace
+//   decode_attn_merge_fast_k    grid (query head, batch): log-sum-exp merge of the splits and of the exact new
+//                               token, every operand requested up front (<= 256 splits); two extra workgroups
+//                               quantise the new token into slot T of the stores (a decode step = two launches)
+//   decode_attn_merge_k         the same arithmetic as a chain of dependent loads (any number of splits)
+//   decode_attn_fused_mfma_k    opt-in single launch (in-workgroup merge + arrival ticket): measured slower
 #include <atomic>
 #include <type_traits>
 
