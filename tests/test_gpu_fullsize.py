@@ -200,3 +200,46 @@ def test_time_next_launch_binds_events_to_the_dequant_dispatch(K):
     K.dequant_tokens(q, s, out, "int4")
     torch.cuda.synchronize()
     assert ev[0].elapsed_time(ev[1]) == small
+
+
+def test_context_of_128k_tokens_quantise_dequantise_and_attend(K):
+    """Eight times the benchmark context (T = 131,072; Llama-3-8B row shape, 2 layers): the token-table kernels against
+    the reference's formulas recomputed with torch ops layer by layer, and the decode attention (streaming kernel by
+    size at batch 1, 2,048 tiles per kv head) against float64 attention over the dequantised store."""
+    G, B, H, T, D = 2, 1, 8, 131072, 128
+    g = torch.Generator(device="cuda").manual_seed(131072)
+    x = torch.randn(G, B, H, T, D, device="cuda", generator=g).half()
+    x[:, :, :, ::97, 5] *= 9.0
+    for kind, qmax, qmin in (("int8", 127.0, -127.0), ("int4", 7.0, -8.0)):
+        Dq = D if kind == "int8" else D // 2
+        q = torch.empty(G, B, H, T, Dq, dtype=K.QDTYPE[kind], device="cuda")
+        sc = torch.empty(G, T, dtype=torch.float32, device="cuda")
+        ws = torch.empty(G * T, dtype=torch.float32, device="cuda")
+        K.quant_tokens(x, q, sc, ws, kind)
+        out = torch.empty(G, B, H, T, D, dtype=torch.float16, device="cuda")
+        K.dequant_tokens(q, sc, out, kind)
+        for l in range(G):
+            qi, s32 = _torch_quant(x[l], qmax, qmin)
+            stored = s32.half().float()
+            assert torch.equal(sc[l], stored)
+            ints = q[l].view(torch.int8).to(torch.int16) if kind == "int8" else _torch_unpack(q[l])
+            assert torch.equal(ints, qi.to(torch.int16))
+            ref = (qi.float() * stored[None, None, :, None]).half()
+            assert torch.equal(out[l].view(torch.int16), ref.view(torch.int16))
+    # attention over layer 0 of the INT4 store (values) and a fresh INT8 store (keys)
+    kq = torch.empty(1, B, H, T, D, dtype=torch.int8, device="cuda")
+    ks = torch.empty(1, T, dtype=torch.float32, device="cuda")
+    K.quant_tokens(x[1:2], kq, ks, torch.empty(T, dtype=torch.float32, device="cuda"), "int8")
+    Hq = 32
+    qv = torch.randn(B, Hq, D, device="cuda", generator=g).half()
+    o = torch.full((B, Hq, D), float("nan"), dtype=torch.float16, device="cuda")
+    wsa = torch.empty(K.decode_attn_workspace(B, Hq, H, T, D), dtype=torch.float32, device="cuda")
+    K.decode_attn(qv, kq[0], ks[0], "int8", q[0], sc[0], "int4", T, o, wsa, D ** -0.5, None, None)
+    kd = torch.empty(1, B, H, T, D, dtype=torch.float16, device="cuda")
+    K.dequant_tokens(kq, ks, kd, "int8")
+    kf, vf = kd[0, 0].double(), out[0, 0].double()
+    s = torch.einsum("hqd,htd->hqt", qv[0].double().view(H, Hq // H, D), kf) * D ** -0.5
+    ref = torch.einsum("hqt,htd->hqd", torch.softmax(s, dim=-1), vf).reshape(Hq, D)
+    got = o[0].double()
+    assert torch.isfinite(got).all()
+    assert bool(((got - ref).abs() <= 2e-3 * (ref.abs() + ref.abs().max())).all())
