@@ -106,6 +106,44 @@ __global__ __launch_bounds__(64) void read_chunk_rows_k(const u32x4* __restrict_
   for (int i = 0; i < 16; ++i) acc ^= x[i];
   if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
 }
+// The quantise kernels' memory traffic without their arithmetic, two tile shapes (input [8 heads][T][128] fp16, 4 MiB
+// per head; INT4 output [8][T][64] bytes):
+//   COOP = false: one-wave workgroup = 4 tokens x 8 heads: 8 loads of 1 KiB (one per head), 2 stores covering 8
+//                 pieces of 256 B (what quant_tokens_fused_k does)
+//   COOP = true:  8-wave workgroup = 32 tokens x 8 heads, wave w = head w: 8 loads covering 8 KiB contiguous, one
+//                 barrier (the abs-max exchange), 2 stores covering 2 KiB contiguous
+template <bool COOP>
+__global__ __launch_bounds__(COOP ? 512 : 64) void rw_quant_tile_k(const u32x4* __restrict__ in, u32x4* __restrict__ out, int64_t head_vec_in,
+                                                                   int64_t head_vec_out) {
+  __shared__ uint32_t s_x[8];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  u32x4 x[8];
+  if (COOP) {
+    const u32x4* p = in + (int64_t)wave * head_vec_in + (int64_t)blockIdx.x * 512 + lane;  // 32 tokens x 16 vectors
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = __builtin_nontemporal_load(p + i * 64);
+  } else {
+    const u32x4* p = in + (int64_t)blockIdx.x * 64 + lane;  // 4 tokens x 16 vectors per head
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = __builtin_nontemporal_load(p + (int64_t)i * head_vec_in);
+  }
+  u32x4 acc = x[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) acc ^= x[i];
+  if (COOP) {
+    if (lane == 0) s_x[wave] = acc[0];
+    __syncthreads();
+    acc[1] ^= s_x[(wave + 1) & 7];
+    u32x4* q = out + (int64_t)wave * head_vec_out + (int64_t)blockIdx.x * 128 + lane;  // 32 tokens x 4 vectors
+    __builtin_nontemporal_store(acc, q);
+    __builtin_nontemporal_store(acc ^ x[3], q + 64);
+  } else {
+    // 8 pieces of 256 B = 16 lanes each: lane -> (head = lane / 16 + 4 j, vector lane % 16)
+    u32x4* q = out + (int64_t)blockIdx.x * 16 + (lane & 15u);
+    __builtin_nontemporal_store(acc, q + (int64_t)(lane >> 4) * head_vec_out);
+    __builtin_nontemporal_store(acc ^ x[3], q + (int64_t)((lane >> 4) + 4) * head_vec_out);
+  }
+}
 // write ceiling with the launch shape of the dequantise kernel: one-wave workgroup w fills the contiguous chunk w of
 // VEC 16-byte vectors (non-temporal or write-back stores)
 template <int VEC, bool NT>
@@ -345,6 +383,16 @@ int main(int argc, char** argv) {
       printf("permprobe %s:", names[k]);
       for (int l = 0; l < 64; l += 8) printf(" l%d=%u", l, h[64 * k + l]);
       printf("\n");
+    }
+  }
+  if (what == "quantpat") {  // the quantise kernels' loads + stores without arithmetic: one-wave tiles vs head-per-wave tiles
+    const int64_t T_all = N / (8 * 128);           // tokens if the 1 GiB input were one [8][T][128] tensor
+    const int64_t head_vec_in = T_all * 16, head_vec_out = T_all * 4;
+    for (int rep = 0; rep < 3; ++rep) {
+      double ms = tm.ms_per([&] { rotate(); rw_quant_tile_k<false><<<(unsigned)(T_all / 4), 64>>>((const u32x4*)in16, (u32x4*)out, head_vec_in, head_vec_out); }, iters);
+      printf("calib quantpat one-wave tile (8 x 1 KiB in, 8 x 256 B out)        %8.3f ms  %8.1f GB/s (r+w, INT4 mix)\n", ms, 2.5 * N / ms / 1e6);
+      ms = tm.ms_per([&] { rotate(); rw_quant_tile_k<true><<<(unsigned)(T_all / 32), 512>>>((const u32x4*)in16, (u32x4*)out, head_vec_in, head_vec_out); }, iters);
+      printf("calib quantpat head-per-wave tile (8 KiB in, 2 KiB out per wave)  %8.3f ms  %8.1f GB/s (r+w, INT4 mix)\n", ms, 2.5 * N / ms / 1e6);
     }
   }
   if (what == "poolpat") {  // one chunk per one-wave workgroup vs the shipped kernel's pattern
