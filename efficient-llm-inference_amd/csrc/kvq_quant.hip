@@ -93,6 +93,7 @@ __device__ inline uint32_t group_umax(uint32_t v, int logw) {
 // without the guard / exact redo, 2 = no arithmetic at all (raw input bits are packed) — they bound
 // what the guard and the whole quotient cost on top of the tile's memory traffic. 3 = 2 without the
 // stores, 4 = 2 without the loads (f16 / bf16 inputs only): the tile pattern's read-only and write-only rates.
+// 5 = 2 without the per-token scale store, 6 = 5 without the abs-max result and the two divides (one-wave REGMAX tiles).
 #ifndef KVQ_QUANT_CALIB
 #define KVQ_QUANT_CALIB 0
 #endif
@@ -224,10 +225,19 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
       uint32_t mp = group_umax(m[p], a.dvshift);  // across the D/8 lanes of the token
       if constexpr (RM == 1)
         for (int sh = a.vshift; sh < 6; ++sh) mp = max(mp, (uint32_t)__shfl_xor((int)mp, 1 << sh));  // row run < one wave
+#if KVQ_QUANT_CALIB == 6  // calibration: no abs-max reduction result, no divides
+      reg_s32[p] = 1.0f + (float)(mp & 1u);
+      reg_rcp[p] = reg_s32[p];
+#else
       reg_s32[p] = fmaxf(Vec8<IDT>::bits_to_f32(mp) / QRange<BITS>::qmax, a.eps);
       reg_rcp[p] = 1.0f / reg_s32[p];
+#endif
       const uint32_t wv = (uint32_t)(p * BLK) + tid;  // this lane's vector in the row run, rounds i % RM == p
+#if KVQ_QUANT_CALIB == 5 || KVQ_QUANT_CALIB == 6  // calibration: the per-token scale store never executes
+      if ((tid & (DV - 1u)) == 0u && (RM > 1 || (tid >> a.vshift) == 0u) && a.eps < 0.0f)
+#else
       if ((tid & (DV - 1u)) == 0u && (RM > 1 || (tid >> a.vshift) == 0u))
+#endif
         a.scales[(int64_t)g * a.ssg + t0 + ((wv & wmask) >> a.dvshift)] = Elem<IDT>::round_trip(reg_s32[p]);
     }
   } else {

@@ -112,7 +112,42 @@ __global__ __launch_bounds__(64) void read_chunk_rows_k(const u32x4* __restrict_
 //                 pieces of 256 B (what quant_tokens_fused_k does)
 //   COOP = true:  8-wave workgroup = 32 tokens x 8 heads, wave w = head w: 8 loads covering 8 KiB contiguous, one
 //                 barrier (the abs-max exchange), 2 stores covering 2 KiB contiguous
-template <bool COOP>
+// NVALU: dependent-free filler vector instructions between the loads' arrival and the stores (how much of the
+// quantise kernel's ~500 vector instructions per wave the memory pipeline feels)
+// one-wave tile + the real kernel's other habits: LDSOUT = the packed output goes through an LDS image (8 ds_write_b32,
+// 2 ds_read_b128) before the two stores; CHAIN = that many dependent scalar loads (pointer chasing through a tiny
+// device table) before the first data load, like the kernel's kernarg -> pointer table -> strides prologue
+template <bool LDSOUT, int CHAIN>
+__global__ __launch_bounds__(64) void rw_quant_tile2_k(const u32x4* const* __restrict__ table, u32x4* __restrict__ out, int64_t head_vec_in,
+                                                       int64_t head_vec_out) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_o[512];
+  const uint32_t lane = threadIdx.x;
+  const u32x4* const* t = table;
+#pragma unroll
+  for (int c = 1; c < CHAIN; ++c) t = reinterpret_cast<const u32x4* const*>(__builtin_nontemporal_load(reinterpret_cast<const uintptr_t*>(t) + 1));
+  const u32x4* in = t[0];
+  const u32x4* p = in + (int64_t)blockIdx.x * 64 + lane;
+  u32x4 x[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = __builtin_nontemporal_load(p + (int64_t)i * head_vec_in);
+  u32x4 a0, a1;
+  if (LDSOUT) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s_o[i * 64 + lane] = x[i][0] ^ x[i][1] ^ x[i][2] ^ x[i][3];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    a0 = *reinterpret_cast<const u32x4*>(&s_o[lane * 4]);
+    a1 = *reinterpret_cast<const u32x4*>(&s_o[256 + lane * 4]);
+  } else {
+    a0 = x[0] ^ x[1] ^ x[2] ^ x[3];
+    a1 = x[4] ^ x[5] ^ x[6] ^ x[7];
+  }
+  u32x4* q = out + (int64_t)blockIdx.x * 16 + (lane & 15u);
+  __builtin_nontemporal_store(a0, q + (int64_t)(lane >> 4) * head_vec_out);
+  __builtin_nontemporal_store(a1, q + (int64_t)((lane >> 4) + 4) * head_vec_out);
+}
+template <bool COOP, int NVALU = 0>
 __global__ __launch_bounds__(COOP ? 512 : 64) void rw_quant_tile_k(const u32x4* __restrict__ in, u32x4* __restrict__ out, int64_t head_vec_in,
                                                                    int64_t head_vec_out) {
   __shared__ uint32_t s_x[8];
@@ -130,6 +165,16 @@ __global__ __launch_bounds__(COOP ? 512 : 64) void rw_quant_tile_k(const u32x4* 
   u32x4 acc = x[0];
 #pragma unroll
   for (int i = 1; i < 8; ++i) acc ^= x[i];
+  if constexpr (NVALU > 0) {
+    float f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = __uint_as_float(x[k][0] & 0x3FFFFFFFu);
+#pragma unroll
+    for (int it = 0; it < NVALU / 8; ++it)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = __builtin_fmaf(f[k], 1.0009765625f, 0.5f);  // 8 independent chains
+    acc[2] ^= __float_as_uint(((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7])));
+  }
   if (COOP) {
     if (lane == 0) s_x[wave] = acc[0];
     __syncthreads();
@@ -393,6 +438,25 @@ int main(int argc, char** argv) {
       printf("calib quantpat one-wave tile (8 x 1 KiB in, 8 x 256 B out)        %8.3f ms  %8.1f GB/s (r+w, INT4 mix)\n", ms, 2.5 * N / ms / 1e6);
       ms = tm.ms_per([&] { rotate(); rw_quant_tile_k<true><<<(unsigned)(T_all / 32), 512>>>((const u32x4*)in16, (u32x4*)out, head_vec_in, head_vec_out); }, iters);
       printf("calib quantpat head-per-wave tile (8 KiB in, 2 KiB out per wave)  %8.3f ms  %8.1f GB/s (r+w, INT4 mix)\n", ms, 2.5 * N / ms / 1e6);
+#define RUN_NV(NV)                                                                                                 \
+  ms = tm.ms_per([&] { rotate(); rw_quant_tile_k<false, NV><<<(unsigned)(T_all / 4), 64>>>((const u32x4*)in16, (u32x4*)out, head_vec_in, head_vec_out); }, iters); \
+  printf("calib quantpat one-wave tile + %4d filler vector instructions       %8.3f ms  %8.1f GB/s (r+w, INT4 mix)\n", NV, ms, 2.5 * N / ms / 1e6);
+      RUN_NV(128) RUN_NV(256) RUN_NV(512) RUN_NV(1024)
+#undef RUN_NV
+      {
+        // pointer table: slot 0 = the data pointer, slot 1 = address of the next table (all the same table)
+        static uintptr_t* d_tab[2] = {nullptr, nullptr};
+        for (int b = 0; b < 2; ++b) {
+          if (!d_tab[b]) HIP_OK(hipMalloc(&d_tab[b], 16));
+          const uintptr_t h[2] = {(uintptr_t)in16s[b], (uintptr_t)d_tab[b]};
+          HIP_OK(hipMemcpy(d_tab[b], h, 16, hipMemcpyHostToDevice));
+        }
+#define RUN_T2(L, C)                                                                                               \
+  ms = tm.ms_per([&] { rotate(); rw_quant_tile2_k<L, C><<<(unsigned)(T_all / 4), 64>>>((const u32x4* const*)d_tab[rot % 2], (u32x4*)out, head_vec_in, head_vec_out); }, iters); \
+  printf("calib quantpat one-wave tile, LDS-staged output=%d, %d dependent scalar loads first  %8.3f ms  %8.1f GB/s\n", (int)L, C, ms, 2.5 * N / ms / 1e6);
+        RUN_T2(false, 1) RUN_T2(true, 1) RUN_T2(false, 3) RUN_T2(false, 5) RUN_T2(true, 4)
+#undef RUN_T2
+      }
     }
   }
   if (what == "poolpat") {  // one chunk per one-wave workgroup vs the shipped kernel's pattern
