@@ -45,6 +45,7 @@ Tunables& tunables() {
     d.attn_mfma_tc = 128;
     d.nt_loads = 1;
     d.quant_nt_stores = -1;
+    d.quant_geo128 = 1;
     d.attn_k_i8 = -1;
     d.attn_merge_fast = 1;
     d.attn_stream_roll = 1;
@@ -75,6 +76,7 @@ static const TunableKey kTunableKeys[] = {
     {"quant_lds_pad", &Tunables::quant_lds_pad},
     {"quant_tpw", &Tunables::quant_tpw},
     {"quant_nt_stores", &Tunables::quant_nt_stores},
+    {"quant_geo128", &Tunables::quant_geo128},
     {"attn_force_valu", &Tunables::attn_force_valu},
     {"attn_mfma_min_nq", &Tunables::attn_mfma_min_nq},
     {"attn_mfma_tc", &Tunables::attn_mfma_tc},

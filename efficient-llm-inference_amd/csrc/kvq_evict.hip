@@ -133,7 +133,9 @@ struct PoolBatch {
 // Fast path: D % 8 == 0, 16-byte aligned rows. One lane owns 8 consecutive d of one output
 // token; the D/8 lanes of a token read one contiguous row per step. fp32 accumulation is
 // sequential in t (bit-reproducible, mirrored by the oracle).
-template <int DT>
+// NTL: non-temporal loads, a COMPILE-TIME choice (a run-time `if (flag) load_nt else load` is merged by the compiler into
+// plain loads: until the end of round 2 this kernel never issued a non-temporal load, whatever the tunable said)
+template <int DT, bool NTL = true>
 __global__ __launch_bounds__(kBlock) void chunk_pool_vec_k(const PoolArgs a, uint32_t items_per_g) {
   constexpr int NB = PoolBatch<DT>::n;
   const uint32_t g = blockIdx.y;
@@ -166,12 +168,10 @@ __global__ __launch_bounds__(kBlock) void chunk_pool_vec_k(const PoolArgs a, uin
     uint32_t i = 0;
     for (; i + NB <= n; i += NB) {
       Vec8<DT> x[NB];
-      if (a.nt_loads) {
 #pragma unroll
-        for (int u = 0; u < NB; ++u) x[u].load_nt(p + (int64_t)(i + u) * tstride);
-      } else {
-#pragma unroll
-        for (int u = 0; u < NB; ++u) x[u].load(p + (int64_t)(i + u) * tstride);
+      for (int u = 0; u < NB; ++u) {
+        if constexpr (NTL) x[u].load_nt(p + (int64_t)(i + u) * tstride);
+        else x[u].load(p + (int64_t)(i + u) * tstride);
       }
 #pragma unroll
       for (int u = 0; u < NB; ++u)
@@ -518,9 +518,18 @@ int kvq_chunk_meanpool(const void* in_base, const void* const* in_ptrs, const kv
       }
       const unsigned blocks = (unsigned)want;
       switch (dtype) {
-        case KVQ_F16: hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_F16>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec); break;
-        case KVQ_BF16: hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_BF16>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec); break;
-        case KVQ_F32: hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_F32>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec); break;
+        case KVQ_F16:
+          if (a.nt_loads) hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_F16, true>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec);
+          else hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_F16, false>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec);
+          break;
+        case KVQ_BF16:
+          if (a.nt_loads) hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_BF16, true>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec);
+          else hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_BF16, false>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec);
+          break;
+        case KVQ_F32:
+          if (a.nt_loads) hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_F32, true>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec);
+          else hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_F32, false>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec);
+          break;
       }
     } else {
       int64_t blocks = (items_gen + kBlock - 1) / kBlock;

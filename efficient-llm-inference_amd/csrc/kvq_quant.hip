@@ -50,7 +50,7 @@ struct QuantArgs {
   uint32_t vpr;      // sweep kernel, same case: TT * D/8 vectors per row run
   uint32_t t_begin;  // first token of this launch's first tile
   int32_t nt_loads;  // non-temporal input loads
-  int32_t nt_stores; // non-temporal output stores (tunable quant_nt_stores; -1 = follow nt_loads)
+  int32_t nt_stores; // non-temporal output stores (tunable quant_nt_stores; -1 = INT8 yes, INT4 no)
   int32_t blk;       // workgroup size of the fused kernel (256, or 64 = one wave per tile)
   int32_t nv;        // vectors per lane per tile (8, or 4 for the small one-wave tile)
   int32_t bh_contig; // rows addressable as r * stride_h on both sides
@@ -163,20 +163,29 @@ __device__ inline uint32_t pack_i4(const uint32_t (&qb)[8]) {
 // register max (plus one lane exchange per halving of the row run below 64 vectors), the scale is
 // computed per lane, and the kernel needs no LDS, atomics or barriers for it.
 // NV: 16-byte vectors per lane per tile (tile = BLK * NV * 8 elements).
-template <int IDT, int BITS, bool ROWU, bool LDS_OUT, bool FULL, int BLK = kBlock, int REGMAX = 0, int NV = kNVMax>
+// GEO128: the tile geometry of the Llama prefill shape as compile-time constants (8 rows of head_dim 128, 4 tokens per
+// one-wave tile: 64 vectors per row run, 16 lanes per token) instead of kernel arguments — the same code with its
+// shifts, masks and lane-exchange loops folded.
+// NTL / NTS: non-temporal input loads / output stores, COMPILE-TIME (a run-time `if (flag) nt_load else load` is merged
+// by the compiler into one plain load: the kernel ran without non-temporal accesses until the end of round 2).
+template <int IDT, int BITS, bool ROWU, bool LDS_OUT, bool FULL, int BLK = kBlock, int REGMAX = 0, int NV = kNVMax, bool GEO128 = false,
+          bool NTL = true, bool NTS = true>
 __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
+  static_assert(!GEO128 || (BLK == 64 && NV == 8 && REGMAX == 1 && ROWU && FULL), "GEO128: the one-wave register-max tile");
+  const uint32_t g_vshift = GEO128 ? 6u : a.vshift, g_dvshift = GEO128 ? 4u : a.dvshift, g_TT = GEO128 ? 4u : a.TT;
+  const uint32_t g_R = GEO128 ? 8u : a.R, g_D = GEO128 ? 128u : a.D, g_nvec = GEO128 ? 512u : a.nvec;
   __shared__ __attribute__((aligned(16))) uint32_t s_out[LDS_OUT ? BLK * NV * 8 * BITS / 32 : 4];
   __shared__ uint32_t s_amax[kMaxTT];
   __shared__ float s_scale[kMaxTT], s_rcp[kMaxTT];
   const uint32_t tid = threadIdx.x;
   const uint32_t g = blockIdx.y;
-  const uint32_t t0 = a.t_begin + xcd_grouped_item(blockIdx.x, a.xcd_group, gridDim.x) * a.TT;
-  const uint32_t DV = a.D >> 3;
-  const uint32_t wmask = (1u << a.vshift) - 1u;
+  const uint32_t t0 = a.t_begin + (GEO128 ? blockIdx.x : xcd_grouped_item(blockIdx.x, a.xcd_group, gridDim.x)) * g_TT;
+  const uint32_t DV = g_D >> 3;
+  const uint32_t wmask = (1u << g_vshift) - 1u;
   // is.t == D and qs.t == Dq (or a single token per tile), so within a row the tile is one
   // contiguous run: element offset = wv * 8
-  const char* in = reinterpret_cast<const char*>(a.in.p[g]) + (int64_t)t0 * a.is.t * Elem<IDT>::size;
-  uint8_t* qbase = a.q + (int64_t)g * a.qs.g + (int64_t)t0 * a.qs.t;
+  const char* in = reinterpret_cast<const char*>(a.in.p[g]) + (int64_t)t0 * (GEO128 ? 128 : a.is.t) * Elem<IDT>::size;
+  uint8_t* qbase = a.q + (int64_t)g * a.qs.g + (int64_t)t0 * (GEO128 ? (int64_t)(128 * BITS / 8) : a.qs.t);
   constexpr int QV = BITS;  // bytes stored per 8-element vector: 8 (INT8) or 4 (INT4)
 
   if constexpr (REGMAX == 0) {
@@ -191,21 +200,21 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
   for (int i = 0; i < NV; ++i) {
     uint32_t r, wv;
     if constexpr (ROWU) {
-      r = (uint32_t)(i * BLK) >> a.vshift;
+      r = (uint32_t)(i * BLK) >> g_vshift;
       wv = ((uint32_t)(i * BLK) & wmask) + tid;
     } else {
       const uint32_t v = i * BLK + tid;
-      r = v >> a.vshift;
+      r = v >> g_vshift;
       wv = v & wmask;
     }
-    valid[i] = FULL || (((uint32_t)(i * BLK) + tid < a.nvec) && (t0 + (wv >> a.dvshift) < a.T));
+    valid[i] = FULL || (((uint32_t)(i * BLK) + tid < g_nvec) && (t0 + (wv >> g_dvshift) < a.T));
     if (valid[i]) {
       const char* src = in + ((int64_t)r * a.is.h + (int64_t)wv * 8) * Elem<IDT>::size;
 #if KVQ_QUANT_CALIB == 4  // write-only pattern: no loads (the branch on eps is never taken)
       if (a.eps < 0.0f) x[i].load(src);
       else if constexpr (IDT != KVQ_F32) x[i].w = u32x4{tid, (uint32_t)i, r, wv};
 #else
-      if (a.nt_loads) x[i].load_nt(src);
+      if constexpr (NTL) x[i].load_nt(src);
       else x[i].load(src);
 #endif
     }
@@ -222,9 +231,9 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
     for (int i = 0; i < NV; ++i) m[i % RM] = max(m[i % RM], x[i].absmax_bits());  // across the tile's rows
 #pragma unroll
     for (int p = 0; p < RM; ++p) {
-      uint32_t mp = group_umax(m[p], a.dvshift);  // across the D/8 lanes of the token
+      uint32_t mp = group_umax(m[p], g_dvshift);  // across the D/8 lanes of the token
       if constexpr (RM == 1)
-        for (int sh = a.vshift; sh < 6; ++sh) mp = max(mp, (uint32_t)__shfl_xor((int)mp, 1 << sh));  // row run < one wave
+        for (int sh = g_vshift; sh < 6; ++sh) mp = max(mp, (uint32_t)__shfl_xor((int)mp, 1 << sh));  // row run < one wave
 #if KVQ_QUANT_CALIB == 6  // calibration: no abs-max reduction result, no divides
       reg_s32[p] = 1.0f + (float)(mp & 1u);
       reg_rcp[p] = reg_s32[p];
@@ -234,26 +243,26 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
 #endif
       const uint32_t wv = (uint32_t)(p * BLK) + tid;  // this lane's vector in the row run, rounds i % RM == p
 #if KVQ_QUANT_CALIB == 5 || KVQ_QUANT_CALIB == 6  // calibration: the per-token scale store never executes
-      if ((tid & (DV - 1u)) == 0u && (RM > 1 || (tid >> a.vshift) == 0u) && a.eps < 0.0f)
+      if ((tid & (DV - 1u)) == 0u && (RM > 1 || (tid >> g_vshift) == 0u) && a.eps < 0.0f)
 #else
-      if ((tid & (DV - 1u)) == 0u && (RM > 1 || (tid >> a.vshift) == 0u))
+      if ((tid & (DV - 1u)) == 0u && (RM > 1 || (tid >> g_vshift) == 0u))
 #endif
-        a.scales[(int64_t)g * a.ssg + t0 + ((wv & wmask) >> a.dvshift)] = Elem<IDT>::round_trip(reg_s32[p]);
+        a.scales[(int64_t)g * a.ssg + t0 + ((wv & wmask) >> g_dvshift)] = Elem<IDT>::round_trip(reg_s32[p]);
     }
   } else {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      if (FULL || (uint32_t)(i * BLK) < a.nvec) {  // uniform: whole waves reach the lane exchanges
+      if (FULL || (uint32_t)(i * BLK) < g_nvec) {  // uniform: whole waves reach the lane exchanges
         const uint32_t wv = ((uint32_t)(i * BLK) + tid) & wmask;
         uint32_t m = valid[i] ? x[i].absmax_bits() : 0u;
-        m = group_umax(m, a.dvshift);  // the D/8 lanes of one (row, token)
-        if (valid[i] && (wv & (DV - 1u)) == 0u) atomicMax(&s_amax[wv >> a.dvshift], m);
+        m = group_umax(m, g_dvshift);  // the D/8 lanes of one (row, token)
+        if (valid[i] && (wv & (DV - 1u)) == 0u) atomicMax(&s_amax[wv >> g_dvshift], m);
       }
     }
     __syncthreads();
 
     // per-token scale, its reciprocal (both IEEE divides, once per token) and the stored scale
-    if (tid < a.TT && (FULL || t0 + tid < a.T)) {
+    if (tid < g_TT && (FULL || t0 + tid < a.T)) {
       const float amax = Vec8<IDT>::bits_to_f32(s_amax[tid]);
       const float s32 = fmaxf(amax / QRange<BITS>::qmax, a.eps);
       s_scale[tid] = s32;
@@ -269,20 +278,20 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
     if (!FULL && !valid[i]) continue;
     uint32_t r, wv;
     if constexpr (ROWU) {
-      r = (uint32_t)(i * BLK) >> a.vshift;
+      r = (uint32_t)(i * BLK) >> g_vshift;
       wv = ((uint32_t)(i * BLK) & wmask) + tid;
     } else {
       const uint32_t v = i * BLK + tid;
-      r = v >> a.vshift;
+      r = v >> g_vshift;
       wv = v & wmask;
     }
-    const uint32_t tl = wv >> a.dvshift;
+    const uint32_t tl = wv >> g_dvshift;
     uint32_t qb[8];
     if constexpr (REGMAX > 0) quotient_bits8<BITS>(x[i], reg_s32[i % RM], reg_rcp[i % RM], qb);
     else quotient_bits8<BITS>(x[i], s_scale[tl], s_rcp[tl], qb);
     if constexpr (LDS_OUT) {
       // stage the packed bytes in LDS in output order (row-major, wv * QV within the row run)
-      const uint32_t widx = ((r << a.vshift) + wv) * (QV / 4);
+      const uint32_t widx = ((r << g_vshift) + wv) * (QV / 4);
       if constexpr (BITS == 8) {
         const u32x2 w = pack_i8(qb);
         s_out[widx] = w[0];
@@ -301,12 +310,12 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
     // 16 B per lane, 1 KiB contiguous per wave store: each row of the tile is one run of
     // TT * Dq bytes in the store (ablation: the direct 4 B/lane stores cost ~100 us of 354)
     __syncthreads();
-    const uint32_t row_shift = a.vshift + (BITS == 8 ? 3 : 2);  // log2(bytes per full row run)
+    const uint32_t row_shift = g_vshift + (BITS == 8 ? 3 : 2);  // log2(bytes per full row run)
     const uint32_t row_bytes = 1u << row_shift;
-    uint32_t nt = FULL ? a.TT : a.T - t0;
-    if (nt > a.TT) nt = a.TT;
-    const uint32_t valid_bytes = nt * (a.D * BITS / 8);  // ragged last tile: shorter runs
-    const uint32_t total = a.R << row_shift;
+    uint32_t nt = FULL ? g_TT : a.T - t0;
+    if (nt > g_TT) nt = g_TT;
+    const uint32_t valid_bytes = nt * (g_D * BITS / 8);  // ragged last tile: shorter runs
+    const uint32_t total = g_R << row_shift;
     for (uint32_t k = tid * 16u; k < total; k += BLK * 16u) {
       const uint32_t r = k >> row_shift;
       const uint32_t off = k & (row_bytes - 1u);
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
       if (off < valid_bytes) {
 #endif
         const u32x4 w = *reinterpret_cast<const u32x4*>(&s_out[k >> 2]);
-        if (a.nt_stores) __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off));
+        if constexpr (NTS) __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off));
         else *reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off) = w;
       }
     }
@@ -351,8 +360,7 @@ __global__ __launch_bounds__(kWave) void quant_tokens_pipe_k(const QuantArgs a) 
     const char* src = in_g + ((int64_t)(a.t_begin + tile * a.TT) * a.is.t + (int64_t)lane * 8) * Elem<IDT>::size;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      if (a.nt_loads) x[r].load_nt(src + (int64_t)r * a.is.h * Elem<IDT>::size);
-      else x[r].load(src + (int64_t)r * a.is.h * Elem<IDT>::size);
+      x[r].load_nt(src + (int64_t)r * a.is.h * Elem<IDT>::size);
     }
   };
   auto process_tile = [&](uint32_t tile, const Vec8<IDT> (&x)[R]) {
@@ -386,8 +394,7 @@ __global__ __launch_bounds__(kWave) void quant_tokens_pipe_k(const QuantArgs a) 
     for (uint32_t k = lane * 16u; k < (uint32_t)R * kRowBytes; k += 64u * 16u) {
       const uint32_t r = k / kRowBytes, off = k % kRowBytes;
       const u32x4 w = *reinterpret_cast<const u32x4*>(&s_out[k >> 2]);
-      if (a.nt_stores) __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off));
-      else *reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off) = w;
+      __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(qbase + (int64_t)r * a.qs.h + off));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next tile's staging writes stay below these reads
     __builtin_amdgcn_wave_barrier();
@@ -701,7 +708,20 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
         QuantArgs f = a;
         f.t_begin = piped * a.TT;
         const dim3 grid(n_small, a.G);
-        if (a.blk == 64 && regmax)  // quant_lds_pad: occupancy A-B only (dynamic LDS the kernel never touches)
+        if (a.blk == 64 && regmax && IDT != KVQ_F32 && a.R == 8u && a.D == 128u && a.TT == 4u && a.vshift == 6 && a.dvshift == 4 &&
+            a.is.t == 128 && a.qs.t == 128 * BITS / 8 && !a.xcd_group && !tunables().quant_lds_pad && tunables().quant_geo128)
+        {  // nt_loads / quant_nt_stores pick the instantiation (A-B knobs; both non-temporal is what ships)
+          constexpr bool kGeo = IDT != KVQ_F32;
+          if (a.nt_loads && a.nt_stores)
+            hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, 1, kNVMax, kGeo, true, true>), grid, dim3(64), 0, st, f);
+          else if (a.nt_loads)
+            hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, 1, kNVMax, kGeo, true, false>), grid, dim3(64), 0, st, f);
+          else if (a.nt_stores)
+            hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, 1, kNVMax, kGeo, false, true>), grid, dim3(64), 0, st, f);
+          else
+            hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, 1, kNVMax, kGeo, false, false>), grid, dim3(64), 0, st, f);
+        }
+        else if (a.blk == 64 && regmax)  // quant_lds_pad: occupancy A-B only (dynamic LDS the kernel never touches)
           hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, true>), grid, dim3(64),
                              (size_t)tunables().quant_lds_pad, st, f);
         else if (a.blk == 64)
@@ -815,7 +835,9 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
   a.blk = kBlock;
   a.nv = kNVMax;
   a.nt_loads = (int32_t)tunables().nt_loads;
-  a.nt_stores = tunables().quant_nt_stores < 0 ? a.nt_loads : (int32_t)(tunables().quant_nt_stores != 0);
+  // -1 (default): what measured fastest once the accesses really were non-temporal — INT8's 512-byte output pieces
+  // non-temporal, INT4's 256-byte pieces write-back (0.228-0.231 vs 0.233-0.237 ms; INT8: 0.269-0.272 vs 0.302-0.304 ms)
+  a.nt_stores = tunables().quant_nt_stores < 0 ? (a.nt_loads && BITS == 8 ? 1 : 0) : (int32_t)(tunables().quant_nt_stores != 0);
   a.bh_contig = bh_contig ? 1 : 0;
   a.xcd_group = (uint32_t)(tunables().quant_xcd_group > 1 ? tunables().quant_xcd_group : 0);
   if (fused && anydv) {

@@ -147,6 +147,21 @@ __global__ __launch_bounds__(64) void rw_quant_tile2_k(const u32x4* const* __res
   __builtin_nontemporal_store(a0, q + (int64_t)(lane >> 4) * head_vec_out);
   __builtin_nontemporal_store(a1, q + (int64_t)((lane >> 4) + 4) * head_vec_out);
 }
+// the one-wave tile with the REAL tensors' strides: input [G][8][T][128] fp16, output [G][8][T][64] bytes
+// (blockIdx.x = tile of 4 tokens in the group, blockIdx.y = group): heads 4 MiB apart on the input side and 1 MiB
+// apart on the output side instead of the flat microbench's 128 MiB / 32 MiB
+__global__ __launch_bounds__(64) void rw_quant_tile_real_k(const u32x4* __restrict__ in, u32x4* __restrict__ out, uint32_t T) {
+  const uint32_t lane = threadIdx.x;
+  const int64_t hv_in = (int64_t)T * 16, hv_out = (int64_t)T * 4;
+  const u32x4* p = in + (int64_t)blockIdx.y * 8 * hv_in + (int64_t)blockIdx.x * 64 + lane;
+  u32x4 x[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = __builtin_nontemporal_load(p + (int64_t)i * hv_in);
+  const u32x4 a0 = x[0] ^ x[1] ^ x[2] ^ x[3], a1 = x[4] ^ x[5] ^ x[6] ^ x[7];
+  u32x4* q = out + (int64_t)blockIdx.y * 8 * hv_out + (int64_t)blockIdx.x * 16 + (lane & 15u);
+  __builtin_nontemporal_store(a0, q + (int64_t)(lane >> 4) * hv_out);
+  __builtin_nontemporal_store(a1, q + (int64_t)((lane >> 4) + 4) * hv_out);
+}
 template <bool COOP, int NVALU = 0>
 __global__ __launch_bounds__(COOP ? 512 : 64) void rw_quant_tile_k(const u32x4* __restrict__ in, u32x4* __restrict__ out, int64_t head_vec_in,
                                                                    int64_t head_vec_out) {
@@ -438,6 +453,8 @@ int main(int argc, char** argv) {
       printf("calib quantpat one-wave tile (8 x 1 KiB in, 8 x 256 B out)        %8.3f ms  %8.1f GB/s (r+w, INT4 mix)\n", ms, 2.5 * N / ms / 1e6);
       ms = tm.ms_per([&] { rotate(); rw_quant_tile_k<true><<<(unsigned)(T_all / 32), 512>>>((const u32x4*)in16, (u32x4*)out, head_vec_in, head_vec_out); }, iters);
       printf("calib quantpat head-per-wave tile (8 KiB in, 2 KiB out per wave)  %8.3f ms  %8.1f GB/s (r+w, INT4 mix)\n", ms, 2.5 * N / ms / 1e6);
+      ms = tm.ms_per([&] { rotate(); rw_quant_tile_real_k<<<dim3((unsigned)(T / 4), (unsigned)G), 64>>>((const u32x4*)in16, (u32x4*)out, (uint32_t)T); }, iters);
+      printf("calib quantpat one-wave tile, the real tensors' strides (heads 4 MiB / 1 MiB apart)  %8.3f ms  %8.1f GB/s\n", ms, 2.5 * N / ms / 1e6);
 #define RUN_NV(NV)                                                                                                 \
   ms = tm.ms_per([&] { rotate(); rw_quant_tile_k<false, NV><<<(unsigned)(T_all / 4), 64>>>((const u32x4*)in16, (u32x4*)out, head_vec_in, head_vec_out); }, iters); \
   printf("calib quantpat one-wave tile + %4d filler vector instructions       %8.3f ms  %8.1f GB/s (r+w, INT4 mix)\n", NV, ms, 2.5 * N / ms / 1e6);
