@@ -1,0 +1,78 @@
+"""The cache hints the kernels are designed around must be IN THE ISA. A run-time `if (flag) nontemporal_load else load`
+is merged by the compiler into one plain load (the hint does not survive the merge): the quantise and pool kernels ran
+without a single non-temporal access for most of two rounds while their source, their tunables and their documentation
+said otherwise. This test compiles the device code of the two files to assembly (hipcc cross-compiles, no GPU) and
+looks at the instructions of the shipped instantiations."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "efficient-llm-inference_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _asm(tmp_path_factory, name):
+    if not shutil.which(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / (name + ".s")
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+                    "--offload-device-only", "-S", os.path.join(CSRC, name + ".hip"), "-o", str(out)],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    return out.read_text()
+
+
+def _kernel_body(asm, symbol_regex):
+    """Instructions of the first kernel whose mangled name matches."""
+    m = re.search(r"^(%s):[^\n]*\n(.*?)\n\s*s_endpgm" % symbol_regex, asm, flags=re.M | re.S)
+    assert m, "kernel not found: " + symbol_regex
+    return m.group(2)
+
+
+@pytest.fixture(scope="module")
+def quant_asm(tmp_path_factory):
+    return _asm(tmp_path_factory, "kvq_quant")
+
+
+@pytest.fixture(scope="module")
+def evict_asm(tmp_path_factory):
+    return _asm(tmp_path_factory, "kvq_evict")
+
+
+@pytest.mark.parametrize("bits,nt_store", [(4, False), (8, True)])
+def test_shipped_quantise_tile_issues_non_temporal_loads(quant_asm, bits, nt_store):
+    # quant_tokens_fused_k<f16, BITS, ROWU, LDS_OUT, FULL, 64, REGMAX = 1, NV = 8, GEO128, NTL = true, NTS = (BITS == 8)>
+    body = _kernel_body(quant_asm, r"_ZN3kvq20quant_tokens_fused_kILi0ELi%dELb1ELb1ELb1ELi64ELi1ELi8ELb1ELb1ELb%dEEEvNS_9QuantArgsE" % (bits, int(nt_store)))
+    loads = re.findall(r"global_load_dwordx4[^\n]*", body)
+    assert len(loads) == 8 and all(l.rstrip().endswith(" nt") for l in loads), loads
+    stores = re.findall(r"global_store_dwordx4[^\n]*", body)
+    assert stores and all(s.rstrip().endswith(" nt") == nt_store for s in stores), stores
+
+
+def test_pool_kernels_issue_non_temporal_loads(evict_asm):
+    wave = _kernel_body(evict_asm, r"_ZN3kvq17chunk_pool_wave_kILi0ELi4ELi16EEEvNS_8PoolArgsE")
+    loads = re.findall(r"buffer_load_dwordx4[^\n]*", wave)
+    assert len(loads) == 16 and all(l.rstrip().endswith(" nt") for l in loads), loads
+    vec_nt = _kernel_body(evict_asm, r"_ZN3kvq16chunk_pool_vec_kILi0ELb1EEEvNS_8PoolArgsEj")
+    vec_plain = _kernel_body(evict_asm, r"_ZN3kvq16chunk_pool_vec_kILi0ELb0EEEvNS_8PoolArgsEj")
+    # the unrolled batch of 16 loads carries the hint in one instantiation and not in the other (the tail loop's single
+    # load is a plain one in both)
+    assert len(re.findall(r"global_load_dwordx4[^\n]* nt\n", vec_nt + "\n")) >= 16
+    assert not re.findall(r"global_load_dwordx4[^\n]* nt\n", vec_plain + "\n")
+
+
+def test_shipped_dequantise_variants_store_non_temporally(tmp_path_factory):
+    asm = _asm(tmp_path_factory, "kvq_dequant")
+    # variant 21 (INT4): dequant_tokens_fast_k<f16, 4, LE 8, UNROLL 4, NT stores, LDS scales, plain loads, 64 threads>
+    i4 = _kernel_body(asm, r"_ZN3kvq21dequant_tokens_fast_kILi0ELi4ELi8ELi4ELb1ELb1ELb0ELi64EEEvNS_11DequantArgsE")
+    st = re.findall(r"global_store_dwordx4[^\n]*", i4)
+    assert st and all(s.rstrip().endswith(" nt") for s in st), st
+    # variant 23 (INT8): UNROLL 2, NT stores AND NT loads of the quantised bytes
+    i8 = _kernel_body(asm, r"_ZN3kvq21dequant_tokens_fast_kILi0ELi8ELi8ELi2ELb1ELb1ELb1ELi64EEEvNS_11DequantArgsE")
+    st = re.findall(r"global_store_dwordx4[^\n]*", i8)
+    assert st and all(s.rstrip().endswith(" nt") for s in st), st
+    ld = re.findall(r"global_load_dwordx2[^\n]*", i8)
+    assert ld and all(l.rstrip().endswith(" nt") for l in ld), ld
