@@ -216,6 +216,14 @@ __global__ __launch_bounds__(64) void fill_chunk_k(u32x4* __restrict__ out, uint
     else p[i * 64] = x;
   }
 }
+// fill through a buffer descriptor with an explicit cache-policy immediate (aux: 1 = sc0, 2 = nt, 16 = sc1 and sums)
+template <int AUX>
+__global__ __launch_bounds__(64) void fill_chunk_aux_k(u32x4* __restrict__ out, uint32_t v) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)blockIdx.x * 256, 0, 4096, 0x00020000);
+  const u32x4 x = {v, v + 1, v + 2, v + 3};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(x, rs, (i * 64 + threadIdx.x) * 16u, 0, AUX);
+}
 // The quantise tile's read pattern without anything else: one-wave workgroup w reads S segments of LVEC 16-byte
 // vectors, segment s at s * seg_stride + w * LVEC (S = 8 heads 4 MiB apart, L = tokens per tile * 256 B). All loads
 // of the workgroup are in flight together (non-temporal).
@@ -503,6 +511,21 @@ int main(int argc, char** argv) {
     RUN_FILL(64, true) RUN_FILL(128, true) RUN_FILL(256, true) RUN_FILL(512, true) RUN_FILL(1024, true)
     RUN_FILL(64, false) RUN_FILL(128, false) RUN_FILL(256, false) RUN_FILL(512, false) RUN_FILL(1024, false)
 #undef RUN_FILL
+  }
+  if (what == "fillaux") {  // 4 KiB per one-wave workgroup, every store cache policy
+    const int64_t bytes = N * 2;
+    const unsigned grid = (unsigned)(bytes / 4096);
+#define RUN_AUX(A)                                                                                               \
+  {                                                                                                               \
+    double best = 1e9;                                                                                            \
+    for (int rep = 0; rep < 3; ++rep) {                                                                           \
+      const double ms = tm.ms_per([&] { rotate(); fill_chunk_aux_k<A><<<grid, 64>>>((u32x4*)out, 7u); }, iters);  \
+      best = ms < best ? ms : best;                                                                               \
+    }                                                                                                             \
+    printf("calib fillaux aux=%2d (sc0=%d nt=%d sc1=%d)  %8.3f ms  %8.1f GB/s (w)\n", A, (A) & 1, ((A) >> 1) & 1, ((A) >> 4) & 1, best, 1.0 * bytes / best / 1e6); \
+  }
+    RUN_AUX(0) RUN_AUX(1) RUN_AUX(2) RUN_AUX(3) RUN_AUX(16) RUN_AUX(17) RUN_AUX(18) RUN_AUX(19)
+#undef RUN_AUX
   }
   if (what == "segread") {  // S strided segments per one-wave workgroup (the quantise tile) vs one contiguous chunk
     const int64_t bytes = N * 2;
