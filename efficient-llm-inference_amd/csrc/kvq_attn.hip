@@ -34,6 +34,12 @@
 
 #include "kvq_common.h"
 
+// cache policy of the K / V row loads (buffer-load aux immediate: 2 = non-temporal, what ships; `make calib_attn`
+// builds may override it for A-B runs)
+#ifndef KVQ_ATTN_KV_AUX
+#define KVQ_ATTN_KV_AUX 2
+#endif
+
 namespace kvq {
 
 constexpr int kAttnBlock = 256;
@@ -555,14 +561,14 @@ struct AttnTile {
       // the row offset rides in the VECTOR offset (one v_add): that is the operand the range check covers
       const uint32_t off = v_lane + row * (uint32_t)a.v_st;
       if constexpr (VB == 8) {
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(v_rsrc, off, 0, 2);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(v_rsrc, off, 0, KVQ_ATTN_KV_AUX);
         dst[j].w0 = v[0];
         dst[j].w1 = v[1];
       } else if constexpr (VB == 4) {
-        dst[j].w0 = __builtin_amdgcn_raw_buffer_load_b32(v_rsrc, off, 0, 2);
+        dst[j].w0 = __builtin_amdgcn_raw_buffer_load_b32(v_rsrc, off, 0, KVQ_ATTN_KV_AUX);
         dst[j].w1 = 0u;
       } else {
-        dst[j].w0 = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(v_rsrc, off, 0, 2);
+        dst[j].w0 = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(v_rsrc, off, 0, KVQ_ATTN_KV_AUX);
         dst[j].w1 = 0u;
       }
     }
@@ -589,11 +595,11 @@ struct AttnTile {
       for (int c = 0; c < NL; ++c) {
         const uint32_t off = k_lane + 16 * i * (uint32_t)a.k_st + 4 * CBK * c;
         if constexpr (CBK == 16) {
-          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, off, 0, 2);
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, off, 0, KVQ_ATTN_KV_AUX);
 #pragma unroll
           for (int j = 0; j < 4; ++j) raw[i][c][j] = v[j];
         } else {
-          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(k_rsrc, off, 0, 2);
+          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(k_rsrc, off, 0, KVQ_ATTN_KV_AUX);
           raw[i][c][0] = v[0];
           raw[i][c][1] = v[1];
         }
@@ -977,11 +983,11 @@ struct AttnStream {
     for (int c = 0; c < NL; ++c) {
       const uint32_t off = k_lane + 16 * i * (uint32_t)a.k_st + 4 * CBK * c;
       if constexpr (CBK == 16) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(s.k, off, 0, 2);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(s.k, off, 0, KVQ_ATTN_KV_AUX);
 #pragma unroll
         for (int j = 0; j < 4; ++j) r.k[i][c][j] = v[j];
       } else {
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(s.k, off, 0, 2);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(s.k, off, 0, KVQ_ATTN_KV_AUX);
         r.k[i][c][0] = v[0];
         r.k[i][c][1] = v[1];
       }
@@ -995,13 +1001,13 @@ struct AttnStream {
       const uint32_t row = 32 * sidx + 16 * (j >> 2) + (j & 3);  // + 4 g from the lane offset
       const uint32_t off = v_lane + row * (uint32_t)a.v_st;
       if constexpr (VB == 8) {
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(s.v, off, 0, 2);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(s.v, off, 0, KVQ_ATTN_KV_AUX);
         r.v[sidx][j][0] = v[0];
         r.v[sidx][j][1] = v[1];
       } else if constexpr (VB == 4) {
-        r.v[sidx][j][0] = __builtin_amdgcn_raw_buffer_load_b32(s.v, off, 0, 2);
+        r.v[sidx][j][0] = __builtin_amdgcn_raw_buffer_load_b32(s.v, off, 0, KVQ_ATTN_KV_AUX);
       } else {
-        r.v[sidx][j][0] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(s.v, off, 0, 2);
+        r.v[sidx][j][0] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(s.v, off, 0, KVQ_ATTN_KV_AUX);
       }
     }
   }
