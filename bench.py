@@ -634,16 +634,21 @@ def run_dequant(args, rank, world, dev, backend):
     # same tensors, re-quantising into the same store (identical bytes every time)
     from efficient_llm_inference_amd import kernels as _k
     quant_info = {}
-    for name, store, tensors in (("k", qc._k, [k for k, _ in past]), ("v", qc._v, [v for _, v in past])):
+    for name, tensors in (("k", [k for k, _ in past]), ("v", [v for _, v in past])):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        # the output alternates between the rotating caches' stores (identical bytes every time): a 268 MB INT4 store
+        # written with write-back stores again and again would otherwise sit in the 256 MB Infinity Cache
+        stores = [getattr(c, "_" + name) for c in caches]
+        store = stores[0]
         ws = store._workspace(L * T)
-        for it in range(6):
+        for it in range(7):
             if it == 1:
                 ev[0].record()
-            _k.quant_tokens(tensors, store.q[:, :, :, :T], store.scales[:, :T], ws, store.kind)
+            st_ = stores[it % len(stores)]
+            _k.quant_tokens(tensors, st_.q[:, :, :, :T], st_.scales[:, :T], ws, st_.kind)
         ev[1].record()
         torch.cuda.synchronize()
-        ms = ev[0].elapsed_time(ev[1]) / 5
+        ms = ev[0].elapsed_time(ev[1]) / 6
         qbytes = L * B * H * T * D * BYTES_PER_ELT[store.kind]  # 2 B read + 1 or 0.5 B written per element
         quant_info[f"quant_{store.kind}"] = {"avg_launch_ms": round(ms, 4), "achieved": round(qbytes / (ms * 1e-3) / 1e9, 1),
                                              "frac": round(qbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),

@@ -61,7 +61,7 @@ struct Tunables {
   int64_t quant_nv;              // 4 = 2048-element one-wave tiles (A-B), else 8
   int64_t quant_no_regmax;       // 1 = keep the LDS abs-max in one-wave tiles (A-B)
   int64_t quant_geo128;          // one-wave quantise tile at 8 rows x head_dim 128: geometry as compile-time constants (1, default) or as arguments (0)
-  int64_t quant_nt_stores;       // one-wave quantise kernel: non-temporal output stores (1), write-back stores (0), -1 (default) = INT8 non-temporal, INT4 write-back
+  int64_t quant_nt_stores;       // one-wave quantise kernel: non-temporal output stores (1), write-back stores (0), -1 (default) = as nt_loads
   int64_t quant_tpw;             // tiles per wave of the pipelined one-wave quantise kernel (2 | 4 | 8); 0 = one tile per wave
   int64_t quant_lds_pad;         // A-B: bytes of unused dynamic LDS on the one-wave quantise launch (caps waves per CU)
   int64_t attn_force_valu;       // 1 = decode attention never takes the MFMA kernel (tests / A-B)

@@ -50,7 +50,7 @@ struct QuantArgs {
   uint32_t vpr;      // sweep kernel, same case: TT * D/8 vectors per row run
   uint32_t t_begin;  // first token of this launch's first tile
   int32_t nt_loads;  // non-temporal input loads
-  int32_t nt_stores; // non-temporal output stores (tunable quant_nt_stores; -1 = INT8 yes, INT4 no)
+  int32_t nt_stores; // non-temporal output stores (tunable quant_nt_stores; -1 = as nt_loads)
   int32_t blk;       // workgroup size of the fused kernel (256, or 64 = one wave per tile)
   int32_t nv;        // vectors per lane per tile (8, or 4 for the small one-wave tile)
   int32_t bh_contig; // rows addressable as r * stride_h on both sides
@@ -835,9 +835,10 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
   a.blk = kBlock;
   a.nv = kNVMax;
   a.nt_loads = (int32_t)tunables().nt_loads;
-  // -1 (default): what measured fastest once the accesses really were non-temporal — INT8's 512-byte output pieces
-  // non-temporal, INT4's 256-byte pieces write-back (0.228-0.231 vs 0.233-0.237 ms; INT8: 0.269-0.272 vs 0.302-0.304 ms)
-  a.nt_stores = tunables().quant_nt_stores < 0 ? (a.nt_loads && BITS == 8 ? 1 : 0) : (int32_t)(tunables().quant_nt_stores != 0);
+  // -1 (default): non-temporal like the loads. (A first measurement, in a loop that rewrote the SAME 268 MB store, had
+  // write-back stores ahead for INT4: the store was sitting in the 256 MB Infinity Cache. With rotating buffers:
+  // INT4 0.231-0.232 ms non-temporal vs 0.247-0.248 write-back, INT8 0.270-0.271 vs 0.300-0.302.)
+  a.nt_stores = tunables().quant_nt_stores < 0 ? a.nt_loads : (int32_t)(tunables().quant_nt_stores != 0);
   a.bh_contig = bh_contig ? 1 : 0;
   a.xcd_group = (uint32_t)(tunables().quant_xcd_group > 1 ? tunables().quant_xcd_group : 0);
   if (fused && anydv) {

@@ -162,6 +162,24 @@ __global__ __launch_bounds__(64) void rw_quant_tile_real_k(const u32x4* __restri
   __builtin_nontemporal_store(a0, q + (int64_t)(lane >> 4) * hv_out);
   __builtin_nontemporal_store(a1, q + (int64_t)((lane >> 4) + 4) * hv_out);
 }
+// the INT8 tile: same 8 loads of 1 KiB, four stores covering 8 pieces of 512 B (NTS: non-temporal stores)
+template <bool NTS>
+__global__ __launch_bounds__(64) void rw_quant_tile_i8_k(const u32x4* __restrict__ in, u32x4* __restrict__ out, uint32_t T) {
+  const uint32_t lane = threadIdx.x;
+  const int64_t hv_in = (int64_t)T * 16, hv_out = (int64_t)T * 8;
+  const u32x4* p = in + (int64_t)blockIdx.y * 8 * hv_in + (int64_t)blockIdx.x * 64 + lane;
+  u32x4 x[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = __builtin_nontemporal_load(p + (int64_t)i * hv_in);
+  u32x4* q = out + (int64_t)blockIdx.y * 8 * hv_out + (int64_t)blockIdx.x * 32 + (lane & 31u);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u32x4 v = x[2 * j] ^ x[2 * j + 1];
+    u32x4* dst = q + (int64_t)((lane >> 5) + 2 * j) * hv_out;
+    if (NTS) __builtin_nontemporal_store(v, dst);
+    else *dst = v;
+  }
+}
 template <bool COOP, int NVALU = 0>
 __global__ __launch_bounds__(COOP ? 512 : 64) void rw_quant_tile_k(const u32x4* __restrict__ in, u32x4* __restrict__ out, int64_t head_vec_in,
                                                                    int64_t head_vec_out) {
@@ -353,6 +371,24 @@ static int64_t G = 32, B = 1, H = 8, T = 16384, D = 128;  // override: KVQ_G / K
 
 int main(int argc, char** argv) {
   std::string what = argc > 1 ? argv[1] : "all";
+  if (const char* tv = getenv("KVQ_TUNABLES")) {  // "key=value,key=value": kvq_set_tunable before anything runs
+    std::string s = tv;
+    size_t pos = 0;
+    while (pos < s.size()) {
+      size_t end = s.find(',', pos);
+      if (end == std::string::npos) end = s.size();
+      const std::string kv = s.substr(pos, end - pos);
+      const size_t eq = kv.find('=');
+      if (eq != std::string::npos) {
+        if (kvq_set_tunable(kv.substr(0, eq).c_str(), atoll(kv.substr(eq + 1).c_str())) != 0) {
+          fprintf(stderr, "unknown tunable %s\n", kv.c_str());
+          return 2;
+        }
+        printf("# tunable %s\n", kv.c_str());
+      }
+      pos = end + 1;
+    }
+  }
   int iters = argc > 2 ? atoi(argv[2]) : 20;
   int n_variants = argc > 3 ? atoi(argv[3]) : 12;
   if (getenv("KVQ_G")) G = atoll(getenv("KVQ_G"));
@@ -463,6 +499,10 @@ int main(int argc, char** argv) {
       printf("calib quantpat head-per-wave tile (8 KiB in, 2 KiB out per wave)  %8.3f ms  %8.1f GB/s (r+w, INT4 mix)\n", ms, 2.5 * N / ms / 1e6);
       ms = tm.ms_per([&] { rotate(); rw_quant_tile_real_k<<<dim3((unsigned)(T / 4), (unsigned)G), 64>>>((const u32x4*)in16, (u32x4*)out, (uint32_t)T); }, iters);
       printf("calib quantpat one-wave tile, the real tensors' strides (heads 4 MiB / 1 MiB apart)  %8.3f ms  %8.1f GB/s\n", ms, 2.5 * N / ms / 1e6);
+      ms = tm.ms_per([&] { rotate(); rw_quant_tile_i8_k<true><<<dim3((unsigned)(T / 4), (unsigned)G), 64>>>((const u32x4*)in16, (u32x4*)out, (uint32_t)T); }, iters);
+      printf("calib quantpat INT8 one-wave tile (8 x 1 KiB in, 8 x 512 B out, nt stores)  %8.3f ms  %8.1f GB/s\n", ms, 3.0 * N / ms / 1e6);
+      ms = tm.ms_per([&] { rotate(); rw_quant_tile_i8_k<false><<<dim3((unsigned)(T / 4), (unsigned)G), 64>>>((const u32x4*)in16, (u32x4*)out, (uint32_t)T); }, iters);
+      printf("calib quantpat INT8 one-wave tile (8 x 1 KiB in, 8 x 512 B out, plain stores)  %8.3f ms  %8.1f GB/s\n", ms, 3.0 * N / ms / 1e6);
 #define RUN_NV(NV)                                                                                                 \
   ms = tm.ms_per([&] { rotate(); rw_quant_tile_k<false, NV><<<(unsigned)(T_all / 4), 64>>>((const u32x4*)in16, (u32x4*)out, head_vec_in, head_vec_out); }, iters); \
   printf("calib quantpat one-wave tile + %4d filler vector instructions       %8.3f ms  %8.1f GB/s (r+w, INT4 mix)\n", NV, ms, 2.5 * N / ms / 1e6);

@@ -276,8 +276,8 @@ int kvq_time_next_launch(void* start_event, void* stop_event);
  *               "quant_nv" (8|4|16), "quant_lds_pad" (bytes of unused dynamic LDS: occupancy A-B),
  *               "quant_tpw" (tiles per wave of the pipelined one-wave kernel: 0 = one tile, 2|4|8),
  *               "quant_no_regmax" (0/1), "quant_xcd_group" (consecutive tiles per XCD, 0 = round robin),
- *               "quant_nt_stores" (1 non-temporal / 0 write-back output stores of the one-wave kernel, -1 = INT8 non-temporal,
- *               INT4 write-back: default), "quant_geo128" (1 = tile geometry of the 8-row head_dim-128 shape as
+ *               "quant_nt_stores" (1 non-temporal / 0 write-back output stores of the one-wave kernel, -1 = as nt_loads:
+ *               default), "quant_geo128" (1 = tile geometry of the 8-row head_dim-128 shape as
  *               compile-time constants, default; 0 = as arguments)
  *   eviction    "pool_grid" (workgroup cap, 0 = none), "pool_block" (64|128|256), "pool_wave" (1 = one wave per
  *               output row where the shape allows, default; 0 = per-lane-group walk; equal output bits)

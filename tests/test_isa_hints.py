@@ -42,9 +42,9 @@ def evict_asm(tmp_path_factory):
     return _asm(tmp_path_factory, "kvq_evict")
 
 
-@pytest.mark.parametrize("bits,nt_store", [(4, False), (8, True)])
+@pytest.mark.parametrize("bits,nt_store", [(4, True), (8, True)])
 def test_shipped_quantise_tile_issues_non_temporal_loads(quant_asm, bits, nt_store):
-    # quant_tokens_fused_k<f16, BITS, ROWU, LDS_OUT, FULL, 64, REGMAX = 1, NV = 8, GEO128, NTL = true, NTS = (BITS == 8)>
+    # quant_tokens_fused_k<f16, BITS, ROWU, LDS_OUT, FULL, 64, REGMAX = 1, NV = 8, GEO128, NTL = true, NTS = true>
     body = _kernel_body(quant_asm, r"_ZN3kvq20quant_tokens_fused_kILi0ELi%dELb1ELb1ELb1ELi64ELi1ELi8ELb1ELb1ELb%dEEEvNS_9QuantArgsE" % (bits, int(nt_store)))
     loads = re.findall(r"global_load_dwordx4[^\n]*", body)
     assert len(loads) == 8 and all(l.rstrip().endswith(" nt") for l in loads), loads
