@@ -1664,6 +1664,12 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_k(const AttnArgs
 // synchronises its waves with LDS-only barriers (`__syncthreads()` would drain the outstanding global loads).
 // Same arithmetic in the same order as decode_attn_merge_k: bit-identical results.
 constexpr int kMergePF = 16;
+// A word another kernel wrote, read through the CONSTANT address space: with a uniform address that is an s_load the
+// compiler tracks itself (issued where it stands, waited for at the first use), where a global-space load becomes a
+// vector load that is waited for on the spot. Only for memory no store of THIS kernel touches.
+__device__ __forceinline__ int scalar_load_i32(const int* p) {
+  return *reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(p));
+}
 __device__ __forceinline__ void lds_barrier() {  // this workgroup's LDS traffic only; global loads stay in flight
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -1683,11 +1689,9 @@ __device__ inline void quant_new_token_regs(const NewTokenArgs& a, const uint32_
                                             const void* valid) {
   const uint32_t tid = threadIdx.x;
   const uint32_t np = a.B * a.H * a.D / 2u;  // element pairs
-  uint32_t t_raw;
-  {
-    const int* tp = t_dev ? t_dev : reinterpret_cast<const int*>(valid);
-    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(t_raw) : "s"(tp));
-  }
+  // the device-side slot number: a SCALAR load (uniform address), issued here and waited for by the compiler at
+  // its first use below the fence
+  const uint32_t t_raw = (uint32_t)scalar_load_i32(t_dev ? t_dev : reinterpret_cast<const int*>(valid));
   const uint16_t* x = reinterpret_cast<const uint16_t*>(a.x[w]);
   uint32_t raw[kNewPairs];
   uint32_t row[kNewPairs], col[kNewPairs];  // (b, h) row and element offset of the pair
@@ -1701,7 +1705,6 @@ __device__ inline void quant_new_token_regs(const NewTokenArgs& a, const uint32_
     raw[k] = *reinterpret_cast<const uint32_t*>(x + off);
   }
   __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t_raw));
   const int64_t slot = t_dev ? (int64_t)(t_raw < t_bound ? t_raw : t_bound) : 0;  // host-side T: a.q / a.scale point at the slot already
   float lo[kNewPairs], hi[kNewPairs];
   float m = 0.0f;
@@ -1780,11 +1783,9 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_fast_k(const Att
   const f32x4* src = reinterpret_cast<const f32x4*>(a.ws + a.acc_off + ((int64_t)b * a.Hq + hq) * nb * a.D) + d4;
 
   // ---- requests: straight-line code (clamped indices, selected addresses), nothing waits before the fence -------
-  uint32_t t_raw;  // the device-side token count: a scalar load the compiler does not know about (waited for below)
-  {
-    const int* tp = a.t_dev ? a.t_dev : reinterpret_cast<const int*>(a.ws);
-    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(t_raw) : "s"(tp));
-  }
+  // the device-side token count: a SCALAR buffer load (uniform address; a plain `*a.t_dev` becomes a vector load that is
+  // waited for on the spot), issued here and waited for by the compiler at its first use below the fence
+  const uint32_t t_raw = (uint32_t)scalar_load_i32(a.t_dev ? a.t_dev : reinterpret_cast<const int*>(a.ws));
   const f32x2 ml_raw = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(ml) + (tid < nb ? tid : nb - 1u));
   const uint32_t di = tid < a.D ? tid : a.D - 1u;
   const uint16_t qb_raw = reinterpret_cast<const uint16_t*>(a.q)[(int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + di];
@@ -1797,7 +1798,6 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_fast_k(const Att
     x[u] = __builtin_nontemporal_load(src + (int64_t)(s < nb ? s : nb - 1u) * dv);
   }
   __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t_raw));
   const uint32_t T = a.t_dev ? (t_raw < a.T ? t_raw : a.T) : a.T;
   const uint16_t qb = (has_new && tid < a.D) ? qb_raw : (uint16_t)0;  // the dot product runs over d < D
   f32x2 mlv = ml_raw;
