@@ -35,6 +35,7 @@
   } while (0)
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void copy16_k(const u32x4* __restrict__ in, u32x4* __restrict__ out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = in[i];
@@ -161,6 +162,32 @@ __global__ __launch_bounds__(64) void rw_quant_tile_real_k(const u32x4* __restri
   u32x4* q = out + (int64_t)blockIdx.y * 8 * hv_out + (int64_t)blockIdx.x * 16 + (lane & 15u);
   __builtin_nontemporal_store(a0, q + (int64_t)(lane >> 4) * hv_out);
   __builtin_nontemporal_store(a1, q + (int64_t)((lane >> 4) + 4) * hv_out);
+}
+// the dequantise kernels' memory traffic without their arithmetic: one-wave workgroup w reads QV 16-byte... no: reads
+// IN_B bytes per lane (4 for the INT4 kernel: 4 x 4 B = 1 KiB per wave; 8 for INT8's 2 x 8 B) and writes OUTV 16-byte
+// vectors per lane (4 KiB / 2 KiB per wave), all contiguous, non-temporal stores
+template <int NLOAD, int LOADB, int NSTORE, bool NTL>
+__global__ __launch_bounds__(64) void rw_dequant_chunk_k(const uint8_t* __restrict__ in, u32x4* __restrict__ out) {
+  const uint32_t lane = threadIdx.x;
+  const uint8_t* p = in + ((int64_t)blockIdx.x * NLOAD * 64 + lane) * LOADB;
+  uint32_t w[NLOAD][2];
+#pragma unroll
+  for (int u = 0; u < NLOAD; ++u) {
+    if (LOADB == 4) {
+      w[u][0] = NTL ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p + (int64_t)u * 64 * LOADB)) : *reinterpret_cast<const uint32_t*>(p + (int64_t)u * 64 * LOADB);
+      w[u][1] = 0;
+    } else {
+      const u32x2 v = NTL ? __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p + (int64_t)u * 64 * LOADB)) : *reinterpret_cast<const u32x2*>(p + (int64_t)u * 64 * LOADB);
+      w[u][0] = v[0];
+      w[u][1] = v[1];
+    }
+  }
+  u32x4* q = out + (int64_t)blockIdx.x * NSTORE * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < NSTORE; ++s) {
+    const uint32_t a = w[s % NLOAD][0], b = w[s % NLOAD][1];
+    __builtin_nontemporal_store(u32x4{a, a ^ b, a + s, b}, q + s * 64);
+  }
 }
 // the INT8 tile: same 8 loads of 1 KiB, four stores covering 8 pieces of 512 B (NTS: non-temporal stores)
 template <bool NTS>
@@ -487,6 +514,18 @@ int main(int argc, char** argv) {
       printf("permprobe %s:", names[k]);
       for (int l = 0; l < 64; l += 8) printf(" l%d=%u", l, h[64 * k + l]);
       printf("\n");
+    }
+  }
+  if (what == "dequantpat") {  // INT4: 1 KiB in / 4 KiB out per wave; INT8: 1 KiB in / 2 KiB out per wave
+    for (int rep = 0; rep < 3; ++rep) {
+      double ms = tm.ms_per([&] { rotate(); rw_dequant_chunk_k<4, 4, 4, false><<<(unsigned)(N / 2048), 64>>>((const uint8_t*)q4, (u32x4*)out); }, iters);
+      printf("calib dequantpat INT4 traffic (1 KiB in, 4 KiB out per wave)            %8.3f ms  %8.1f GB/s\n", ms, 2.5 * N / ms / 1e6);
+      ms = tm.ms_per([&] { rotate(); rw_dequant_chunk_k<4, 4, 4, true><<<(unsigned)(N / 2048), 64>>>((const uint8_t*)q4, (u32x4*)out); }, iters);
+      printf("calib dequantpat INT4 traffic, non-temporal loads                        %8.3f ms  %8.1f GB/s\n", ms, 2.5 * N / ms / 1e6);
+      ms = tm.ms_per([&] { rotate(); rw_dequant_chunk_k<2, 8, 2, true><<<(unsigned)(N / 1024), 64>>>((const uint8_t*)q8, (u32x4*)out); }, iters);
+      printf("calib dequantpat INT8 traffic (1 KiB in, 2 KiB out per wave, nt loads)   %8.3f ms  %8.1f GB/s\n", ms, 3.0 * N / ms / 1e6);
+      ms = tm.ms_per([&] { rotate(); rw_dequant_chunk_k<4, 8, 4, true><<<(unsigned)(N / 2048), 64>>>((const uint8_t*)q8, (u32x4*)out); }, iters);
+      printf("calib dequantpat INT8 traffic (2 KiB in, 4 KiB out per wave, nt loads)   %8.3f ms  %8.1f GB/s\n", ms, 3.0 * N / ms / 1e6);
     }
   }
   if (what == "quantpat") {  // the quantise kernels' loads + stores without arithmetic: one-wave tiles vs head-per-wave tiles
