@@ -6,6 +6,7 @@ import os
 import subprocess
 import sys
 
+import pytest
 import torch
 
 from tests.conftest import ROOT
@@ -57,3 +58,35 @@ def test_gpus_flag_fails_loudly():
     proc = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--launcher-selftest"], cwd=ROOT, capture_output=True,
                           text=True, env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
     assert proc.returncode != 0 and "WORLD_SIZE" in proc.stderr
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_the_contract_fields(tmp_path):
+    """One real run of the default workload on the GPU (few steps, CPU baseline on a tiny sample): ONE JSON line on
+    stdout with every field the driver's contract names, the roofline and cpu_baseline objects, self-consistent."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+                           "--cpu-sample-layers", "1"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 4 and j["warmup"] == 2 and j["higher_is_better"] is True and j["vs_baseline"] is None
+    assert j["unit"] == "GB/s" and j["scaling"] == "weak" and j["data"] == "synthetic" and j["config"]["workload"] == "llama3_8b_mixed_seq16k"
+    r = j["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # value = bytes per step / step time; the INT4 launch is part of the step
+    assert abs(j["value"] - j["config"]["bytes_per_step"] / (j["ms_per_step"] * 1e-3) / 1e9) / j["value"] < 2e-3
+    assert r["avg_launch_ms"] < j["ms_per_step"] and 0.5 < r["frac"] < 1.0
+    c = j["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
