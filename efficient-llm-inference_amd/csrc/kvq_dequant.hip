@@ -192,6 +192,35 @@ __global__ __launch_bounds__(kBlock) void dequant_flat_vec_k(const uint8_t* __re
   }
 }
 
+// The same entry points for LARGE buffers: the token-table kernel's launch shape (one-wave workgroups, one contiguous
+// chunk each — 4 KiB of output for INT4, 2 KiB for INT8 —, all loads in flight, non-temporal stores) with the one scalar
+// scale. The grid-stride kernel above stays for small calls (the reference's per-slice use: 768-1024 elements).
+#ifndef KVQ_FLAT_CHUNK_MIN
+#define KVQ_FLAT_CHUNK_MIN (1 << 17)
+#endif
+constexpr int64_t kFlatChunkMin = KVQ_FLAT_CHUNK_MIN;  // groups of 8 elements (1 Mi elements) from which the chunk kernel is used
+template <int BITS>
+__global__ __launch_bounds__(64) void dequant_flat_chunk_k(const uint8_t* __restrict__ q, float s, uint16_t* __restrict__ out,
+                                                           int64_t n_groups8) {
+  constexpr int UNROLL = BITS == 4 ? 4 : 2;
+  const int64_t g0 = (int64_t)blockIdx.x * (64 * UNROLL) + threadIdx.x;
+  uint32_t w[UNROLL][BITS / 4];
+#pragma unroll
+  for (int u = 0; u < UNROLL; ++u) {
+    const int64_t gi = g0 + u * 64;
+    if (gi < n_groups8) load_words<BITS / 4, BITS == 8>(q + gi * BITS, w[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < UNROLL; ++u) {
+    const int64_t gi = g0 + u * 64;
+    if (gi < n_groups8) {
+      float x[8];
+      expand8<BITS>(w[u], s, x);
+      store8<KVQ_F16, true>(out + gi * 8, x);
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void dequant_i8_flat_scalar_k(const int8_t* __restrict__ q, float s,
                                                                    uint16_t* __restrict__ out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
@@ -442,8 +471,12 @@ int kvq_dequant_i8_f16_flat(const int8_t* q, float scale, void* out_f16, int64_t
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (n % 8 == 0 && aligned(q, 8) && aligned(out_f16, 16)) {
     const int64_t ng = n / 8;
-    hipLaunchKernelGGL((dequant_flat_vec_k<8>), dim3(grid_for((ng + kBlock - 1) / kBlock, 256 * 16)), dim3(kBlock), 0,
-                       st, reinterpret_cast<const uint8_t*>(q), scale, reinterpret_cast<uint16_t*>(out_f16), ng);
+    if (ng >= kFlatChunkMin && (ng + 127) / 128 < (int64_t(1) << 31))
+      hipLaunchKernelGGL((dequant_flat_chunk_k<8>), dim3((unsigned)((ng + 127) / 128)), dim3(64), 0, st, reinterpret_cast<const uint8_t*>(q),
+                         scale, reinterpret_cast<uint16_t*>(out_f16), ng);
+    else
+      hipLaunchKernelGGL((dequant_flat_vec_k<8>), dim3(grid_for((ng + kBlock - 1) / kBlock, 256 * 16)), dim3(kBlock), 0,
+                         st, reinterpret_cast<const uint8_t*>(q), scale, reinterpret_cast<uint16_t*>(out_f16), ng);
   } else {
     hipLaunchKernelGGL(dequant_i8_flat_scalar_k, dim3(grid_for((n + kBlock - 1) / kBlock, 256 * 16)), dim3(kBlock), 0,
                        st, q, scale, reinterpret_cast<uint16_t*>(out_f16), n);
@@ -467,8 +500,12 @@ int kvq_dequant_i4_f16_flat(const uint8_t* packed, float scale, void* out_f16, i
   const int64_t total_last = packed_last * 2;
   if (orig_last_dim >= total_last && n_packed % 4 == 0 && aligned(packed, 4) && aligned(out_f16, 16)) {
     const int64_t ng = n_packed / 4;  // no pad column to zero: pure vector path
-    hipLaunchKernelGGL((dequant_flat_vec_k<4>), dim3(grid_for((ng + kBlock - 1) / kBlock, 256 * 16)), dim3(kBlock), 0,
-                       st, packed, scale, reinterpret_cast<uint16_t*>(out_f16), ng);
+    if (ng >= kFlatChunkMin && (ng + 255) / 256 < (int64_t(1) << 31))
+      hipLaunchKernelGGL((dequant_flat_chunk_k<4>), dim3((unsigned)((ng + 255) / 256)), dim3(64), 0, st, packed, scale,
+                         reinterpret_cast<uint16_t*>(out_f16), ng);
+    else
+      hipLaunchKernelGGL((dequant_flat_vec_k<4>), dim3(grid_for((ng + kBlock - 1) / kBlock, 256 * 16)), dim3(kBlock), 0,
+                         st, packed, scale, reinterpret_cast<uint16_t*>(out_f16), ng);
   } else {
     const int64_t out_n = n_packed * 2;
     hipLaunchKernelGGL(dequant_i4_flat_scalar_k, dim3(grid_for((out_n + kBlock - 1) / kBlock, 256 * 16)), dim3(kBlock),

@@ -516,6 +516,14 @@ int main(int argc, char** argv) {
       printf("\n");
     }
   }
+  if (what == "flat") {  // the reference's two entry points on one large contiguous buffer (one scalar scale)
+    for (int rep = 0; rep < 3; ++rep) {
+      double ms = tm.ms_per([&] { rotate(); KVQ_OK(kvq_dequant_i4_f16_flat((const uint8_t*)q4, 0.0123f, out, N / 2, D / 2, D, 0)); }, iters);
+      printf("flat dequant_i4_f16  %8.3f ms  %8.1f GB/s  frac8T=%.3f\n", ms, 2.5 * N / ms / 1e6, 2.5 * N / ms / 1e6 / 8000.0);
+      ms = tm.ms_per([&] { rotate(); KVQ_OK(kvq_dequant_i8_f16_flat((const int8_t*)q8, 0.0123f, out, N, 0)); }, iters);
+      printf("flat dequant_i8_f16  %8.3f ms  %8.1f GB/s  frac8T=%.3f\n", ms, 3.0 * N / ms / 1e6, 3.0 * N / ms / 1e6 / 8000.0);
+    }
+  }
   if (what == "dequantpat") {  // INT4: 1 KiB in / 4 KiB out per wave; INT8: 1 KiB in / 2 KiB out per wave
     for (int rep = 0; rep < 3; ++rep) {
       double ms = tm.ms_per([&] { rotate(); rw_dequant_chunk_k<4, 4, 4, false><<<(unsigned)(N / 2048), 64>>>((const uint8_t*)q4, (u32x4*)out); }, iters);

@@ -248,6 +248,14 @@ def test_flat_entry_points(E):
         out = ext.dequant_int4_packed_to_fp16(to_torch(p), 0.37, orig)
         assert out.shape[-1] == 2 * shape[-1]
         assert np.array_equal(bits(out), bits(O.dequant_int4_packed_kernel_full(p, np.float32(0.37), orig)))
+    # large buffers take the one-wave-per-chunk kernel (>= 1 Mi elements): whole chunks, a ragged last chunk, one group over
+    for n in (1 << 20, (1 << 20) + 8, 3 * (1 << 20) + 1024 * 5 + 8):
+        q = rng.integers(-127, 128, size=(n,), dtype=np.int8)
+        out = ext.dequant_int8_to_fp16(to_torch(q), 0.0123)
+        assert np.array_equal(bits(out), bits(O.dequantize_int8_per_tensor(q, np.float32(0.0123), "f16")))
+        p = rng.integers(0, 256, size=(n // 64, 64), dtype=np.uint8)
+        out = ext.dequant_int4_packed_to_fp16(to_torch(p), 0.37, 128)
+        assert np.array_equal(bits(out), bits(O.dequant_int4_packed_kernel_full(p, np.float32(0.37), 128)))
     with pytest.raises(RuntimeError):
         ext.dequant_int8_to_fp16(torch.zeros(4, dtype=torch.int8), 1.0)  # CPU tensor
     with pytest.raises(RuntimeError):
