@@ -1,25 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the MI355X KV-cache dequantise hot path.
+"""bench.py — the BASELINE metric of the MI355X KV-cache quantise / dequantise / eviction path in ONE line.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload llama3_8b_mixed_seq16k]
 
-Workload (BASELINE.json configs[3], the one the target is quoted on): Llama-3-8B KV shape
-[L=32, 2, B=1, H_kv=8, T=16384, D=128], ``quant_mixed`` = INT8 keys + packed-INT4 values,
-synthetic N(0,1) fp16 KV (seed 42) quantised once by the HIP quantise kernels before timing.
+Headline workload (BASELINE.json configs[3], the one the target is quoted on): Llama-3-8B KV shape
+[L=32, 2, B=1, H_kv=8, T=16384, D=128], ``quant_mixed`` = INT8 keys + packed-INT4 values, synthetic N(0,1)
+fp16 KV (seed 42) quantised once by the HIP quantise kernels before timing.
 
-One STEP = one full ``QuantizedKVCache.to_past_key_values()`` of that cache — what the
+One STEP = dequantise the whole cache, all 32 layers of K (INT8 -> fp16) and V (INT4 -> fp16) — what the
 reference does before every decode forward (reference src/quantization/ops.py:345-355,
-src/benchmarking/benchmarker.py:470): dequantise all 32 layers of K (INT8 -> fp16) and V
-(INT4 -> fp16): exactly two kernel launches, inputs resident in HBM.
+src/benchmarking/benchmarker.py:470): exactly two kernel launches into pre-allocated rotating outputs
+(``_KVStore.dequant(out=...)``, the store-level call ``QuantizedKVCache.to_past_key_values(copy=True)`` makes
+after allocating its two output tensors; the public call itself is timed beside it: ``public_api``).
 
-value  = algorithmic bytes of the step (INT8 3.0 B/elt, INT4 2.5 B/elt) x ranks
-         / max-over-ranks wall time, GB/s.  Weak scaling: every rank holds its own prompt's
-         cache (batch shard, no data-path collective).
-roofline = the INT4 dequantise kernel (north-star kernel): algorithmic bytes per launch
-         (1,342,177,280) / its mean duration, timed with HIP events on the launch stream
-         inside the timed region; peak 8000 GB/s (MI355X HBM3E spec).
-cpu_baseline = the C restatement of the reference's algorithm (oracle/kvq_oracle.c, scalar,
-         1 core) on a bounded sample of the same INT4 workload, on this box's host cores.
+value    = algorithmic bytes of the step (INT8 3.0 B/elt, INT4 2.5 B/elt) x ranks / max-over-ranks
+           wall time, GB/s. Weak scaling: every rank holds its own prompt's cache (batch shard, no collective).
+roofline = the INT4 dequantise kernel (north-star kernel): algorithmic bytes per launch (1,342,177,280) / its mean
+           duration over the timed region, from HIP events bound to each launch's own dispatch; peak 8000 GB/s.
+           ``roofline.kernel`` (and every other ``kernel`` field) is what the library launched, as the profiler
+           prints it (kvq_kernel_log), never a name typed here.
+Sub-records of the default line (the rest of BASELINE.json's metric; each with its own small fixed iteration count):
+  decode                          configs[1]: gpt2 quant_int8, prompt 512 + 512 new tokens through
+                                  KVCacheBenchmarker.benchmark_method: tokens/sec + est_kv_cache_mb for the staged
+                                  (bit-exact), fused-attention and HIP-graph decode beside full_cache
+  configs.gpt2m_int4_seq4k        configs[2] made HBM-bound by rotating 4 caches: dequantise + quantise rooflines
+                                  at the 16-row x 64 shape
+  configs.gpt2_shape_seq32k       the default model's 12-row x 64 shape at an HBM-sized T (per-shape table)
+  configs.llama3_8b_evict_seq32k  configs[4] per-GPU share: chunk mean-pool + sliding-window rooflines
+  sharded_quant (N > 1 only)      the ONE data-path collective: batch-sharded quantise with all_reduce(MAX) over RCCL
+cpu_baseline = the C restatement of the reference's algorithm (oracle/kvq_oracle.c, scalar, 1 core), the
+           whole-tensor torch-CPU form and the reference's literal per-slice loop on bounded samples of the same
+           workload, on this box's host cores (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -39,6 +50,11 @@ WORKLOADS = {
     "llama3_8b_mixed_seq16k": (32, 1, 8, 16384, 128, "mixed"),
     "gpt2m_int4_seq4k": (24, 1, 16, 4096, 64, "int4"),
     "gpt2_int8_seq1k": (12, 1, 12, 1024, 64, "int8"),
+}
+# shapes measured as sub-records of the default line: (L, B, H, T, D, config mode, rotating caches)
+SHAPE_RECORDS = {
+    "gpt2m_int4_seq4k": (24, 1, 16, 4096, 64, "int4", 4),     # BASELINE configs[2]; 96 MiB store: rotation makes it HBM-bound
+    "gpt2_shape_seq32k": (12, 1, 12, 32768, 64, "int8", 2),   # the default model's head shape at an HBM-sized T
 }
 # BASELINE.json configs[1]/[2] as decode loops through KVCacheBenchmarker (random-init weights of
 # the named architecture; see benchmarking/offline.py): --workload decode:<arch>:<method>
@@ -63,6 +79,7 @@ ATTN = {  # name: (L, B, Hq, Hkv, T, D, mode)
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 BYTES_PER_ELT = {"int8": 3.0, "int4": 2.5}  # q read + fp16 write
+MODE_KINDS = {"int8": ("int8", "int8"), "int4": ("int4", "int4"), "mixed": ("int8", "int4")}
 
 
 def parse():
@@ -74,13 +91,17 @@ def parse():
                     help="one of %s, or decode:<arch>:<method>[:<prompt_tokens>:<new_tokens>] "
                          "(e.g. decode:gpt2:quant_int8:512:512; steps = prompts per rank)" % sorted(list(WORKLOADS) + list(ATTN) + list(EVICT) + list(SHARDQ)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-subrecords", action="store_true",
+                    help="headline workload only: skip the decode / configs / sharded_quant sub-records of the default line "
+                         "(profiling runs that want nothing but the two dequantise kernels)")
     ap.add_argument("--rotate-caches", type=int, default=2,
                     help="independent quantised caches visited round-robin by consecutive steps, so that no "
                          "step re-reads lines the 256 MiB Infinity Cache may still hold (1 = the decode loop's "
                          "behaviour: the same cache every step; its 256 MiB INT4 store then stays cache-resident)")
     ap.add_argument("--cpu-sample-layers", type=int, default=8)
     ap.add_argument("--tunable", action="append", default=[], metavar="KEY=VALUE",
-                    help="A-B only: kvq_set_tunable(KEY, VALUE) before the run (include/kvq_hip.h lists the keys)")
+                    help="kvq_set_tunable(KEY, VALUE) before the run (include/kvq_hip.h lists the keys; A-B keys need "
+                         "KVQ_HIP_LIB=<pkg>/lib/ab/libkvq_hip.so)")
     ap.add_argument("--per-layer-calls", action="store_true",
                     help="decode-attention workloads: one host call per layer (kvq_decode_attn) instead of one per step "
                          "(kvq_decode_step_layers)")
@@ -102,6 +123,8 @@ def parse():
     return ap.parse_args()
 
 
+# --------------------------------------------------------------------------------------------- small helpers
+
 def _median_time(fn, reps):
     """median wall time of `reps` calls after one warm-up call"""
     fn()
@@ -114,7 +137,64 @@ def _median_time(fn, reps):
     return ts[len(ts) // 2]
 
 
-def cpu_baseline(L, B, H, T, D, sample_layers, reps=5):
+def _kernels_of(fn):
+    """the kernel(s) `fn` makes the library launch, as the profiler names them (kvq_kernel_log)"""
+    from efficient_llm_inference_amd import _lib
+    _lib.kernel_log_clear()
+    fn()
+    names = _lib.kernel_log()
+    return names[0] if len(names) == 1 else " + ".join(names)
+
+
+def _time_launches(fn, n, warm=2):
+    """`fn(i)` makes exactly one library launch: its dispatch's own start / stop timestamps (kvq_time_next_launch ->
+    hipExtLaunchKernelGGL), n times after `warm` untimed calls -> sorted list of milliseconds"""
+    from efficient_llm_inference_amd import _lib
+    for i in range(warm):
+        fn(i)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(n)]
+    for e in evs:  # torch creates the underlying event at its first record()
+        e[0].record()
+        e[1].record()
+    torch.cuda.synchronize()
+    for i in range(n):
+        with _lib.timed_launch(evs[i][0], evs[i][1]):
+            fn(warm + i)
+    torch.cuda.synchronize()
+    return sorted(e[0].elapsed_time(e[1]) for e in evs)
+
+
+def _roofline(kernel, nbytes, ms_sorted, timer, **extra):
+    avg = sum(ms_sorted) / len(ms_sorted)
+    r = {"kernel": kernel, "bound": "hbm", "achieved": round(nbytes / (avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+         "frac": round(nbytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None, "algorithmic_bytes_per_launch": int(nbytes),
+         "avg_launch_ms": round(avg, 4), "median_launch_ms": round(ms_sorted[len(ms_sorted) // 2], 4),
+         "min_launch_ms": round(ms_sorted[0], 4), "max_launch_ms": round(ms_sorted[-1], 4), "launches_timed": len(ms_sorted),
+         "timer": timer}
+    r.update(extra)
+    return r
+
+
+_DISPATCH_TIMER = "HIP events bound to each launch's own dispatch (hipExtLaunchKernelGGL start / stop timestamps)"
+
+
+def _traffic(workload, key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), or None"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(workload, {}).get(key)
+    except Exception:
+        return None
+
+
+def _free():
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+# --------------------------------------------------------------------------------------------- cpu baseline
+
+def cpu_baseline(L, B, H, T, D, sample_layers, reps=5, gpu_check=None):
     """the reference's CPU algorithm for the INT4 dequantise (the roofline kernel's
     op) and quantise of the same V set, on this box's host cores, three ways — each one warm-up +
     `reps` timed repetitions, median reported, on a bounded sample (stated per entry):
@@ -122,16 +202,19 @@ def cpu_baseline(L, B, H, T, D, sample_layers, reps=5):
       vectorised  whole-tensor torch-CPU ops (oracle/vectorised_torch.py), every host core
       literal     the reference's own call structure: one op chain per [B,H,1,D] slice + a T-way
                   cat (oracle/literal_loop.py), torch-CPU, every host core
-    The top-level value / cores / kind / sample are the port's dequantise figure."""
+    plus the two eviction ops as the reference writes them (whole-tensor torch ops) on one [B,H,T,D] tensor.
+    The top-level value / cores / kind / sample are the port's dequantise figure.
+    gpu_check: (q uint8 [1,B,H,T,D/2], scales f32 [1,T], out f16 [1,B,H,T,D]) host copies of one layer of what the
+    GPU dequantised in this run: the port dequantises the same bytes and the largest relative difference is reported
+    (`max_rel_err_vs_gpu`, expected 0.0 — the accuracy gate of SURVEY §8d)."""
     import numpy as np
     import torch as _t
     from oracle import c_oracle as C
     from oracle import literal_loop as LL
     from oracle import vectorised_torch as VT
     cores = os.cpu_count() or 1
-    bpe = BYTES_PER_ELT["int4"]
     rng = np.random.default_rng(42)
-    gbps = lambda n, dt: round(n * bpe / dt / 1e9, 5)  # noqa: E731
+    gbps = lambda n, dt, kind="int4": round(n * BYTES_PER_ELT[kind] / dt / 1e9, 5)  # noqa: E731
 
     # ---- port: scalar C, 1 core --------------------------------------------------------------
     n_layers = max(1, min(sample_layers, L))
@@ -143,11 +226,24 @@ def cpu_baseline(L, B, H, T, D, sample_layers, reps=5):
     xq = (rng.standard_normal((nq_layers, B, H, T, D), dtype=np.float32)).astype(np.float16)
     dq_s = _median_time(lambda: C.quantize_tokens(xq, "int4"), reps)
     nq = nq_layers * B * H * T * D
+    q8 = rng.integers(-127, 128, size=(nq_layers, B, H, T, D), dtype=np.int8)
+    d8 = _median_time(lambda: C.dequantize_tokens(q8, sc[:nq_layers], "int8", D, "f16"), reps)
+    dq8 = _median_time(lambda: C.quantize_tokens(xq, "int8"), reps)
     port = {"value": gbps(n, dt), "unit": "GB/s", "cores": 1, "reps": reps, "kind": "port",
             "sample": f"INT4->fp16 dequantise of {n_layers}/{L} layers of the V set [{n_layers},{B},{H},{T},{D}] "
                       f"({n} elements, median {dt:.3f} s), oracle/kvq_oracle.c scalar",
             "quantise_value": gbps(nq, dq_s),
-            "quantise_sample": f"fp16->INT4 per-token quantise of {nq_layers}/{L} layers ({nq} elements, median {dq_s:.3f} s)"}
+            "quantise_sample": f"fp16->INT4 per-token quantise of {nq_layers}/{L} layers ({nq} elements, median {dq_s:.3f} s)",
+            "int8": {"dequantise_value": gbps(nq, d8, "int8"), "quantise_value": gbps(nq, dq8, "int8"),
+                     "sample": f"{nq_layers}/{L} layers of the K set ({nq} elements; medians {d8:.3f} / {dq8:.3f} s)"}}
+    if gpu_check is not None:
+        gq, gs, gout = gpu_check
+        ref16 = C.dequantize_tokens(gq, gs, "int4", D, "f16")
+        ref, got = ref16.astype(np.float32), gout.astype(np.float32)
+        denom = np.maximum(np.abs(ref), np.float32(1e-30))
+        port["max_rel_err_vs_gpu"] = float(np.max(np.abs(got - ref) / denom))
+        port["max_rel_err_sample"] = (f"layer 0 of the V set as the GPU dequantised it in this run ({got.size} elements); bit patterns equal: "
+                                      f"{bool(np.array_equal(gout.view(np.uint16), ref16.view(np.uint16)))}")
 
     # ---- vectorised: whole-tensor torch-CPU, all cores ------------------------------------------
     _t.set_num_threads(cores)
@@ -175,34 +271,47 @@ def cpu_baseline(L, B, H, T, D, sample_layers, reps=5):
                      f"loop is linear in T) with torch-CPU ops (median {dl:.3f} s), oracle/literal_loop.py",
            "quantise_value": gbps(n_lit, dlq), "quantise_sample": f"same slices, per-slice fp16->INT4 (median {dlq:.3f} s)",
            "torch_threads": _t.get_num_threads()}
-    return {"value": port["value"], "unit": "GB/s", "cores": 1, "kind": "port", "sample": port["sample"], "reps": reps,
-            "host_cores_available": cores, "port": port, "vectorised": vect, "literal": lit}
+
+    # ---- eviction: the reference's own whole-tensor op chains on ONE [B,H,T,D] tensor ---------------
+    xe = _t.from_numpy(xq[0])
+    W, chunk, keep = 256, 64, 256
+    tw = _median_time(lambda: VT.trim_kv_sliding_window(xe, W), reps)
+    tp = _median_time(lambda: VT.chunk_summarize_kv(xe, chunk, keep), reps)
+    Tout = (max(T - keep, 0) + chunk - 1) // chunk + min(keep, T)
+    evict = {"cores": cores, "reps": reps, "kind": "port", "unit": "GB/s",
+             "window_value": round(4.0 * B * H * min(W, T) * D / tw / 1e9, 5),
+             "pool_value": round(2.0 * B * H * D * (T + Tout) / tp / 1e9, 5),
+             "sample": f"trim_kv_sliding_window(W={W}) + materialise and chunk_summarize_kv(chunk={chunk}, keep_last={keep}) of one "
+                       f"[{B},{H},{T},{D}] fp16 tensor as the reference's torch ops (medians {tw * 1e3:.3f} ms / {tp * 1e3:.2f} ms), "
+                       f"oracle/vectorised_torch.py"}
+    out = {"value": port["value"], "unit": "GB/s", "cores": 1, "kind": "port", "sample": port["sample"], "reps": reps,
+           "host_cores_available": cores, "port": port, "vectorised": vect, "literal": lit, "eviction": evict}
+    if "max_rel_err_vs_gpu" in port:
+        out["max_rel_err_vs_gpu"] = port["max_rel_err_vs_gpu"]
+    return out
 
 
-def run_decode(args, rank, world, dev):
+# --------------------------------------------------------------------------------------------- decode (configs[1])
+
+def measure_decode(arch, method, n_prompt, n_new, prompts_per_rank, warmup, world, fused=False, graph=False, extras=True):
     """BASELINE configs[1]: decode tokens/sec + KV-cache MB through KVCacheBenchmarker.benchmark_method
-    (reference benchmarker.py:643-832), prompts sharded over ranks, counters aggregated once."""
+    (reference benchmarker.py:643-832), prompts sharded over ranks, counters aggregated once. Returns the record."""
     import efficient_llm_inference_amd as E
     from efficient_llm_inference_amd import sharding
     from efficient_llm_inference_amd.benchmarking.offline import load_model
-    parts = args.workload.split(":")
-    arch = parts[1] if len(parts) > 1 else DECODE_DEFAULT[0]
-    method = parts[2] if len(parts) > 2 else DECODE_DEFAULT[1]
-    n_prompt = int(parts[3]) if len(parts) > 3 else DECODE_DEFAULT[2]
-    n_new = int(parts[4]) if len(parts) > 4 else DECODE_DEFAULT[3]
     model, tok = load_model(arch, "cuda", torch.float16)
     bm = E.KVCacheBenchmarker(model, tok, device="cuda")
-    bm.fused_attention = bool(args.fused_attention or args.graph_decode)
-    bm.graph_decode = bool(args.graph_decode)
-    prompts = [f"<{n_prompt}>"] * (args.steps * world)
-    for _ in range(args.warmup):
+    bm.fused_attention = bool(fused or graph)
+    bm.graph_decode = bool(graph)
+    prompts = [f"<{n_prompt}>"] * (prompts_per_rank * world)
+    for _ in range(warmup):
         bm.benchmark_method([f"<{min(n_prompt, 64)}>"], method=method, max_new_tokens=8)
     torch.cuda.synchronize()
     sharding.barrier()
     res = sharding.benchmark_sharded(bm, prompts, method, max_new_tokens=n_new)
     base = sharding.benchmark_sharded(bm, prompts, "full_cache", max_new_tokens=n_new)
     extra = {}
-    if method.startswith("quant_") and not bm.fused_attention:
+    if extras and method.startswith("quant_") and not bm.fused_attention:
         # the same method with the model attending over the store directly, eager and as a replayed HIP graph
         # (tolerance-level logits instead of the bit-exact staged path: reported beside `value`, never as it)
         try:
@@ -213,157 +322,248 @@ def run_decode(args, rank, world, dev):
         except RuntimeError as exc:  # head_dim / attention variant the fused kernel does not serve
             extra["fused_attention_unavailable"] = str(exc)[:200]
         finally:
-            bm.fused_attention = bool(args.fused_attention or args.graph_decode)
-            bm.graph_decode = bool(args.graph_decode)
+            bm.fused_attention = bool(fused or graph)
+            bm.graph_decode = bool(graph)
+    cfg = model.config
+    n_layers = getattr(cfg, "num_hidden_layers", None) or cfg.n_layer
+    n_heads = getattr(cfg, "num_attention_heads", None) or cfg.n_head
+    kv_heads = getattr(cfg, "num_key_value_heads", None) or n_heads
+    head_dim = getattr(cfg, "head_dim", None) or cfg.hidden_size // n_heads
+    rec = {
+        "workload": f"decode:{arch}:{method}:{n_prompt}:{n_new}", "tokens_per_sec": round(res["tokens_per_sec"], 2),
+        "est_kv_cache_mb": round(res["est_kv_cache_mb_avg"], 3),
+        "full_cache_tokens_per_sec": round(base["tokens_per_sec"], 2),
+        "full_cache_kv_mb": round(2 * n_layers * kv_heads * head_dim * (n_prompt + n_new) * 2 / 2**20, 3),
+        "vs_full_cache": round(res["tokens_per_sec"] / base["tokens_per_sec"], 3),
+        "elapsed_sec": round(res["elapsed_sec"], 4), "total_new_tokens": int(res["total_new_tokens"]),
+        "gpu_peak_mb": res["gpu_peak_mb"], **extra,
+        "what": "KVCacheBenchmarker.benchmark_method dict keys tokens_per_sec / est_kv_cache_mb_avg (reference benchmarker.py:811-832); "
+                "tokens_per_sec = the staged decode (bit-exact with the reference's loop), fused / graph = attention over the store",
+        "config": {"arch": arch, "method": method, "fused_attention": bm.fused_attention, "graph_decode": bm.graph_decode,
+                   "prompt_tokens": n_prompt, "new_tokens": n_new, "prompts_per_rank": prompts_per_rank,
+                   "weights": "random-init (offline)", "layers": n_layers, "heads": n_heads, "kv_heads": kv_heads, "head_dim": head_dim},
+    }
+    del bm, model
+    _free()
+    return rec
+
+
+def run_decode(args, rank, world, dev):
+    from efficient_llm_inference_amd import sharding
+    parts = args.workload.split(":")
+    arch = parts[1] if len(parts) > 1 else DECODE_DEFAULT[0]
+    method = parts[2] if len(parts) > 2 else DECODE_DEFAULT[1]
+    n_prompt = int(parts[3]) if len(parts) > 3 else DECODE_DEFAULT[2]
+    n_new = int(parts[4]) if len(parts) > 4 else DECODE_DEFAULT[3]
+    rec = measure_decode(arch, method, n_prompt, n_new, args.steps, args.warmup, world, args.fused_attention, args.graph_decode)
     if rank == 0:
-        cfg = model.config
+        cfg = rec.pop("config")
         print(json.dumps({
-            "metric": "decode tokens/sec + KV-cache MB", "value": round(res["tokens_per_sec"], 2), "unit": "tokens/s",
+            "metric": "decode tokens/sec + KV-cache MB", "value": rec["tokens_per_sec"], "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(res["elapsed_sec"] / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
+            "ms_per_step": round(rec["elapsed_sec"] / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16 model, u8/u4 KV", "data": "synthetic",
-            "config": {"workload": args.workload, "arch": arch, "method": method, "fused_attention": bm.fused_attention,
-                       "graph_decode": bm.graph_decode,
-                       "prompt_tokens": n_prompt,
-                       "new_tokens": n_new, "weights": "random-init (offline)",
-                       "layers": getattr(cfg, "num_hidden_layers", None) or cfg.n_layer,
-                       "heads": getattr(cfg, "num_attention_heads", None) or cfg.n_head,
-                       "kv_heads": getattr(cfg, "num_key_value_heads", None) or getattr(cfg, "num_attention_heads", None) or cfg.n_head,
-                       "head_dim": getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads,
-                       "parallelism": f"prompt-shard x{world}, one all_reduce of counters",
+            "config": {"workload": args.workload, **cfg, "parallelism": f"prompt-shard x{world}, one all_reduce of counters",
                        "timing_reduction_backend": sharding.backend()},
-            "est_kv_cache_mb": round(res["est_kv_cache_mb_avg"], 3),
-            "full_cache_tokens_per_sec": round(base["tokens_per_sec"], 2),
-            "vs_full_cache": round(res["tokens_per_sec"] / base["tokens_per_sec"], 3),
-            "gpu_peak_mb": res["gpu_peak_mb"], **extra,
+            **{k: v for k, v in rec.items() if k not in ("workload", "tokens_per_sec", "what")},
         }), flush=True)
 
 
-def run_evict(args, rank, world, dev):
+# --------------------------------------------------------------------------------------------- eviction (configs[4])
+
+def measure_evict(name, dev, rank, world, steps, warmup):
     """configs[4] per-rank slice: one STEP = trim_kv_sliding_window + chunk_summarize_kv over the
     whole legacy tuple (64 tensors of [8,8,32768,128] fp16): two launches, inputs resident."""
     import efficient_llm_inference_amd as E
-    from efficient_llm_inference_amd import sharding
-    L, B, H, T, D, W, chunk, keep = EVICT[args.workload]
+    from efficient_llm_inference_amd import _lib, sharding
+    from efficient_llm_inference_amd.kernels import chunk_summary_len
+    L, B, H, T, D, W, chunk, keep = EVICT[name]
     torch.manual_seed(42 + rank)
     past = tuple((torch.randn(B, H, T, D, device=dev, dtype=torch.float16),
                   torch.randn(B, H, T, D, device=dev, dtype=torch.float16)) for _ in range(L))
-    from efficient_llm_inference_amd.kernels import chunk_summary_len
     Tout = chunk_summary_len(T, chunk, keep)
     n_t = 2 * L
     bytes_win = 4.0 * n_t * B * H * W * D                      # 2 B read + 2 B write per kept element
     bytes_pool = 2.0 * n_t * B * H * D * (T + Tout)            # read every token once, write Tout rows
     step_bytes = bytes_win + bytes_pool
+    k_win = _kernels_of(lambda: E.trim_kv_sliding_window(past, W))
+    k_pool = _kernels_of(lambda: E.chunk_summarize_kv(past, chunk_size=chunk, keep_last=keep))
 
     def step(evs=None):
-        if evs is not None:
-            evs[0].record()
-        E.trim_kv_sliding_window(past, W)
-        if evs is not None:
-            evs[1].record()
-        E.chunk_summarize_kv(past, chunk_size=chunk, keep_last=keep)
-        if evs is not None:
-            evs[2].record()
+        if evs is None:
+            E.trim_kv_sliding_window(past, W)
+            E.chunk_summarize_kv(past, chunk_size=chunk, keep_last=keep)
+            return
+        with _lib.timed_launch(evs[0], evs[1]):
+            E.trim_kv_sliding_window(past, W)
+        with _lib.timed_launch(evs[2], evs[3]):
+            E.chunk_summarize_kv(past, chunk_size=chunk, keep_last=keep)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+    for evs in events:
+        for e in evs:
+            e.record()
     torch.cuda.synchronize()
     sharding.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(events[i])
     torch.cuda.synchronize()
     sharding.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    w_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
-    p_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
+    w_ms = sorted(e[0].elapsed_time(e[1]) for e in events)
+    p_ms = sorted(e[2].elapsed_time(e[3]) for e in events)
     elapsed = sharding.max_over_ranks(elapsed, dev)  # the step takes as long as the slowest rank
+    rec = {
+        "value": round(step_bytes * world / (elapsed / steps) / 1e9, 1), "unit": "GB/s", "steps": steps,
+        "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "config": {"workload": name, "shape_per_rank_L2BHTD": [L, 2, B, H, T, D], "window": W,
+                   "chunk_size": chunk, "keep_last": keep, "global_batch": B * world,
+                   "step": "trim_kv_sliding_window(past, 256) + chunk_summarize_kv(past, 64, 256) over the 64-tensor legacy tuple "
+                           "(public functions: output allocation + one launch each)",
+                   "parallelism": f"batch-shard x{world} (8 rows per GPU), no collective",
+                   "timing_reduction_backend": sharding.backend()},
+        "roofline": _roofline(k_pool, bytes_pool, p_ms, _DISPATCH_TIMER, what="chunk_summarize_kv (mean-pool + recent tail)",
+                              traffic=_traffic(name, "chunk_pool")),
+        "roofline_window": _roofline(k_win, bytes_win, w_ms, _DISPATCH_TIMER, what="trim_kv_sliding_window, materialised"),
+    }
+    del past
+    _free()
+    return rec
+
+
+def run_evict(args, rank, world, dev):
+    rec = measure_evict(args.workload, dev, rank, world, args.steps, args.warmup)
     if rank == 0:
         print(json.dumps({
             "metric": "KV eviction GB/s vs HBM roofline (sliding_window + chunk_summary step)",
-            "value": round(step_bytes * world / (elapsed / args.steps) / 1e9, 1), "unit": "GB/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "dtype_detail": "fp16 in/out, fp32 accumulate",
-            "data": "synthetic",
-            "config": {"workload": args.workload, "shape_per_rank_L2BHTD": [L, 2, B, H, T, D], "window": W,
-                       "chunk_size": chunk, "keep_last": keep, "global_batch": B * world,
-                       "parallelism": f"batch-shard x{world} (8 rows per GPU), no collective",
-                       "timing_reduction_backend": sharding.backend()},
-            "roofline": {"kernel": "chunk_pool_vec_k<f16>", "bound": "hbm",
-                         "achieved": round(bytes_pool / (p_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(bytes_pool / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": int(bytes_pool), "avg_launch_ms": round(p_ms, 4)},
-            "roofline_window": {"kernel": "copy_rows_k", "achieved": round(bytes_win / (w_ms * 1e-3) / 1e9, 1),
-                                "frac": round(bytes_win / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                "algorithmic_bytes_per_launch": int(bytes_win), "avg_launch_ms": round(w_ms, 4),
-                                "note": "includes torch.empty + host launch path; 0.5 GB per launch"},
+            "value": rec["value"], "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "dtype_detail": "fp16 in/out, fp32 accumulate", "data": "synthetic", "config": rec["config"],
+            "roofline": rec["roofline"], "roofline_window": rec["roofline_window"],
         }), flush=True)
 
 
-def run_sharded_quant(args, rank, world, dev):
-    """One STEP = quantise_tokens_batch_sharded of the K set (INT8) and the V set (INT4) of every layer: two abs-max
-    launches, two all_reduce(MAX) of a [L,T] fp32 table (the ONLY collective that carries path data), two quantise
-    launches. Each rank holds B_global / world batch rows."""
+# --------------------------------------------------------------------------------------------- sharded quantise (§8e)
+
+def measure_sharded_quant(name, dev, rank, world, steps, warmup):
+    """One STEP = quantise_tokens_batch_sharded of the K set (INT8) and the V set (INT4) of every layer: per layer chunk an
+    abs-max launch, an all_reduce(MAX) of its [Lc,T] fp32 table on a side stream (the ONLY collective that carries path
+    data) and a quantise launch that re-reads the chunk while the Infinity Cache still holds it. Each rank holds
+    B_global / world batch rows."""
     from efficient_llm_inference_amd import sharding
-    L, Bg, H, T, D = SHARDQ[args.workload]
+    L, Bg, H, T, D = SHARDQ[name]
     rows = sharding.shard_batch_rows(Bg)
     Bl = len(rows)
     torch.manual_seed(42 + rank)
     k = torch.randn(L, Bl, H, T, D, device=dev, dtype=torch.float16)
     v = torch.randn(L, Bl, H, T, D, device=dev, dtype=torch.float16)
     step_bytes = L * Bg * H * T * D * (BYTES_PER_ELT["int8"] + BYTES_PER_ELT["int4"])  # whole job, single-pass bytes
+    outs = [sharding.ShardedQuantBuffers(k, "int8"), sharding.ShardedQuantBuffers(v, "int4")]
 
     def step():
-        sharding.quantize_tokens_batch_sharded(k, "int8")
-        sharding.quantize_tokens_batch_sharded(v, "int4")
+        sharding.quantize_tokens_batch_sharded(k, "int8", out=outs[0])
+        sharding.quantize_tokens_batch_sharded(v, "int4", out=outs[1])
 
-    for _ in range(args.warmup):
+    kernels = _kernels_of(step)
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     sharding.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     sharding.barrier()
     torch.cuda.synchronize()
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    rec = {
+        "value": round(step_bytes / (elapsed / steps) / 1e9, 2), "unit": "GB/s", "steps": steps,
+        "ms_per_step": round(elapsed / steps * 1e3, 4), "scaling": "strong",
+        "frac_of_hbm_peak_per_gpu": round(step_bytes / world / (elapsed / steps) / 1e9 / HBM_PEAK_GBPS, 4),
+        "kernels": kernels,
+        "config": {"workload": name, "shape_L_Bglobal_H_T_D": [L, Bg, H, T, D], "batch_rows_per_rank": Bl,
+                   "step": "per layer chunk: kvq_absmax_tokens -> all_reduce(MAX) [Lc,T] fp32 (side stream) -> "
+                           "kvq_quant_tokens_from_absmax; K (INT8) then V (INT4)",
+                   "layer_chunks": outs[0].n_chunks, "collective": "all_reduce(MAX)", "collective_backend": sharding.backend() or "none (1 rank)",
+                   "collective_bytes_per_step": 2 * L * T * 4, "bytes_per_step_single_pass": int(step_bytes),
+                   "parallelism": f"batch rows sharded x{world}; one all_reduce(MAX) per layer chunk, set and step",
+                   "timing_reduction_backend": sharding.backend()},
+    }
+    del k, v, outs
+    _free()
+    return rec
+
+
+def run_sharded_quant(args, rank, world, dev):
+    rec = measure_sharded_quant(args.workload, dev, rank, world, args.steps, args.warmup)
     if rank == 0:
         print(json.dumps({
             "metric": "batch-sharded KV quantise step (INT8 K + INT4 V, one scale per token across the WHOLE batch), GB/s",
-            "value": round(step_bytes / (elapsed / args.steps) / 1e9, 2), "unit": "GB/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "shape_L_Bglobal_H_T_D": [L, Bg, H, T, D], "batch_rows_per_rank": Bl,
-                       "step": "kvq_absmax_tokens -> all_reduce(MAX) [L,T] fp32 -> kvq_quant_tokens_from_absmax, K then V",
-                       "collective_bytes_per_step": 2 * L * T * 4,
-                       "parallelism": f"batch rows sharded x{world}; one all_reduce(MAX) per set and step",
-                       "timing_reduction_backend": sharding.backend()},
+            "value": rec["value"], "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "config": rec["config"], "kernels": rec["kernels"],
+            "frac_of_hbm_peak_per_gpu": rec["frac_of_hbm_peak_per_gpu"],
         }), flush=True)
 
 
-def _traffic(workload, key):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), or None"""
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(workload, {}).get(key)
-    except Exception:
-        return None
+# --------------------------------------------------------------------------------------------- per-shape rooflines
 
+def measure_shape(name, dev, rank, iters=24):
+    """Dequantise + quantise rooflines of one KV shape, both kinds, with `n_rot` independent input sets / stores /
+    outputs visited round-robin so that nothing is served from the 256 MiB Infinity Cache (a 96 MiB INT4 store
+    dequantised again and again would be)."""
+    from efficient_llm_inference_amd import kernels as K
+    from efficient_llm_inference_amd.quantization.ops import _KVStore
+    L, B, H, T, D, mode, n_rot = SHAPE_RECORDS[name]
+    torch.manual_seed(42 + rank)
+    n_elts = L * B * H * T * D
+    xs = [torch.randn(L, B, H, T, D, device=dev, dtype=torch.float16) for _ in range(n_rot)]
+    outs = [torch.empty(L, B, H, T, D, device=dev, dtype=torch.float16) for _ in range(n_rot)]
+    for o in outs:
+        o.zero_()
+    rec = {"shape_LBHTD": [L, B, H, T, D], "config_mode": mode, "rotating_sets": n_rot, "rows_x_head_dim": f"{B * H} x {D}",
+           "working_set_mb": round(n_rot * n_elts * (2 + 2 + 1.5) / 2**20, 1)}
+    for kind in ("int8", "int4"):
+        stores = []
+        for i in range(n_rot):
+            st = _KVStore(kind, L, dev)
+            st.reserve(T)
+            st.append(xs[i])
+            stores.append(st)
+        ws = stores[0]._workspace(L * T)
+        k_q = _kernels_of(lambda: K.quant_tokens(xs[0], stores[0].q[:, :, :, :T], stores[0].scales[:, :T], ws, kind))
+        k_d = _kernels_of(lambda: stores[0].dequant(torch.float16, out=outs[0]))
+        q_ms = _time_launches(lambda i: K.quant_tokens(xs[i % n_rot], stores[i % n_rot].q[:, :, :, :T], stores[i % n_rot].scales[:, :T], ws, kind), iters)
+        d_ms = _time_launches(lambda i: stores[i % n_rot].dequant(torch.float16, out=outs[(i + 1) % n_rot]), iters)
+        nbytes = n_elts * BYTES_PER_ELT[kind]
+        rec[f"dequant_{kind}"] = _roofline(k_d, nbytes, d_ms, _DISPATCH_TIMER)
+        rec[f"quant_{kind}"] = _roofline(k_q, nbytes, q_ms, _DISPATCH_TIMER)
+        del stores
+    vk = MODE_KINDS[mode][1]
+    rec["roofline"] = rec[f"dequant_{vk}"]            # the config's own kind (V set)
+    rec["roofline_quantise"] = rec[f"quant_{vk}"]
+    del xs, outs
+    _free()
+    return rec
+
+
+# --------------------------------------------------------------------------------------------- decode attention (N1)
 
 def run_attn(args, rank, world, dev):
     """One STEP = the attention of one decode step over the quantised store of every layer
     (kvq_decode_attn per layer: split-T partial kernel + merge), new token's exact K/V included.
     Side measurement: the same step as the staged path runs it (torch SDPA over the fp16 copy)."""
     import efficient_llm_inference_amd as E
-    from efficient_llm_inference_amd import _lib
     from efficient_llm_inference_amd import kernels as K
     from efficient_llm_inference_amd import sharding
     L, B, Hq, Hkv, T, D, mode = ATTN[args.workload]
-    kk, vk = {"int8": ("int8", "int8"), "int4": ("int4", "int4"), "mixed": ("int8", "int4")}[mode]
+    kk, vk = MODE_KINDS[mode]
     torch.manual_seed(42 + rank)
     qc = E.QuantizedKVCache(n_layers=L, mode=mode, device="cuda", compute_dtype=torch.float16)
     qc.reserve(T)
@@ -390,6 +590,7 @@ def run_attn(args, rank, world, dev):
         else:  # kvq_decode_step_layers: ONE host call enqueues every layer's launch
             K.decode_step_layers(plan, T, ws, sm)
 
+    kernels = _kernels_of(step)
     for _ in range(args.warmup):
         step()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -431,12 +632,10 @@ def run_attn(args, rank, world, dev):
                        "step": "one decode step = every layer's attention over the store: "
                                + ("kvq_decode_attn per layer" if args.per_layer_calls else "ONE kvq_decode_step_layers call")
                                + ", host launch gaps included",
-                       "launches_per_layer": 1 if (D in (64, 128) and 3 <= Hq // Hkv <= 16 and _lib.get_tunable("attn_fused")) else 2,
+                       "launches_per_layer": len(kernels.split(" + ")),
                        "bytes_per_step": int(step_bytes), "parallelism": f"batch-shard x{world}, no collective",
                        "timing_reduction_backend": sharding.backend()},
-            "roofline": {"kernel": ("decode_attn_fused_mfma_k (one launch per layer)" if _lib.get_tunable("attn_fused") and D in (64, 128) and 3 <= Hq // Hkv <= 16
-                                    else ("decode_attn_partial_mfma_k" if D in (64, 128) and 3 <= Hq // Hkv <= 16 else "decode_attn_partial_k")
-                                    + " + decode_attn_merge_k (per layer)"), "bound": "hbm",
+            "roofline": {"kernel": kernels + " (per layer)", "bound": "hbm",
                          "achieved": round(layer_bytes / (layer_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(layer_bytes / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": _traffic(args.workload, "decode_attn_per_layer_call"),
                          "algorithmic_bytes_per_launch": int(layer_bytes), "avg_launch_ms": round(layer_ms, 5),
@@ -448,6 +647,8 @@ def run_attn(args, rank, world, dev):
             "fp16_kv_cache_mb": round(L * 4 * B * Hkv * T * D / 2**20, 3),
         }), flush=True)
 
+
+# --------------------------------------------------------------------------------------------- launcher
 
 def _free_port():
     import socket
@@ -507,6 +708,18 @@ def launch_ranks(args, argv):
     sys.stdout.flush()
 
 
+def _abort_rank(rank, world, exc):
+    """A rank whose workload raised must not walk into sharding.shutdown()'s barrier (its peers sit in a collective
+    of the workload: the barrier would block until the 300 s gloo timeout and bury the exception). Print the error
+    and leave at once with a non-zero code; the launcher sees it and terminates the peers."""
+    import traceback
+    sys.stderr.write(f"bench.py: rank {rank}/{world} failed in its workload:\n")
+    traceback.print_exception(type(exc), exc, exc.__traceback__, file=sys.stderr)
+    sys.stderr.flush()
+    sys.stdout.flush()
+    os._exit(1)
+
+
 def selftest_rank(args, rank, world):
     """--launcher-selftest: what a rank does with no GPU at all (CPU test of the launcher): join the
     gloo group, reduce the ranks, report."""
@@ -514,6 +727,8 @@ def selftest_rank(args, rank, world):
     if os.environ.get("KVQ_SELFTEST_FAIL_RANK") == str(rank):  # test hook: a rank that dies before the rendezvous
         raise SystemExit(3)
     be = sharding.init_distributed(rank, world, None) if world > 1 else None
+    if os.environ.get("KVQ_SELFTEST_RAISE_RANK") == str(rank):  # test hook: a rank whose WORKLOAD raises after the rendezvous
+        _abort_rank(rank, world, RuntimeError("selftest: workload failure"))
     seen = sharding.max_over_ranks(float(rank))
     t = torch.tensor([float(rank)])
     if world > 1:
@@ -579,9 +794,12 @@ def main():
             run_dequant(args, rank, world, dev, backend)
         else:
             raise SystemExit(f"unknown workload {args.workload}")
-    finally:
+    except Exception as exc:  # noqa: BLE001
         if world > 1:
-            sharding.shutdown()
+            _abort_rank(rank, world, exc)
+        raise
+    if world > 1:
+        sharding.shutdown()
 
 
 READ_CEIL_GBPS, WRITE_CEIL_GBPS = 7000.0, 6900.0  # profiles/r02ae_microbench_read_write_ceilings.txt
@@ -597,12 +815,34 @@ def _mix_bound(n_elts, kind, measured_ms):
             "source": "profiles/r02ae_microbench_read_write_ceilings.txt (one-wave workgroups; reads and writes add)"}
 
 
+_WORLD = 1
+
+
+def _subrecord(fn, *a, **kw):
+    """a sub-record must never cost the headline: its failure is recorded in its place. (With several ranks a failure
+    on one of them cannot be swallowed — its peers sit in the sub-record's barriers — and takes the job down.)"""
+    if _WORLD > 1:
+        return fn(*a, **kw)
+    try:
+        return fn(*a, **kw)
+    except Exception as exc:  # noqa: BLE001
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        _free()
+        return {"error": f"{type(exc).__name__}: {exc}"[:400]}
+
+
 def run_dequant(args, rank, world, dev, backend):
-    """The headline workload (module docstring): one STEP = to_past_key_values() of the quantised cache."""
+    """The headline workload (module docstring): one STEP = dequantise the whole quantised cache (2 launches)."""
     import efficient_llm_inference_amd as E
+    from efficient_llm_inference_amd import _lib as _l
+    from efficient_llm_inference_amd import kernels as _k
     from efficient_llm_inference_amd import sharding
+    global _WORLD
+    _WORLD = world
     L, B, H, T, D, mode = WORKLOADS[args.workload]
-    kk, vk = {"int8": ("int8", "int8"), "int4": ("int4", "int4"), "mixed": ("int8", "int4")}[mode]
+    kk, vk = MODE_KINDS[mode]
+    t_run0 = time.perf_counter()
 
     # ---- build the quantised cache once (each rank its own prompt: seed 42 + rank) ------------
     torch.manual_seed(42 + rank)
@@ -629,44 +869,39 @@ def run_dequant(args, rank, world, dev, backend):
     for ko, vo in outs:  # first touch of the fresh pages happens here, not in a timed step
         ko.zero_()
         vo.zero_()
-
-    # side measurement, outside the timed region: the prefill quantise kernels (rows a1/a2) on the
-    # same tensors, re-quantising into the same store (identical bytes every time)
-    from efficient_llm_inference_amd import kernels as _k
-    quant_info = {}
-    for name, tensors in (("k", [k for k, _ in past]), ("v", [v for _, v in past])):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        # the output alternates between the rotating caches' stores (identical bytes every time): a 268 MB INT4 store
-        # written with write-back stores again and again would otherwise sit in the 256 MB Infinity Cache
-        stores = [getattr(c, "_" + name) for c in caches]
-        store = stores[0]
-        ws = store._workspace(L * T)
-        for it in range(7):
-            if it == 1:
-                ev[0].record()
-            st_ = stores[it % len(stores)]
-            _k.quant_tokens(tensors, st_.q[:, :, :, :T], st_.scales[:, :T], ws, st_.kind)
-        ev[1].record()
-        torch.cuda.synchronize()
-        ms = ev[0].elapsed_time(ev[1]) / 6
-        qbytes = L * B * H * T * D * BYTES_PER_ELT[store.kind]  # 2 B read + 1 or 0.5 B written per element
-        quant_info[f"quant_{store.kind}"] = {"avg_launch_ms": round(ms, 4), "achieved": round(qbytes / (ms * 1e-3) / 1e9, 1),
-                                             "frac": round(qbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                             "algorithmic_bytes_per_launch": int(qbytes), "set": name.upper()}
     n_elts = L * B * H * T * D  # per K or V set
     bytes_k = n_elts * BYTES_PER_ELT[kk]
     bytes_v = n_elts * BYTES_PER_ELT[vk]
     step_bytes = bytes_k + bytes_v
 
-    from efficient_llm_inference_amd import _lib as _l
+    # side measurement, outside the timed region: the prefill quantise kernels (rows a1/a2) on the same tensors,
+    # re-quantising into the rotating caches' stores (identical bytes every time; a 268 MB INT4 store written again
+    # and again would otherwise sit in the 256 MB Infinity Cache)
+    quant_info = {}
+    for name, tensors in (("k", [k for k, _ in past]), ("v", [v for _, v in past])):
+        stores = [getattr(c, "_" + name) for c in caches]
+        ws = stores[0]._workspace(L * T)
+
+        def qfn(i, tensors=tensors, stores=stores, ws=ws):
+            st_ = stores[i % len(stores)]
+            _k.quant_tokens(tensors, st_.q[:, :, :, :T], st_.scales[:, :T], ws, st_.kind)
+
+        kern = _kernels_of(lambda: qfn(0))
+        ms = _time_launches(qfn, 12)
+        quant_info[f"quant_{stores[0].kind}"] = _roofline(kern, n_elts * BYTES_PER_ELT[stores[0].kind], ms, _DISPATCH_TIMER, set=name.upper())
+
+    k_kernel = _kernels_of(lambda: caches[0]._k.dequant(torch.float16, out=outs[0][0]))
+    v_kernel = _kernels_of(lambda: caches[0]._v.dequant(torch.float16, out=outs[0][1]))
 
     def step(i, evs=None):
         ko, vo = outs[i & 1]
         c = caches[i % len(caches)]
         c._k.dequant(torch.float16, out=ko)  # all layers of K: one launch
         if evs is not None:
-            _l.time_next_launch(evs[0], evs[1])  # the INT4 launch's own start / stop timestamps
-        c._v.dequant(torch.float16, out=vo)  # all layers of V: one launch (the roofline kernel)
+            with _l.timed_launch(evs[0], evs[1]):  # the INT4 launch's own start / stop timestamps
+                c._v.dequant(torch.float16, out=vo)
+        else:
+            c._v.dequant(torch.float16, out=vo)  # all layers of V: one launch (the roofline kernel)
 
     for i in range(args.warmup):
         step(i)
@@ -690,35 +925,38 @@ def run_dequant(args, rank, world, dev, backend):
     elapsed = time.perf_counter() - t0
 
     v_each = sorted(e[0].elapsed_time(e[1]) for e in events)
-    v_ms = sum(v_each) / args.steps
     elapsed = sharding.max_over_ranks(elapsed, dev)  # the step takes as long as the slowest rank
 
-    # side measurement, outside the timed region: the INT8 (K) launch on the same rotation of caches / outputs
-    kev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    k_ms, k_n = 0.0, 8
-    for i in range(k_n + 2):
-        ko, _ = outs[i & 1]
-        c = caches[i % len(caches)]
-        if i >= 2:
-            kev[0].record()
-        c._k.dequant(torch.float16, out=ko)
-        if i >= 2:
-            kev[1].record()
-            torch.cuda.synchronize()
-            k_ms += kev[0].elapsed_time(kev[1])
-    k_ms /= k_n
+    # side measurements, outside the timed region, same rotation of caches / outputs: a longer sample of both launches
+    # (the timed region's K samples are enough for a mean, thin for a min / max) ...
+    v_long = _time_launches(lambda i: caches[i % len(caches)]._v.dequant(torch.float16, out=outs[i & 1][1]), 100, warm=0)
+    k_long = _time_launches(lambda i: caches[i % len(caches)]._k.dequant(torch.float16, out=outs[i & 1][0]), 100, warm=0)
+    # ... and the PUBLIC call the step stands for: to_past_key_values(copy=True) = two torch.empty + the same two launches
+    # + the tuple of per-layer views, wall clock over 20 calls
+    for i in range(2):
+        caches[i % len(caches)].to_past_key_values(copy=True)
+    torch.cuda.synchronize()
+    tp0 = time.perf_counter()
+    n_pub = 20
+    for i in range(n_pub):
+        pkv = caches[i % len(caches)].to_past_key_values(copy=True)
+    torch.cuda.synchronize()
+    pub_ms = (time.perf_counter() - tp0) / n_pub * 1e3
+    del pkv
 
+    gpu_check = None
+    if rank == 0 and not args.no_cpu_baseline and world == 1:  # one layer of what the GPU just dequantised, for the port to check
+        c0 = caches[0]
+        c0._v.dequant(torch.float16, out=outs[0][1])
+        torch.cuda.synchronize()
+        gpu_check = (c0._v.q[:1, :, :, :T].contiguous().cpu().numpy(), c0._v.scales[:1, :T].contiguous().cpu().numpy(),
+                     outs[0][1][:1].cpu().numpy())
+
+    line = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = step_bytes * world / (elapsed / args.steps) / 1e9
-        target_ms, target_bytes, target_name = (v_ms, bytes_v, f"{vk} dequant (V set)")
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 PMC passes (see profiles/README.md)
-            try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get(f"dequant_{vk}")
-            except Exception:
-                traffic = None
+        traffic = _traffic(args.workload, f"dequant_{vk}")
         line = {
             "metric": f"KV dequant GB/s vs HBM roofline (quant_{mode} step: {kk.upper()} K + {vk.upper()} V -> fp16)",
             "value": round(value, 1),
@@ -734,37 +972,50 @@ def run_dequant(args, rank, world, dev, backend):
             "dtype_detail": "int8 / packed-int4 in, fp32 multiply, fp16 out",
             "data": "synthetic",
             "config": {"workload": args.workload, "shape_LBHTD": [L, B, H, T, D], "mode": mode,
-                       "step": "QuantizedKVCache.to_past_key_values(): 2 launches (K set, V set)",
+                       "step": "_KVStore.dequant(out=rotating buffer) of the K set and of the V set: 2 launches — the store-level calls "
+                               "of QuantizedKVCache.to_past_key_values(copy=True), whose own cost is `public_api`",
                        "bytes_per_step": int(step_bytes), "parallelism": f"batch-shard x{world}, no collective",
                        "timing_reduction_backend": backend, "rotating_caches": len(caches)},
-            "roofline": {
-                "kernel": f"dequant_tokens_fast_k<{vk}>", "what": target_name, "bound": "hbm",
-                "achieved": round(target_bytes / (target_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(target_bytes / (target_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                "traffic": traffic, "traffic_source": "profiles/traffic.json (rocprofv3 PMC passes of this command, committed; "
-                                                      "not re-measured in this run)" if traffic is not None else None,
-                "algorithmic_bytes_per_launch": int(target_bytes),
-                "avg_launch_ms": round(target_ms, 4), "median_launch_ms": round(v_each[len(v_each) // 2], 4),
-                "min_launch_ms": round(v_each[0], 4), "max_launch_ms": round(v_each[-1], 4),
-                "timer": "HIP events bound to every INT4 launch of the timed region (hipExtLaunchKernelGGL start / stop timestamps)",
+            "roofline": _roofline(
+                v_kernel, bytes_v, v_each, "HIP events bound to every INT4 launch of the timed region (hipExtLaunchKernelGGL start / stop timestamps)",
+                what=f"{vk} dequant (V set)", traffic=traffic,
+                traffic_source="profiles/traffic.json (rocprofv3 PMC passes of this command, committed; not re-measured in this run)" if traffic is not None else None,
                 # informational, beside the contract's frac: what this chip moves for THIS read / write mix. Reads and
                 # writes add on its memory system; the two rates are the one-wave-workgroup ceilings measured with
                 # kvq_microbench segread / fillchunk (profiles/r02ae_microbench_read_write_ceilings.txt), not this run's.
-                "mix_bound": _mix_bound(n_elts, vk, target_ms),
-            },
-            "roofline_k": {
-                "kernel": f"dequant_tokens_fast_k<{kk}>", "bound": "hbm",
-                "achieved": round(bytes_k / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(bytes_k / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                "algorithmic_bytes_per_launch": int(bytes_k), "avg_launch_ms": round(k_ms, 4),
-                "timer": "HIP events around 8 launches after the timed region",
-            },
+                mix_bound=_mix_bound(n_elts, vk, sum(v_each) / len(v_each)),
+                extended=_roofline(v_kernel, bytes_v, v_long, _DISPATCH_TIMER + ", 100 launches after the timed region")),
+            "roofline_k": _roofline(k_kernel, bytes_k, k_long, _DISPATCH_TIMER + ", 100 launches after the timed region", what=f"{kk} dequant (K set)"),
             "roofline_quantise": quant_info,
+            "public_api": {"call": "QuantizedKVCache.to_past_key_values(copy=True)", "ms_per_call": round(pub_ms, 4),
+                           "value": round(step_bytes / (pub_ms * 1e-3) / 1e9, 1), "unit": "GB/s", "calls_timed": n_pub,
+                           "vs_raw_store_step": round(ms_per_step / pub_ms, 4),
+                           "what": "wall clock of the public method (allocates 2 x 1 GiB, 2 launches, tuple of 32 (k, v) views), rotating caches"},
             "est_kv_cache_mb": round(est_mb, 3),
             "fp16_kv_cache_mb": round(2 * n_elts * 2 / 2**20, 3),
         }
+    del past, caches, qc, outs
+    _free()
+
+    # ---- the rest of BASELINE.json's metric: sub-records (each guarded: a failure is recorded, never fatal) -----------
+    if not args.no_subrecords and args.workload == "llama3_8b_mixed_seq16k":
+        sub_t0 = time.perf_counter()
+        decode = _subrecord(measure_decode, *DECODE_DEFAULT, 1, 1, world)
+        cfgs = {}
+        for name in SHAPE_RECORDS:
+            cfgs[name] = _subrecord(measure_shape, name, dev, rank)
+        cfgs["llama3_8b_evict_seq32k"] = _subrecord(measure_evict, "llama3_8b_evict_seq32k", dev, rank, world, 6, 2)
+        shq = _subrecord(measure_sharded_quant, "llama3_8b_batch64_sharded_prefill512", dev, rank, world, 10, 3) if world > 1 else None
+        if rank == 0:
+            line["decode"] = decode
+            line["configs"] = cfgs
+            if shq is not None:
+                line["sharded_quant"] = shq
+            line["subrecords_s"] = round(time.perf_counter() - sub_t0, 2)
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            line["cpu_baseline"] = cpu_baseline(L, B, H, T, D, args.cpu_sample_layers)
+            line["cpu_baseline"] = cpu_baseline(L, B, H, T, D, args.cpu_sample_layers, gpu_check=gpu_check)
+        line["run_s"] = round(time.perf_counter() - t_run0, 2)
         print(json.dumps(line), flush=True)
 
 

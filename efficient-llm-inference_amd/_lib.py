@@ -9,6 +9,7 @@ missing library is an error.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 import threading
@@ -17,7 +18,10 @@ from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_int64,
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkvq_hip.so")
+# KVQ_HIP_LIB: load another build of the same ABI instead — the A-B library (lib/ab/libkvq_hip.so, `make -C csrc ab`)
+# for `pytest -m ab` and the sweep scripts, or a calibration build. Unset = the shipped library.
+LIB_PATH = os.environ.get("KVQ_HIP_LIB") or os.path.join(_HERE, "lib", "libkvq_hip.so")
+AB_LIB_PATH = os.path.join(_HERE, "lib", "ab", "libkvq_hip.so")
 
 KVQ_F16, KVQ_BF16, KVQ_F32 = 0, 1, 2
 _DTYPE_CODE = {torch.float16: KVQ_F16, torch.bfloat16: KVQ_BF16, torch.float32: KVQ_F32}
@@ -45,8 +49,11 @@ EXPORTS = (
     "kvq_decode_step_dev",
     "kvq_decode_step_layers",
     "kvq_time_next_launch",
+    "kvq_kernel_log_clear",
+    "kvq_kernel_log",
     "kvq_set_tunable",
     "kvq_get_tunable",
+    "kvq_is_ab_build",
 )
 
 
@@ -130,6 +137,12 @@ def _declare(lib):
     lib.kvq_chunk_summary_len.argtypes = [c_int64, c_int64, c_int64]
     lib.kvq_time_next_launch.restype = c_int
     lib.kvq_time_next_launch.argtypes = [P, P]
+    lib.kvq_kernel_log_clear.restype = None
+    lib.kvq_kernel_log_clear.argtypes = []
+    lib.kvq_kernel_log.restype = c_int64
+    lib.kvq_kernel_log.argtypes = [ctypes.c_char_p, c_int64]
+    lib.kvq_is_ab_build.restype = c_int
+    lib.kvq_is_ab_build.argtypes = []
     lib.kvq_set_tunable.restype = c_int
     lib.kvq_set_tunable.argtypes = [c_char_p, c_int64]
     lib.kvq_get_tunable.restype = c_int64
@@ -192,10 +205,51 @@ def ptr_array(ptrs):
     return arr
 
 
-def time_next_launch(start: "torch.cuda.Event", stop: "torch.cuda.Event") -> None:
-    """The next token-table dequantise launch records its own start / stop timestamps into these two events
-    (kvq_time_next_launch). Both must have been recorded once before (torch creates the HIP event lazily)."""
-    check(load().kvq_time_next_launch(c_void_p(start.cuda_event), c_void_p(stop.cuda_event)), "time_next_launch")
+@contextlib.contextmanager
+def timed_launch(start: "torch.cuda.Event", stop: "torch.cuda.Event"):
+    """``with timed_launch(e0, e1): kernels.<one-launch call>(...)`` — the first kernel launched inside the block
+    records its own dispatch start / stop timestamps into the two events (kvq_time_next_launch ->
+    hipExtLaunchKernelGGL): the kernel's duration as rocprofv3 reports it, no queue gaps, no barrier packets. Both
+    events must have been recorded once before (torch creates the HIP event lazily). The pair is disarmed on the way
+    out whatever happened inside (a shape error raised before the library was reached must not leave handles armed
+    for a later, unrelated launch)."""
+    lib = load()
+    check(lib.kvq_time_next_launch(c_void_p(start.cuda_event), c_void_p(stop.cuda_event)), "time_next_launch")
+    try:
+        yield
+    finally:
+        lib.kvq_time_next_launch(None, None)
+
+
+def kernel_log_clear() -> None:
+    load().kvq_kernel_log_clear()
+
+
+def kernel_log() -> list:
+    """Demangled names of the distinct kernels this thread has launched since :func:`kernel_log_clear`, in first-launch
+    order, shortened the way the profiles quote them (no ``void`` / ``kvq::`` / argument list)."""
+    buf = ctypes.create_string_buffer(16384)
+    load().kvq_kernel_log(buf, len(buf))
+    out = []
+    for name in buf.value.decode("utf-8", "replace").splitlines():
+        name = name.strip()
+        if name.startswith("void "):
+            name = name[5:]
+        depth, cut = 0, len(name)
+        for i, ch in enumerate(name):  # drop the trailing "(kvq::Args ...)": the last top-level parenthesis group
+            if ch == "<":
+                depth += 1
+            elif ch == ">":
+                depth -= 1
+            elif ch == "(" and depth == 0:
+                cut = i
+                break
+        out.append(name[:cut].replace("kvq::", ""))
+    return out
+
+
+def is_ab_build() -> bool:
+    return bool(load().kvq_is_ab_build())
 
 
 def set_tunable(key: str, value: int) -> None:
@@ -208,6 +262,7 @@ def get_tunable(key: str) -> int:
 
 __all__ = [
     "KvqDims", "KvqStrides", "KvqAttnDims", "KvqError", "load", "check", "current_stream", "require_gpu",
-    "strides4", "dims5", "ptr_array", "dtype_code", "set_tunable", "get_tunable", "byref",
+    "strides4", "dims5", "ptr_array", "dtype_code", "set_tunable", "get_tunable", "byref", "timed_launch", "kernel_log",
+    "kernel_log_clear", "is_ab_build", "AB_LIB_PATH",
     "c_void_p", "LIB_PATH", "EXPORTS", "KVQ_F16", "KVQ_BF16", "KVQ_F32",
 ]

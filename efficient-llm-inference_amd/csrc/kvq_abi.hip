@@ -1,6 +1,8 @@
 // kvq_abi.hip — version, error reporting and tunables of libkvq_hip.so (include/kvq_hip.h).
+#include <cxxabi.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "kvq_common.h"
@@ -33,6 +35,16 @@ TimingEvents take_timing_events() {
   return e;
 }
 
+// kernels launched by the calling thread since kvq_kernel_log_clear(): distinct host stubs, in first-launch order
+constexpr int kLogCap = 32;
+static thread_local const void* g_log[kLogCap];
+static thread_local int g_log_n = 0;
+void note_launch(const void* host_stub) {
+  for (int i = 0; i < g_log_n; ++i)
+    if (g_log[i] == host_stub) return;
+  if (g_log_n < kLogCap) g_log[g_log_n++] = host_stub;
+}
+
 Tunables& tunables() {
   static Tunables t = [] {
     Tunables d = {};  // every knob 0 unless named here
@@ -45,7 +57,8 @@ Tunables& tunables() {
     d.attn_mfma_tc = 128;
     d.nt_loads = 1;
     d.quant_nt_stores = -1;
-    d.quant_geo128 = 1;
+    d.quant_tile = 1;
+    d.attn_lds = -1;
     d.attn_k_i8 = -1;
     d.attn_merge_fast = 1;
     d.attn_stream_roll = 1;
@@ -54,45 +67,52 @@ Tunables& tunables() {
   return t;
 }
 
-// name -> field, one table for kvq_set_tunable and kvq_get_tunable
+// name -> field, one table for kvq_set_tunable and kvq_get_tunable. `ab`: the key selects code that exists in
+// A-B builds only (`make ab`); the default library refuses to set it.
 struct TunableKey {
   const char* name;
   int64_t Tunables::*field;
+  bool ab;
 };
 static const TunableKey kTunableKeys[] = {
-    {"dequant_variant", &Tunables::dequant_variant},
-    {"dequant_grid", &Tunables::dequant_grid},
-    {"dequant_xcd_group", &Tunables::dequant_xcd_group},
-    {"quant_xcd_group", &Tunables::quant_xcd_group},
-    {"quant_force_two_pass", &Tunables::quant_force_two_pass},
-    {"quant_direct_stores", &Tunables::quant_direct_stores},
-    {"pool_grid", &Tunables::pool_grid},
-    {"nt_loads", &Tunables::nt_loads},
-    {"quant_block", &Tunables::quant_block},
-    {"pool_block", &Tunables::pool_block},
-    {"pool_wave", &Tunables::pool_wave},
-    {"quant_no_regmax", &Tunables::quant_no_regmax},
-    {"quant_nv", &Tunables::quant_nv},
-    {"quant_lds_pad", &Tunables::quant_lds_pad},
-    {"quant_tpw", &Tunables::quant_tpw},
-    {"quant_nt_stores", &Tunables::quant_nt_stores},
-    {"quant_geo128", &Tunables::quant_geo128},
-    {"attn_force_valu", &Tunables::attn_force_valu},
-    {"attn_mfma_min_nq", &Tunables::attn_mfma_min_nq},
-    {"attn_mfma_tc", &Tunables::attn_mfma_tc},
-    {"attn_fused", &Tunables::attn_fused},
-    {"attn_k_i8", &Tunables::attn_k_i8},
-    {"attn_merge_fast", &Tunables::attn_merge_fast},
-    {"attn_stream_roll", &Tunables::attn_stream_roll},
-    {"attn_stream_tpw", &Tunables::attn_stream_tpw},
-    {"attn_stream_slots", &Tunables::attn_stream_slots},
-    {"attn_stream_tc", &Tunables::attn_stream_tc},
-    {"attn_fused_tc", &Tunables::attn_fused_tc},
-    {"attn_fused_nw", &Tunables::attn_fused_nw},
+    // test knobs of the default library: they route a call to SHIPPED code it would not take by size / shape
+    {"quant_force_two_pass", &Tunables::quant_force_two_pass, false},
+    {"quant_direct_stores", &Tunables::quant_direct_stores, false},
+    {"quant_tile", &Tunables::quant_tile, false},
+    {"quant_block", &Tunables::quant_block, false},
+    {"pool_wave", &Tunables::pool_wave, false},
+    {"attn_force_valu", &Tunables::attn_force_valu, false},
+    {"attn_stream_tpw", &Tunables::attn_stream_tpw, false},
+    {"attn_lds", &Tunables::attn_lds, false},
+    // A-B keys
+    {"dequant_variant", &Tunables::dequant_variant, true},
+    {"dequant_grid", &Tunables::dequant_grid, true},
+    {"dequant_xcd_group", &Tunables::dequant_xcd_group, true},
+    {"quant_xcd_group", &Tunables::quant_xcd_group, true},
+    {"pool_grid", &Tunables::pool_grid, true},
+    {"nt_loads", &Tunables::nt_loads, true},
+    {"pool_block", &Tunables::pool_block, true},
+    {"quant_no_regmax", &Tunables::quant_no_regmax, true},
+    {"quant_nv", &Tunables::quant_nv, true},
+    {"quant_lds_pad", &Tunables::quant_lds_pad, true},
+    {"quant_tpw", &Tunables::quant_tpw, true},
+    {"quant_nt_stores", &Tunables::quant_nt_stores, true},
+    {"quant_geo128", &Tunables::quant_geo128, true},
+    {"quant_tile_tt", &Tunables::quant_tile_tt, true},
+    {"attn_mfma_min_nq", &Tunables::attn_mfma_min_nq, true},
+    {"attn_mfma_tc", &Tunables::attn_mfma_tc, true},
+    {"attn_fused", &Tunables::attn_fused, true},
+    {"attn_k_i8", &Tunables::attn_k_i8, true},
+    {"attn_merge_fast", &Tunables::attn_merge_fast, true},
+    {"attn_stream_roll", &Tunables::attn_stream_roll, true},
+    {"attn_stream_slots", &Tunables::attn_stream_slots, true},
+    {"attn_stream_tc", &Tunables::attn_stream_tc, true},
+    {"attn_fused_tc", &Tunables::attn_fused_tc, true},
+    {"attn_fused_nw", &Tunables::attn_fused_nw, true},
 };
-static int64_t* tunable_slot(const char* key) {
+static const TunableKey* tunable_key(const char* key) {
   for (const TunableKey& k : kTunableKeys)
-    if (!strcmp(key, k.name)) return &(tunables().*(k.field));
+    if (!strcmp(key, k.name)) return &k;
   return nullptr;
 }
 
@@ -111,19 +131,44 @@ int kvq_time_next_launch(void* start_event, void* stop_event) {
 
 int kvq_set_tunable(const char* key, int64_t value) {
   if (!key) return KVQ_E_NULL;
-  int64_t* slot = kvq::tunable_slot(key);
-  if (!slot) {
+  const kvq::TunableKey* k = kvq::tunable_key(key);
+  if (!k) {
     kvq::set_error("kvq_set_tunable: unknown key '%s'", key);
     return KVQ_E_DIMS;
   }
-  *slot = value;
+  if (k->ab && !KVQ_AB) {
+    kvq::set_error("kvq_set_tunable: '%s' is an A-B key; this is the default library (build `make ab`)", key);
+    return KVQ_E_DIMS;
+  }
+  kvq::tunables().*(k->field) = value;
   return 0;
 }
 
 int64_t kvq_get_tunable(const char* key) {
   if (!key) return 0;
-  const int64_t* slot = kvq::tunable_slot(key);
-  return slot ? *slot : 0;
+  const kvq::TunableKey* k = kvq::tunable_key(key);
+  return k ? kvq::tunables().*(k->field) : 0;
+}
+
+int kvq_is_ab_build(void) { return KVQ_AB; }
+
+void kvq_kernel_log_clear(void) { kvq::g_log_n = 0; }
+
+int64_t kvq_kernel_log(char* buf, int64_t n) {
+  if (!buf || n <= 0) return kvq::g_log_n;
+  int64_t off = 0;
+  buf[0] = 0;
+  for (int i = 0; i < kvq::g_log_n; ++i) {
+    const char* mangled = hipKernelNameRefByPtr(kvq::g_log[i], nullptr);
+    int status = -1;
+    char* dem = mangled ? abi::__cxa_demangle(mangled, nullptr, nullptr, &status) : nullptr;
+    const char* name = (status == 0 && dem) ? dem : (mangled ? mangled : "?");
+    const int w = snprintf(buf + off, (size_t)(n - off), "%s%s", i ? "\n" : "", name);
+    free(dem);
+    if (w < 0 || off + w >= n) break;
+    off += w;
+  }
+  return kvq::g_log_n;
 }
 
 int64_t kvq_chunk_summary_len(int64_t T, int64_t chunk_size, int64_t keep_last) {

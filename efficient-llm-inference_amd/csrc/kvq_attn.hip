@@ -1271,6 +1271,7 @@ __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_stream_mf
   }
 }
 
+#if KVQ_AB
 // ---------------------------------------------------------------------------- fused single launch
 // One launch per layer call: NW waves per workgroup, one TC-token tile per wave, then
 //   1. the NW waves' (m, l, acc) are merged through LDS -> ONE partial per workgroup and head
@@ -1545,6 +1546,8 @@ __global__ __launch_bounds__(NW* kWave) void decode_attn_fused_mfma_k(const Attn
     }
   }
 }
+
+#endif  // KVQ_AB (fused single launch)
 
 constexpr int kAttnMfmaTC = 128;
 
@@ -1860,7 +1863,7 @@ static bool use_mfma(const kvq_attn_dims_t* d) {
 }
 // streaming kernel: tiles per wave (0 = one-tile kernel). Chosen so that every wave of the launch is resident
 // at once (one round) when the batch offers more 64-token tiles than the chip has wave slots.
-static int stream_tc() { return tunables().attn_stream_tc == 32 ? 32 : 64; }
+static int stream_tc() { return KVQ_AB && tunables().attn_stream_tc == 32 ? 32 : 64; }
 static uint32_t stream_tpw(const kvq_attn_dims_t* d) {
   if (!use_mfma(d) || d->D != 128 || d->T <= 0) return 0;
   const int64_t forced = tunables().attn_stream_tpw;  // -1 = never, 0 = by size, > 0 = that many
@@ -1875,19 +1878,25 @@ static uint32_t stream_tpw(const kvq_attn_dims_t* d) {
   return (uint32_t)tpw;
 }
 static bool plan_onetile(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit);
-static bool plan(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit) {
+// tpw_out (optional): tiles per wave of the streaming layout when THAT is what the plan chose, 0 when it fell back to
+// one-tile splits (the launcher must size its kernel choice from this, never from stream_tpw() on its own)
+static bool plan(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit, uint32_t* tpw_out = nullptr) {
+  if (tpw_out) *tpw_out = 0;
   if (const uint32_t tpw = stream_tpw(d)) {  // one wave per tpw tiles of 64 (32) tokens
     const int64_t per = (int64_t)tpw * stream_tc();
     *ts = (uint32_t)per;
     *nsplit = (uint32_t)((d->T + per - 1) / per);
-    if (*nsplit <= (uint32_t)kAttnMaxSplit) return true;
+    if (*nsplit <= (uint32_t)kAttnMaxSplit) {
+      if (tpw_out) *tpw_out = tpw;
+      return true;
+    }
   }
   return plan_onetile(d, ts, nsplit);
 }
 // one tile (MFMA kernel) / one workgroup pass (VALU kernel) per split: also the only shapes a device-side T takes
 static bool plan_onetile(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit) {
   if (use_mfma(d)) {  // one wave per split of TC tokens
-    int64_t tc = tunables().attn_mfma_tc == 64 && d->D == 128 ? 64 : kAttnMfmaTC;
+    int64_t tc = KVQ_AB && tunables().attn_mfma_tc == 64 && d->D == 128 ? 64 : kAttnMfmaTC;
     if ((d->T + tc - 1) / tc > kAttnMaxSplit) tc = kAttnMfmaTC;
     *ts = (uint32_t)tc;
     *nsplit = (uint32_t)((d->T + tc - 1) / tc);
@@ -1905,6 +1914,7 @@ static bool plan_onetile(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nspli
   return *nsplit <= (uint32_t)kAttnMaxSplit;
 }
 
+#if KVQ_AB
 // ---- fused single launch: which (tokens per wave, waves per workgroup) and how many workgroup splits
 struct FusedPlan {
   uint32_t tc, nw, nwg, lds_bytes;
@@ -1964,7 +1974,7 @@ static void launch_fused(const AttnArgs& a, const FusedPlan& p, const NewTokenAr
   const NewTokenArgs& nta = nt ? *nt : none;
   const dim3 grid(p.nwg + (nt ? 2u : 0u), a.Hkv, a.B);
 #define KVQ_FUSED(TC_, HD_, NW_) \
-  hipLaunchKernelGGL((decode_attn_fused_mfma_k<KBITS, VBITS, TC_, HD_, NW_>), grid, dim3(NW_ * kWave), p.lds_bytes, st, a, f, nta)
+  KVQ_LAUNCH((decode_attn_fused_mfma_k<KBITS, VBITS, TC_, HD_, NW_>), grid, dim3(NW_ * kWave), p.lds_bytes, st, a, f, nta)
   if (a.D == 64u) KVQ_FUSED(128, 64, 4);
   else if (p.tc == 128u && p.nw == 4u) KVQ_FUSED(128, 128, 4);
   else if (p.tc == 128u) KVQ_FUSED(128, 128, 8);
@@ -1973,42 +1983,49 @@ static void launch_fused(const AttnArgs& a, const FusedPlan& p, const NewTokenAr
 #undef KVQ_FUSED
 }
 
+#endif  // KVQ_AB (fused single launch)
+
 template <int KBITS, int VBITS>
 static void launch_partial(const AttnArgs& a, hipStream_t st) {
   const dim3 grid(a.nsplit, a.Hkv, a.B);
-  if constexpr (KBITS == 8) {  // INT8 keys: the stored bytes straight into the int8 MFMA (head_dim 128 shapes)
-    // attn_k_i8: -1 (default) = where the query's int8 planes are amortised over several tiles per wave (streaming
-    // kernel: 50.6 vs 52.3 us per call at batch 8), 1 = always, 0 = never (one tile per wave: 52.6 vs 50.5 us)
-    const int64_t ki8 = tunables().attn_k_i8;
-    if (a.mfma && a.D == 128u && (ki8 > 0 || (ki8 < 0 && a.stream_tpw))) {
-      if (a.stream_tpw && stream_tc() == 64 && tunables().attn_stream_roll)
-        hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128, true, true>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
-      else if (a.stream_tpw && stream_tc() == 64)
-        hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128, true>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
-      else if (a.stream_tpw)
-        hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 32, 128, true>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
-      else if (a.TS == 64u) hipLaunchKernelGGL((decode_attn_partial_mfma_k<KBITS, VBITS, 64, 128, true>), grid, dim3(kWave), 0, st, a);
-      else hipLaunchKernelGGL((decode_attn_partial_mfma_k<KBITS, VBITS, kAttnMfmaTC, 128, true>), grid, dim3(kWave), 0, st, a);
-      return;
-    }
-  }
+  // INT8 keys at head_dim 128 in the streaming kernel: the stored bytes straight into the int8 MFMA, the query as two
+  // int8 planes whose cost is amortised over the wave's tiles (50.6 vs 52.3 us per call at batch 8). A-B builds can
+  // force that operand form on (attn_k_i8 = 1) or off (0) everywhere.
+  constexpr bool kI8 = KBITS == 8;
   if (a.mfma && a.stream_tpw) {
-    if (stream_tc() == 64 && tunables().attn_stream_roll)
-      hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128, false, true>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
-    else if (stream_tc() == 64) hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
-    else hipLaunchKernelGGL((decode_attn_stream_mfma_k<KBITS, VBITS, 32, 128>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
+#if KVQ_AB
+    const int64_t ki8 = tunables().attn_k_i8;
+    const bool i8 = kI8 && ki8 != 0;
+    if constexpr (kI8) {
+      if (i8 && stream_tc() == 64 && !tunables().attn_stream_roll) { KVQ_LAUNCH((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128, kI8, false>), grid, dim3(kWave), 0, st, a, a.stream_tpw); return; }
+      if (i8 && stream_tc() == 32) { KVQ_LAUNCH((decode_attn_stream_mfma_k<KBITS, VBITS, 32, 128, kI8, false>), grid, dim3(kWave), 0, st, a, a.stream_tpw); return; }
+    }
+    if (!i8 && stream_tc() == 64 && tunables().attn_stream_roll) { KVQ_LAUNCH((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128, false, true>), grid, dim3(kWave), 0, st, a, a.stream_tpw); return; }
+    if (!i8 && stream_tc() == 64) { KVQ_LAUNCH((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128>), grid, dim3(kWave), 0, st, a, a.stream_tpw); return; }
+    if (!i8) { KVQ_LAUNCH((decode_attn_stream_mfma_k<KBITS, VBITS, 32, 128>), grid, dim3(kWave), 0, st, a, a.stream_tpw); return; }
+#endif
+    KVQ_LAUNCH((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128, kI8, true>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
     return;
   }
   if (a.mfma) {
-    if (a.D == 64u) hipLaunchKernelGGL((decode_attn_partial_mfma_k<KBITS, VBITS, kAttnMfmaTC, 64>), grid, dim3(kWave), 0, st, a);
-    else if (a.TS == 64u) hipLaunchKernelGGL((decode_attn_partial_mfma_k<KBITS, VBITS, 64, 128>), grid, dim3(kWave), 0, st, a);
-    else hipLaunchKernelGGL((decode_attn_partial_mfma_k<KBITS, VBITS, kAttnMfmaTC, 128>), grid, dim3(kWave), 0, st, a);
+#if KVQ_AB
+    if constexpr (kI8) {
+      if (a.D == 128u && tunables().attn_k_i8 > 0) {
+        if (a.TS == 64u) KVQ_LAUNCH((decode_attn_partial_mfma_k<KBITS, VBITS, 64, 128, kI8>), grid, dim3(kWave), 0, st, a);
+        else KVQ_LAUNCH((decode_attn_partial_mfma_k<KBITS, VBITS, kAttnMfmaTC, 128, kI8>), grid, dim3(kWave), 0, st, a);
+        return;
+      }
+    }
+    if (a.D == 128u && a.TS == 64u) { KVQ_LAUNCH((decode_attn_partial_mfma_k<KBITS, VBITS, 64, 128>), grid, dim3(kWave), 0, st, a); return; }
+#endif
+    if (a.D == 64u) KVQ_LAUNCH((decode_attn_partial_mfma_k<KBITS, VBITS, kAttnMfmaTC, 64>), grid, dim3(kWave), 0, st, a);
+    else KVQ_LAUNCH((decode_attn_partial_mfma_k<KBITS, VBITS, kAttnMfmaTC, 128>), grid, dim3(kWave), 0, st, a);
     return;
   }
-  if (a.nq == 1) hipLaunchKernelGGL((decode_attn_partial_k<KBITS, VBITS, 1>), grid, dim3(kAttnBlock), 0, st, a);
-  else if (a.nq == 2) hipLaunchKernelGGL((decode_attn_partial_k<KBITS, VBITS, 2>), grid, dim3(kAttnBlock), 0, st, a);
-  else if (a.nq <= 4) hipLaunchKernelGGL((decode_attn_partial_k<KBITS, VBITS, 4>), grid, dim3(kAttnBlock), 0, st, a);
-  else hipLaunchKernelGGL((decode_attn_partial_k<KBITS, VBITS, 8>), grid, dim3(kAttnBlock), 0, st, a);
+  if (a.nq == 1) KVQ_LAUNCH((decode_attn_partial_k<KBITS, VBITS, 1>), grid, dim3(kAttnBlock), 0, st, a);
+  else if (a.nq == 2) KVQ_LAUNCH((decode_attn_partial_k<KBITS, VBITS, 2>), grid, dim3(kAttnBlock), 0, st, a);
+  else if (a.nq <= 4) KVQ_LAUNCH((decode_attn_partial_k<KBITS, VBITS, 4>), grid, dim3(kAttnBlock), 0, st, a);
+  else KVQ_LAUNCH((decode_attn_partial_k<KBITS, VBITS, 8>), grid, dim3(kAttnBlock), 0, st, a);
 }
 
 }  // namespace kvq
@@ -2020,13 +2037,19 @@ extern "C" {
 int64_t kvq_decode_attn_workspace(const kvq_attn_dims_t* d) {
   if (!d || d->B <= 0 || d->Hq <= 0 || d->Hkv <= 0 || d->T < 0 || d->D <= 0) return -1;
   if (d->D != 32 && d->D != 64 && d->D != 128 && d->D != 256) return -1;
-  uint32_t ts, ns;
+  uint32_t ts, ns, ns1;
   if (!plan(d, &ts, &ns)) return -1;
+  // kvq_decode_step_dev always takes one-tile splits, which can be more than the streaming layout's: cover both
+  if (plan_onetile(d, &ts, &ns1) && ns1 > ns) ns = ns1;
   const int64_t rows = d->B * d->Hq * (int64_t)(ns > 0 ? ns : 1);
   const int64_t legacy = (rows * 2 + 3) / 4 * 4 + rows * d->D;
   // the fused single-launch path (whatever shape the tunables pick: at most one split per 512 tokens)
+#if KVQ_AB
   const int64_t fused = use_mfma(d) ? fused_ws_floats(d, (d->T + 511) / 512 > 0 ? (d->T + 511) / 512 : 1) : 0;
   return legacy > fused ? legacy : fused;
+#else
+  return legacy;
+#endif
 }
 
 }  // extern "C"
@@ -2112,9 +2135,9 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
   a.lpt_shift = ilog2_exact(d->D / 16);
   a.dtype = dtype;
   a.mfma = use_mfma(d) ? 1 : 0;
-  a.stream_tpw = t_dev ? 0u : stream_tpw(d);
+  a.stream_tpw = 0u;
   a.t_dev = t_dev;
-  if (!(t_dev ? plan_onetile(d, &a.TS, &a.nsplit) : plan(d, &a.TS, &a.nsplit))) {
+  if (!(t_dev ? plan_onetile(d, &a.TS, &a.nsplit) : plan(d, &a.TS, &a.nsplit, &a.stream_tpw))) {
     set_error("%s: T=%lld needs more than %d splits of %d tokens", name, (long long)d->T, kAttnMaxSplit, kAttnMaxTS);
     return KVQ_E_DIMS;
   }
@@ -2130,14 +2153,20 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
     return KVQ_E_DIMS;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#if KVQ_AB
   FusedPlan fp;
-  if (!t_dev && plan_fused(d, &fp)) {  // ONE launch: tiles, in-workgroup merge, ticketed final merge, new-token quantise
+  // a captured HIP graph would replay the launch's host-side epoch: the arrival word then already holds
+  // epoch | nwg, nobody draws the last ticket and `out` stays stale — the fused plan is refused while capturing
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+  if (!t_dev && cap == hipStreamCaptureStatusNone && plan_fused(d, &fp)) {  // ONE launch: tiles, in-workgroup merge, ticketed final merge, new-token quantise
     if (k_bits == 8 && v_bits == 8) launch_fused<8, 8>(a, fp, nt, st);
     else if (k_bits == 8) launch_fused<8, 4>(a, fp, nt, st);
     else if (v_bits == 8) launch_fused<4, 8>(a, fp, nt, st);
     else launch_fused<4, 4>(a, fp, nt, st);
     return check_launch(name);
   }
+#endif
   if (a.nsplit > 0) {
     if (k_bits == 8 && v_bits == 8) launch_partial<8, 8>(a, st);
     else if (k_bits == 8) launch_partial<8, 4>(a, st);
@@ -2147,7 +2176,7 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
     if (rc) return rc;
   }
   NewTokenArgs none = {};
-  if (a.nsplit >= 1u && a.nsplit <= (uint32_t)kAttnBlock && a.D <= (uint32_t)kAttnBlock && tunables().attn_merge_fast)
+  if (a.nsplit >= 1u && a.nsplit <= (uint32_t)kAttnBlock && a.D <= (uint32_t)kAttnBlock && (!KVQ_AB || tunables().attn_merge_fast))
   {
     AttnArgs af = a;
     if (!a.kn) {  // no new token: valid addresses for the kernel's unconditional loads (values unused)
@@ -2155,10 +2184,10 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
       af.kn_sb = af.vn_sb = a.q_sb;
       af.kn_sh = af.vn_sh = 0;
     }
-    hipLaunchKernelGGL(decode_attn_merge_fast_k, dim3(a.Hq + (nt ? 2u : 0u), a.B), dim3(kAttnBlock), 0, st, af, nt ? *nt : none,
+    KVQ_LAUNCH(decode_attn_merge_fast_k, dim3(a.Hq + (nt ? 2u : 0u), a.B), dim3(kAttnBlock), 0, st, af, nt ? *nt : none,
                        nt ? 1 : 0, a.kn ? 1 : 0);
   } else
-    hipLaunchKernelGGL(decode_attn_merge_k, dim3(a.Hq + (nt ? 2u : 0u), a.B), dim3(kAttnBlock), 0, st, a, nt ? *nt : none,
+    KVQ_LAUNCH(decode_attn_merge_k, dim3(a.Hq + (nt ? 2u : 0u), a.B), dim3(kAttnBlock), 0, st, a, nt ? *nt : none,
                        nt ? 1 : 0);
   return check_launch(name);
 }
@@ -2184,8 +2213,12 @@ int64_t kvq_decode_attn_workspace_cap(const kvq_attn_dims_t* d) {
   }
   const int64_t rows = d->B * d->Hq * (int64_t)(ns_max + 1);
   const int64_t legacy = (rows * 2 + 3) / 4 * 4 + rows * d->D;
+#if KVQ_AB
   const int64_t fused = use_mfma(d) ? fused_ws_floats(d, (d->T + 511) / 512 + 1) : 0;  // monotone in T
   return legacy > fused ? legacy : fused;
+#else
+  return legacy;
+#endif
 }
 
 int kvq_decode_attn(const void* q, int64_t q_sb, int64_t q_sh, const uint8_t* k_store, const kvq_strides_t* k_st,

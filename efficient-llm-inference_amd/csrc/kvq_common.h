@@ -34,49 +34,72 @@ struct PtrTable {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
-// kvq_time_next_launch: HIP events the NEXT token-table dequantise launch of the calling thread binds to its own
-// dispatch (hipExtLaunchKernelGGL start / stop timestamps): the kernel's duration without queue gaps. Taken (and
-// cleared) by the launch; {nullptr, nullptr} = plain launch.
+// kvq_time_next_launch: HIP events the NEXT kernel launch of the calling thread binds to its own dispatch
+// (hipExtLaunchKernelGGL start / stop timestamps): the kernel's duration without queue gaps. Taken (and cleared) by
+// the first launch that follows, whichever entry point makes it; {nullptr, nullptr} = plain launch.
 struct TimingEvents {
   hipEvent_t start, stop;
 };
 TimingEvents take_timing_events();
-template <typename Kern, typename... Args>
-inline void launch_with_events(Kern kernel, dim3 grid, dim3 block, hipStream_t st, const TimingEvents& ev, Args... args) {
-  if (ev.start || ev.stop) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, ev.start, ev.stop, 0, args...);
-  else hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
-}
 
+// kvq_kernel_log: every launch notes its kernel's host stub; the log resolves the stubs to the names a profiler
+// prints (hipKernelNameRefByPtr + demangling), so a benchmark labels its roofline with the kernel that actually ran.
+void note_launch(const void* host_stub);
+
+// The one way this library launches a kernel.
+#define KVQ_LAUNCH(KERNEL, GRID, BLOCK, LDS, ST, ...)                                                                \
+  do {                                                                                                               \
+    ::kvq::note_launch(reinterpret_cast<const void*>(&KERNEL));                                                      \
+    const ::kvq::TimingEvents kvq_ev_ = ::kvq::take_timing_events();                                                 \
+    if (kvq_ev_.start || kvq_ev_.stop)                                                                               \
+      hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, ST, kvq_ev_.start, kvq_ev_.stop, 0, __VA_ARGS__);              \
+    else                                                                                                             \
+      hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, ST, __VA_ARGS__);                                                 \
+  } while (0)
+
+// A-B builds (`make ab`, -DKVQ_AB=1) keep every experiment that lost a measurement next to what ships; the default
+// library holds the shipped instantiations and the generic fallbacks only, and kvq_set_tunable refuses A-B keys.
+#ifndef KVQ_AB
+#define KVQ_AB 0
+#endif
+
+// Process-global knobs (kvq_set_tunable). "test knob": routes a call to SHIPPED code it would not take by size or
+// shape, settable in every build. Everything else is an A-B key: it selects code that only `make ab` builds contain.
 struct Tunables {
+  // ---- test knobs
+  int64_t quant_force_two_pass;  // 1 = generic two-pass quantise for every shape
+  int64_t quant_direct_stores;   // 1 = skip the LDS-staged 16 B stores of the 256-thread fused kernel
+  int64_t quant_block;           // general fused quantise kernel: 64 (default, one wave per tile) or 256 threads; 128 in A-B builds (measured: 241 / 261 / 270 us)
+  int64_t quant_tile;            // 1 (default) = compile-time-geometry one-wave tile kernel where the shape has one; 0 = general kernels
+  int64_t pool_wave;             // chunk mean-pool: one wave per output row when the shape allows (1, default) or the per-lane-group walk (0)
+  int64_t attn_force_valu;       // 1 = decode attention never takes an MFMA kernel
+  int64_t attn_stream_tpw;       // streaming MFMA kernel: 64-token tiles per wave; 0 = by size (only when tiles exceed wave slots), -1 = never
+  int64_t attn_lds;              // LDS-staged MFMA kernel (contiguous row loads): -1 = by shape (default), 0 = never, 1 = wherever it applies
+  // ---- A-B keys
   int64_t dequant_variant;       // -1 = shipped default
   int64_t dequant_grid;          // 0 = one chunk per workgroup
   int64_t dequant_xcd_group;     // consecutive chunks per XCD (xcd_grouped_item): 0 / 1 = round robin
   int64_t quant_xcd_group;       // same for the one-wave quantise tiles
-  int64_t quant_force_two_pass;  // 1 = generic two-pass quantise for every shape (tests)
-  int64_t quant_direct_stores;   // 1 = skip the LDS-staged 16 B stores (tests / A-B)
-  int64_t pool_grid;             // benchmarks: cap the chunk mean-pool grid (256-thread equivalents); 0 = one item per thread
-  int64_t pool_wave;             // chunk mean-pool: one wave per output row when the shape allows (1, default) or the per-lane-group walk (0)
+  int64_t pool_grid;             // cap the chunk mean-pool grid (256-thread equivalents); 0 = one item per thread
   int64_t pool_block;            // chunk mean-pool workgroup size: 64 (default, +7 %), 128 or 256
-  int64_t quant_block;           // fused quantise kernel workgroup: 64 (default, one wave per tile), 128 or 256 (measured: 241 / 261 / 270 us)
-  int64_t quant_nv;              // 4 = 2048-element one-wave tiles (A-B), else 8
-  int64_t quant_no_regmax;       // 1 = keep the LDS abs-max in one-wave tiles (A-B)
-  int64_t quant_geo128;          // one-wave quantise tile at 8 rows x head_dim 128: geometry as compile-time constants (1, default) or as arguments (0)
-  int64_t quant_nt_stores;       // one-wave quantise kernel: non-temporal output stores (1), write-back stores (0), -1 (default) = as nt_loads
+  int64_t quant_nv;              // 4 = 2048-element one-wave tiles, 16 = 8192, else 8
+  int64_t quant_no_regmax;       // 1 = keep the LDS abs-max in one-wave tiles
+  int64_t quant_geo128;          // round 2's GEO128 instantiation of the general kernel instead of the tile kernel (needs quant_tile = 0)
+  int64_t quant_nt_stores;       // GEO128 kernel: non-temporal output stores (1), write-back stores (0), -1 (default) = as nt_loads
   int64_t quant_tpw;             // tiles per wave of the pipelined one-wave quantise kernel (2 | 4 | 8); 0 = one tile per wave
-  int64_t quant_lds_pad;         // A-B: bytes of unused dynamic LDS on the one-wave quantise launch (caps waves per CU)
-  int64_t attn_force_valu;       // 1 = decode attention never takes the MFMA kernel (tests / A-B)
+  int64_t quant_lds_pad;         // bytes of unused dynamic LDS on the one-wave quantise launch (caps waves per CU)
+  int64_t quant_tile_tt;         // tile kernel at head_dim 64: tokens per tile 8 (one row per load instruction) or 4 (two rows); 0 = shipped choice
   int64_t attn_mfma_min_nq;      // fewest query heads per kv head that take the MFMA kernel at head_dim 128 (default 3)
   int64_t attn_mfma_tc;          // tokens per one-wave split of the MFMA kernel: 128 (default) or 64
-  int64_t attn_stream_tpw;       // streaming MFMA kernel: 64-token tiles per wave; 0 = by size (only when tiles exceed wave slots), -1 = never
   int64_t attn_stream_tc;        // tokens per tile of the streaming kernel: 64 (default) or 32
-  int64_t attn_stream_slots;     // wave slots the streaming plan fills in one round (default 3072 = 3 per SIMD)
+  int64_t attn_stream_slots;     // wave slots the streaming plan fills in one round (default 2048 = 2 per SIMD)
   int64_t attn_stream_roll;      // streaming kernel, 64-token tiles: re-request a tile's registers piece by piece for the tile after next (1) or whole tiles between reductions (0)
   int64_t attn_merge_fast;       // 1 (default) = merge kernel that requests everything up front (<= 256 splits); 0 = the chained one
   int64_t attn_k_i8;             // INT8 keys at head_dim 128: stored bytes straight into v_mfma_i32_16x16x64_i8 (query as two int8 planes): -1 = streaming kernel only (default), 0 = never, 1 = always
   int64_t attn_fused;            // 1 = decode attention as ONE launch (decode_attn_fused_mfma_k) where it applies; default 0: partial + merge measured faster
   int64_t attn_fused_tc;         // fused launch, head_dim 128: tokens per wave 128 | 64 | 32 (with attn_fused_nw 4 or 8 | 8 | 16); 0 = by batch size
   int64_t attn_fused_nw;
-  int64_t nt_loads;              // non-temporal input loads in the quantise / pool kernels (default 1: +2-3 % on quantise)
+  int64_t nt_loads;              // non-temporal input loads in the general quantise / pool kernels (default 1)
 };
 Tunables& tunables();
 

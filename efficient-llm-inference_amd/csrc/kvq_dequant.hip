@@ -250,7 +250,12 @@ struct Variant {
   bool nt, lds;
   int blk = kBlock;
 };
-// Index = tunable "dequant_variant". kDefaultVariant ships.
+// Index = tunable "dequant_variant" (A-B builds). Shipped (profiles/r01_microbench.txt, r02ag_*): one-wave workgroups,
+// contiguous 1 KiB stores per wave instruction, non-temporal stores; INT4 4 vectors per lane (4 KiB of output per
+// wave), INT8 2 vectors per lane + non-temporal loads.
+constexpr int kDefaultVariantI4 = 21;
+constexpr int kDefaultVariantI8 = 23;
+#if KVQ_AB
 static const Variant kVariants[] = {
     {8, 4, false, true},   // 0
     {8, 4, true, true},    // 1
@@ -273,9 +278,9 @@ static const Variant kVariants[] = {
     {8, 1, true, false},   // 18: one vector per thread, scales straight from global (no LDS, no barrier)
     {8, 2, true, false},   // 19
     {8, 1, true, false},   // 20: 18 + non-temporal loads
-    {8, 4, true, true, 64},   // 21: as 1, one-wave workgroups
+    {8, 4, true, true, 64},   // 21: as 1, one-wave workgroups (INT4 default)
     {8, 8, true, true, 64},   // 22
-    {8, 2, true, true, 64},   // 23: as 17 (NT loads), one-wave workgroups
+    {8, 2, true, true, 64},   // 23: as 17 (NT loads), one-wave workgroups (INT8 default)
     {8, 4, true, true, 64},   // 24: as 21 + NT loads
     {8, 16, true, true, 64},  // 25
     {8, 2, true, true, 64},   // 26
@@ -290,55 +295,58 @@ static const Variant kVariants[] = {
     {8, 2, false, true, 64},  // 35: 33 without NT loads
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-// shipped defaults (profiles/r01_microbench.txt): contiguous 1 KiB stores per wave instruction;
-// non-temporal stores for the 80 %-write INT4 stream.
-constexpr int kDefaultVariantI4 = 21;
-constexpr int kDefaultVariantI8 = 23;
+static Variant variant_of(int v) { return kVariants[v]; }
+#else
+constexpr int kNumVariants = 0;  // "dequant_variant" is an A-B key: the default library holds the two shipped shapes
+static Variant variant_of(int v) { return v == kDefaultVariantI4 ? Variant{8, 4, true, true, 64} : Variant{8, 2, true, true, 64}; }
+#endif
 
 template <int ODT, int BITS, int LE, int UNROLL, bool NT, bool LDS_SC, bool NTL = false, int BLK = kBlock>
-static void launch_fast(const DequantArgs& a, unsigned grid, hipStream_t st, const TimingEvents& ev) {
-  launch_with_events((dequant_tokens_fast_k<ODT, BITS, LE, UNROLL, NT, LDS_SC, NTL, BLK>), dim3(grid), dim3(BLK), st, ev, a);
+static void launch_fast(const DequantArgs& a, unsigned grid, hipStream_t st) {
+  KVQ_LAUNCH((dequant_tokens_fast_k<ODT, BITS, LE, UNROLL, NT, LDS_SC, NTL, BLK>), dim3(grid), dim3(BLK), 0, st, a);
 }
 
 template <int ODT, int BITS>
-static bool launch_fast_variant(int v, const DequantArgs& a, unsigned grid, hipStream_t st, const TimingEvents& ev) {
+static bool launch_fast_variant(int v, const DequantArgs& a, unsigned grid, hipStream_t st) {
   switch (v) {
-    case 0: launch_fast<ODT, BITS, 8, 4, false, true>(a, grid, st, ev); return true;
-    case 1: launch_fast<ODT, BITS, 8, 4, true, true>(a, grid, st, ev); return true;
-    case 2: launch_fast<ODT, BITS, 16, 2, false, true>(a, grid, st, ev); return true;
-    case 3: launch_fast<ODT, BITS, 16, 2, true, true>(a, grid, st, ev); return true;
-    case 4: launch_fast<ODT, BITS, 32, 1, false, true>(a, grid, st, ev); return true;
-    case 5: launch_fast<ODT, BITS, 32, 1, true, true>(a, grid, st, ev); return true;
-    case 6: launch_fast<ODT, BITS, 8, 8, false, true>(a, grid, st, ev); return true;
-    case 7: launch_fast<ODT, BITS, 8, 4, false, false>(a, grid, st, ev); return true;
-    case 8: launch_fast<ODT, BITS, 8, 2, false, true>(a, grid, st, ev); return true;
-    case 9: launch_fast<ODT, BITS, 8, 8, true, true>(a, grid, st, ev); return true;
-    case 10: launch_fast<ODT, BITS, 16, 4, false, true>(a, grid, st, ev); return true;
-    case 11: launch_fast<ODT, BITS, 32, 2, false, true>(a, grid, st, ev); return true;
-    case 12: launch_fast<ODT, BITS, 8, 2, true, true>(a, grid, st, ev); return true;
-    case 13: launch_fast<ODT, BITS, 8, 1, true, true>(a, grid, st, ev); return true;
-    case 14: launch_fast<ODT, BITS, 8, 4, true, false>(a, grid, st, ev); return true;
-    case 15: launch_fast<ODT, BITS, 8, 1, false, true>(a, grid, st, ev); return true;
-    case 16: launch_fast<ODT, BITS, 8, 4, true, true, true>(a, grid, st, ev); return true;
-    case 17: launch_fast<ODT, BITS, 8, 2, true, true, true>(a, grid, st, ev); return true;
-    case 18: launch_fast<ODT, BITS, 8, 1, true, false>(a, grid, st, ev); return true;
-    case 19: launch_fast<ODT, BITS, 8, 2, true, false>(a, grid, st, ev); return true;
-    case 20: launch_fast<ODT, BITS, 8, 1, true, false, true>(a, grid, st, ev); return true;
-    case 21: launch_fast<ODT, BITS, 8, 4, true, true, false, 64>(a, grid, st, ev); return true;
-    case 22: launch_fast<ODT, BITS, 8, 8, true, true, false, 64>(a, grid, st, ev); return true;
-    case 23: launch_fast<ODT, BITS, 8, 2, true, true, true, 64>(a, grid, st, ev); return true;
-    case 24: launch_fast<ODT, BITS, 8, 4, true, true, true, 64>(a, grid, st, ev); return true;
-    case 25: launch_fast<ODT, BITS, 8, 16, true, true, false, 64>(a, grid, st, ev); return true;
-    case 26: launch_fast<ODT, BITS, 8, 2, true, true, false, 64>(a, grid, st, ev); return true;
-    case 27: launch_fast<ODT, BITS, 8, 1, true, true, false, 64>(a, grid, st, ev); return true;
-    case 28: launch_fast<ODT, BITS, 8, 1, true, true, true, 64>(a, grid, st, ev); return true;
-    case 29: launch_fast<ODT, BITS, 8, 4, true, true, false, 128>(a, grid, st, ev); return true;
-    case 30: launch_fast<ODT, BITS, 8, 2, true, true, true, 128>(a, grid, st, ev); return true;
-    case 31: launch_fast<ODT, BITS, 8, 4, false, true, false, 64>(a, grid, st, ev); return true;
-    case 32: launch_fast<ODT, BITS, 8, 4, false, true, true, 64>(a, grid, st, ev); return true;
-    case 33: launch_fast<ODT, BITS, 8, 2, false, true, true, 64>(a, grid, st, ev); return true;
-    case 34: launch_fast<ODT, BITS, 8, 8, false, true, true, 64>(a, grid, st, ev); return true;
-    case 35: launch_fast<ODT, BITS, 8, 2, false, true, false, 64>(a, grid, st, ev); return true;
+    case 21: launch_fast<ODT, BITS, 8, 4, true, true, false, 64>(a, grid, st); return true;
+    case 23: launch_fast<ODT, BITS, 8, 2, true, true, true, 64>(a, grid, st); return true;
+#if KVQ_AB
+    case 0: launch_fast<ODT, BITS, 8, 4, false, true>(a, grid, st); return true;
+    case 1: launch_fast<ODT, BITS, 8, 4, true, true>(a, grid, st); return true;
+    case 2: launch_fast<ODT, BITS, 16, 2, false, true>(a, grid, st); return true;
+    case 3: launch_fast<ODT, BITS, 16, 2, true, true>(a, grid, st); return true;
+    case 4: launch_fast<ODT, BITS, 32, 1, false, true>(a, grid, st); return true;
+    case 5: launch_fast<ODT, BITS, 32, 1, true, true>(a, grid, st); return true;
+    case 6: launch_fast<ODT, BITS, 8, 8, false, true>(a, grid, st); return true;
+    case 7: launch_fast<ODT, BITS, 8, 4, false, false>(a, grid, st); return true;
+    case 8: launch_fast<ODT, BITS, 8, 2, false, true>(a, grid, st); return true;
+    case 9: launch_fast<ODT, BITS, 8, 8, true, true>(a, grid, st); return true;
+    case 10: launch_fast<ODT, BITS, 16, 4, false, true>(a, grid, st); return true;
+    case 11: launch_fast<ODT, BITS, 32, 2, false, true>(a, grid, st); return true;
+    case 12: launch_fast<ODT, BITS, 8, 2, true, true>(a, grid, st); return true;
+    case 13: launch_fast<ODT, BITS, 8, 1, true, true>(a, grid, st); return true;
+    case 14: launch_fast<ODT, BITS, 8, 4, true, false>(a, grid, st); return true;
+    case 15: launch_fast<ODT, BITS, 8, 1, false, true>(a, grid, st); return true;
+    case 16: launch_fast<ODT, BITS, 8, 4, true, true, true>(a, grid, st); return true;
+    case 17: launch_fast<ODT, BITS, 8, 2, true, true, true>(a, grid, st); return true;
+    case 18: launch_fast<ODT, BITS, 8, 1, true, false>(a, grid, st); return true;
+    case 19: launch_fast<ODT, BITS, 8, 2, true, false>(a, grid, st); return true;
+    case 20: launch_fast<ODT, BITS, 8, 1, true, false, true>(a, grid, st); return true;
+    case 22: launch_fast<ODT, BITS, 8, 8, true, true, false, 64>(a, grid, st); return true;
+    case 24: launch_fast<ODT, BITS, 8, 4, true, true, true, 64>(a, grid, st); return true;
+    case 25: launch_fast<ODT, BITS, 8, 16, true, true, false, 64>(a, grid, st); return true;
+    case 26: launch_fast<ODT, BITS, 8, 2, true, true, false, 64>(a, grid, st); return true;
+    case 27: launch_fast<ODT, BITS, 8, 1, true, true, false, 64>(a, grid, st); return true;
+    case 28: launch_fast<ODT, BITS, 8, 1, true, true, true, 64>(a, grid, st); return true;
+    case 29: launch_fast<ODT, BITS, 8, 4, true, true, false, 128>(a, grid, st); return true;
+    case 30: launch_fast<ODT, BITS, 8, 2, true, true, true, 128>(a, grid, st); return true;
+    case 31: launch_fast<ODT, BITS, 8, 4, false, true, false, 64>(a, grid, st); return true;
+    case 32: launch_fast<ODT, BITS, 8, 4, false, true, true, 64>(a, grid, st); return true;
+    case 33: launch_fast<ODT, BITS, 8, 2, false, true, true, 64>(a, grid, st); return true;
+    case 34: launch_fast<ODT, BITS, 8, 8, false, true, true, 64>(a, grid, st); return true;
+    case 35: launch_fast<ODT, BITS, 8, 2, false, true, false, 64>(a, grid, st); return true;
+#endif
   }
   return false;
 }
@@ -347,9 +355,6 @@ template <int BITS>
 static int dequant_tokens(const uint8_t* q, const kvq_strides_t* q_st, const float* scales, int64_t ssg,
                           void* out, const kvq_strides_t* out_st, int out_dtype, const kvq_dims_t* d,
                           void* stream, const char* name) {
-  // kvq_time_next_launch is one-shot: whatever this call does (either kernel, an empty table, an error), the
-  // pending events are taken here and never reach a later launch
-  const TimingEvents ev = take_timing_events();
   if (!q || !q_st || !scales || !out || !out_st || !d) {
     set_error("%s: NULL argument", name);
     return KVQ_E_NULL;
@@ -380,7 +385,7 @@ static int dequant_tokens(const uint8_t* q, const kvq_strides_t* q_st, const flo
 
   int v = (int)tunables().dequant_variant;
   if (v < 0 || v >= kNumVariants) v = BITS == 4 ? kDefaultVariantI4 : kDefaultVariantI8;
-  const Variant var = kVariants[v];
+  const Variant var = variant_of(v);
   const int64_t chunk = (int64_t)var.blk * var.le * var.unroll;
 
   // fast path: rows contiguous in (t,d) on both sides, 16-byte vectors everywhere, 32-bit indices
@@ -408,9 +413,9 @@ static int dequant_tokens(const uint8_t* q, const kvq_strides_t* q_st, const flo
     const unsigned grid = grid_for(a.total_items, cap);
     bool ok = false;
     switch (out_dtype) {
-      case KVQ_F16: ok = launch_fast_variant<KVQ_F16, BITS>(v, a, grid, st, ev); break;
-      case KVQ_BF16: ok = launch_fast_variant<KVQ_BF16, BITS>(v, a, grid, st, ev); break;
-      case KVQ_F32: ok = launch_fast_variant<KVQ_F32, BITS>(v, a, grid, st, ev); break;
+      case KVQ_F16: ok = launch_fast_variant<KVQ_F16, BITS>(v, a, grid, st); break;
+      case KVQ_BF16: ok = launch_fast_variant<KVQ_BF16, BITS>(v, a, grid, st); break;
+      case KVQ_F32: ok = launch_fast_variant<KVQ_F32, BITS>(v, a, grid, st); break;
     }
     if (!ok) {
       set_error("%s: no such variant %d", name, v);
@@ -431,9 +436,9 @@ static int dequant_tokens(const uint8_t* q, const kvq_strides_t* q_st, const flo
   a.xcd_group = 0;
   const unsigned grid = grid_for((total + kBlock - 1) / kBlock, 256 * 32);
   switch (out_dtype) {
-    case KVQ_F16: launch_with_events((dequant_tokens_generic_k<KVQ_F16, BITS>), dim3(grid), dim3(kBlock), st, ev, a, total); break;
-    case KVQ_BF16: launch_with_events((dequant_tokens_generic_k<KVQ_BF16, BITS>), dim3(grid), dim3(kBlock), st, ev, a, total); break;
-    case KVQ_F32: launch_with_events((dequant_tokens_generic_k<KVQ_F32, BITS>), dim3(grid), dim3(kBlock), st, ev, a, total); break;
+    case KVQ_F16: KVQ_LAUNCH((dequant_tokens_generic_k<KVQ_F16, BITS>), dim3(grid), dim3(kBlock), 0, st, a, total); break;
+    case KVQ_BF16: KVQ_LAUNCH((dequant_tokens_generic_k<KVQ_BF16, BITS>), dim3(grid), dim3(kBlock), 0, st, a, total); break;
+    case KVQ_F32: KVQ_LAUNCH((dequant_tokens_generic_k<KVQ_F32, BITS>), dim3(grid), dim3(kBlock), 0, st, a, total); break;
   }
   return check_launch(name);
 }
@@ -472,13 +477,13 @@ int kvq_dequant_i8_f16_flat(const int8_t* q, float scale, void* out_f16, int64_t
   if (n % 8 == 0 && aligned(q, 8) && aligned(out_f16, 16)) {
     const int64_t ng = n / 8;
     if (ng >= kFlatChunkMin && (ng + 127) / 128 < (int64_t(1) << 31))
-      hipLaunchKernelGGL((dequant_flat_chunk_k<8>), dim3((unsigned)((ng + 127) / 128)), dim3(64), 0, st, reinterpret_cast<const uint8_t*>(q),
+      KVQ_LAUNCH((dequant_flat_chunk_k<8>), dim3((unsigned)((ng + 127) / 128)), dim3(64), 0, st, reinterpret_cast<const uint8_t*>(q),
                          scale, reinterpret_cast<uint16_t*>(out_f16), ng);
     else
-      hipLaunchKernelGGL((dequant_flat_vec_k<8>), dim3(grid_for((ng + kBlock - 1) / kBlock, 256 * 16)), dim3(kBlock), 0,
+      KVQ_LAUNCH((dequant_flat_vec_k<8>), dim3(grid_for((ng + kBlock - 1) / kBlock, 256 * 16)), dim3(kBlock), 0,
                          st, reinterpret_cast<const uint8_t*>(q), scale, reinterpret_cast<uint16_t*>(out_f16), ng);
   } else {
-    hipLaunchKernelGGL(dequant_i8_flat_scalar_k, dim3(grid_for((n + kBlock - 1) / kBlock, 256 * 16)), dim3(kBlock), 0,
+    KVQ_LAUNCH(dequant_i8_flat_scalar_k, dim3(grid_for((n + kBlock - 1) / kBlock, 256 * 16)), dim3(kBlock), 0,
                        st, q, scale, reinterpret_cast<uint16_t*>(out_f16), n);
   }
   return check_launch("kvq_dequant_i8_f16_flat");
@@ -501,14 +506,14 @@ int kvq_dequant_i4_f16_flat(const uint8_t* packed, float scale, void* out_f16, i
   if (orig_last_dim >= total_last && n_packed % 4 == 0 && aligned(packed, 4) && aligned(out_f16, 16)) {
     const int64_t ng = n_packed / 4;  // no pad column to zero: pure vector path
     if (ng >= kFlatChunkMin && (ng + 255) / 256 < (int64_t(1) << 31))
-      hipLaunchKernelGGL((dequant_flat_chunk_k<4>), dim3((unsigned)((ng + 255) / 256)), dim3(64), 0, st, packed, scale,
+      KVQ_LAUNCH((dequant_flat_chunk_k<4>), dim3((unsigned)((ng + 255) / 256)), dim3(64), 0, st, packed, scale,
                          reinterpret_cast<uint16_t*>(out_f16), ng);
     else
-      hipLaunchKernelGGL((dequant_flat_vec_k<4>), dim3(grid_for((ng + kBlock - 1) / kBlock, 256 * 16)), dim3(kBlock), 0,
+      KVQ_LAUNCH((dequant_flat_vec_k<4>), dim3(grid_for((ng + kBlock - 1) / kBlock, 256 * 16)), dim3(kBlock), 0,
                          st, packed, scale, reinterpret_cast<uint16_t*>(out_f16), ng);
   } else {
     const int64_t out_n = n_packed * 2;
-    hipLaunchKernelGGL(dequant_i4_flat_scalar_k, dim3(grid_for((out_n + kBlock - 1) / kBlock, 256 * 16)), dim3(kBlock),
+    KVQ_LAUNCH(dequant_i4_flat_scalar_k, dim3(grid_for((out_n + kBlock - 1) / kBlock, 256 * 16)), dim3(kBlock),
                        0, st, packed, scale, reinterpret_cast<uint16_t*>(out_f16), out_n, orig_last_dim, total_last);
   }
   return check_launch("kvq_dequant_i4_f16_flat");

@@ -377,9 +377,9 @@ int kvq_window_compact(const void* in_base, const void* const* in_ptrs, const kv
                a.isb.t % 16 == 0 && a.osb.g % 16 == 0 && a.osb.b % 16 == 0 && a.osb.h % 16 == 0 && a.osb.t % 16 == 0;
     for (int64_t i = 0; i < gn && vec; ++i) vec = aligned(a.in.p[i], 16);
     if (vec)
-      hipLaunchKernelGGL((copy_rows_k<true>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a);
+      KVQ_LAUNCH((copy_rows_k<true>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a);
     else
-      hipLaunchKernelGGL((copy_rows_k<false>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a);
+      KVQ_LAUNCH((copy_rows_k<false>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a);
     rc = check_launch(name);
     if (rc) return rc;
   }
@@ -427,9 +427,9 @@ int kvq_gather_tokens(const void* in_base, const void* const* in_ptrs, const kvq
     int64_t blocks = (items + kBlock - 1) / kBlock;
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (vec)
-      hipLaunchKernelGGL((gather_tokens_k<true>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a, (uint32_t)items);
+      KVQ_LAUNCH((gather_tokens_k<true>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a, (uint32_t)items);
     else
-      hipLaunchKernelGGL((gather_tokens_k<false>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a, (uint32_t)items);
+      KVQ_LAUNCH((gather_tokens_k<false>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a, (uint32_t)items);
     rc = check_launch(name);
     if (rc) return rc;
   }
@@ -492,7 +492,7 @@ int kvq_chunk_meanpool(const void* in_base, const void* const* in_ptrs, const kv
                       chunk_size * a.is.t * 2 < (int64_t(1) << 31);  // 32-bit offsets inside a chunk
     if (wave) {
       const dim3 grid((unsigned)(d->B * d->H * Tout), (unsigned)gn);
-#define KVQ_POOL_WAVE(DT_, G_, R_) hipLaunchKernelGGL((chunk_pool_wave_k<DT_, G_, R_>), grid, dim3(64), 0, st, a)
+#define KVQ_POOL_WAVE(DT_, G_, R_) KVQ_LAUNCH((chunk_pool_wave_k<DT_, G_, R_>), grid, dim3(64), 0, st, a)
 #define KVQ_POOL_WAVE_DT(G_, R_)                  \
   do {                                            \
     if (dtype == KVQ_F16) KVQ_POOL_WAVE(KVQ_F16, G_, R_); \
@@ -518,26 +518,27 @@ int kvq_chunk_meanpool(const void* in_base, const void* const* in_ptrs, const kv
       }
       const unsigned blocks = (unsigned)want;
       switch (dtype) {
-        case KVQ_F16:
-          if (a.nt_loads) hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_F16, true>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec);
-          else hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_F16, false>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec);
-          break;
-        case KVQ_BF16:
-          if (a.nt_loads) hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_BF16, true>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec);
-          else hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_BF16, false>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec);
-          break;
-        case KVQ_F32:
-          if (a.nt_loads) hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_F32, true>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec);
-          else hipLaunchKernelGGL((chunk_pool_vec_k<KVQ_F32, false>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec);
-          break;
+#if KVQ_AB
+#define KVQ_POOL_VEC(DT_)                                                                                                             \
+  do {                                                                                                                                \
+    if (a.nt_loads) KVQ_LAUNCH((chunk_pool_vec_k<DT_, true>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec); \
+    else KVQ_LAUNCH((chunk_pool_vec_k<DT_, false>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec);  \
+  } while (0)
+#else  // non-temporal loads ship (the plain-load instantiation is an A-B variant)
+#define KVQ_POOL_VEC(DT_) KVQ_LAUNCH((chunk_pool_vec_k<DT_, true>), dim3(blocks, (unsigned)gn), dim3((unsigned)blk), 0, st, a, (uint32_t)items_vec)
+#endif
+        case KVQ_F16: KVQ_POOL_VEC(KVQ_F16); break;
+        case KVQ_BF16: KVQ_POOL_VEC(KVQ_BF16); break;
+        case KVQ_F32: KVQ_POOL_VEC(KVQ_F32); break;
+#undef KVQ_POOL_VEC
       }
     } else {
       int64_t blocks = (items_gen + kBlock - 1) / kBlock;
       if (blocks > 256 * 32) blocks = 256 * 32;
       switch (dtype) {
-        case KVQ_F16: hipLaunchKernelGGL((chunk_pool_generic_k<KVQ_F16>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a, items_gen); break;
-        case KVQ_BF16: hipLaunchKernelGGL((chunk_pool_generic_k<KVQ_BF16>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a, items_gen); break;
-        case KVQ_F32: hipLaunchKernelGGL((chunk_pool_generic_k<KVQ_F32>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a, items_gen); break;
+        case KVQ_F16: KVQ_LAUNCH((chunk_pool_generic_k<KVQ_F16>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a, items_gen); break;
+        case KVQ_BF16: KVQ_LAUNCH((chunk_pool_generic_k<KVQ_BF16>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a, items_gen); break;
+        case KVQ_F32: KVQ_LAUNCH((chunk_pool_generic_k<KVQ_F32>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a, items_gen); break;
       }
     }
     rc = check_launch(name);

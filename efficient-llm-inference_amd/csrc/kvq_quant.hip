@@ -332,6 +332,122 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------- compile-time tile (what ships for the BASELINE shapes)
+// The shapes the benchmarks are quoted on — R = B*H head rows of head_dim D with f16 / bf16 input: 8 x 128 (Llama-3-8B),
+// 16 x 64 (gpt2-medium), 12 x 64 (gpt2), 8 x 64 — as ONE WAVE per tile of TT tokens with the whole geometry in the
+// template: lane = (row-in-instruction, token, 8-element d-vector); every load instruction of the wave reads RPI = 64 /
+// (TT * D/8) rows' contiguous TT*D-element runs (1 KiB, or 2 x 512 B); the abs-max across the rows is a register max
+// (+ one lane exchange when two rows share an instruction), across a token's D/8 lanes DPP; the scale is per lane.
+// Addressing is by BUFFER instructions: a per-wave descriptor of the group's rows (scalar), a lane offset that never
+// changes, the row as the instruction's scalar offset — no 64-bit vector address arithmetic, no pointer per row. A
+// ragged last tile costs nothing: lanes of tokens past T carry an out-of-range offset (loads return 0, which cannot
+// raise an abs-max; stores are dropped), so ONE instantiation serves complete and ragged tiles.
+// Same arithmetic, same order of operations per element as quant_tokens_fused_k (quotient_bits8 / pack_*): bit-identical.
+struct QuantTileArgs {
+  PtrTable in;      // per-group input base pointers
+  uint8_t* q;       // store base of this launch's first group
+  float* scales;
+  float* absmax;    // split phases: [G, T] fp32 table of this launch's first group
+  int64_t qs_g;     // bytes
+  int64_t ssg;
+  uint32_t is_h;    // input row stride in BYTES
+  uint32_t qs_h;    // store row stride in bytes
+  uint32_t T;
+  uint32_t rows;    // B*H rows of a group; blockIdx.z walks them R at a time (fused: rows == R, gridDim.z == 1)
+  float eps;
+};
+
+// PHASE 0: the fused quantise (abs-max, scale, quantise: one pass over the tile).
+// Split phases of a batch-sharded slice (the scale spans the WHOLE batch, ops.py:27,48, so the abs-max table
+// crosses ranks between the two): the same tile walk over R-row groups of a group's B_local*H rows (blockIdx.z),
+//   PHASE 1: abs-max of the R rows -> atomicMax into absmax[g, t] (the host zeroes the table first; non-negative floats
+//            order like their bit patterns); plain loads, so the rows stay in the Infinity Cache for phase 2
+//   PHASE 2: quantise the R rows with scale max(absmax[g, t] / QMAX, eps) (the table completed by all_reduce(MAX)),
+//            non-temporal loads (last use); row group 0 stores the scales.
+template <int IDT, int BITS, int R, int DV, int TT, int PHASE = 0>
+__global__ __launch_bounds__(kWave) void quant_tile_k(const QuantTileArgs a) {
+  static_assert(IDT != KVQ_F32, "two-byte inputs");
+  constexpr int LPR = TT * DV;              // lanes per row run
+  static_assert(LPR == 64 || LPR == 32, "a row run is one wave or half a wave wide");
+  constexpr int RPI = 64 / LPR;             // rows per load instruction
+  static_assert(R % RPI == 0, "rows pair up");
+  constexpr int NV = R / RPI;               // 16-byte vectors per lane
+  constexpr int D = DV * 8;
+  constexpr int QV = BITS;                  // bytes stored per 8-element vector
+  constexpr int ROWB = LPR * QV;            // bytes of one row's run in the store
+  constexpr int OUTB = R * ROWB;            // bytes of the tile in the store
+  constexpr int NST = (OUTB + 1023) / 1024; // 16 B per lane store instructions
+  constexpr uint32_t kOut = 0x80000000u;    // offset no descriptor of ours covers
+  __shared__ __attribute__((aligned(16))) uint32_t s_out[PHASE == 1 ? 4 : NST * 256];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t g = blockIdx.y;
+  const uint32_t t0 = blockIdx.x * TT;
+  const uint32_t nt = a.T - t0 < (uint32_t)TT ? a.T - t0 : (uint32_t)TT;  // uniform
+  const uint32_t r0 = PHASE == 0 ? 0u : blockIdx.z * (uint32_t)R;
+  const uint32_t nr = PHASE == 0 ? (uint32_t)R : (a.rows - r0 < (uint32_t)R ? a.rows - r0 : (uint32_t)R);  // rows of this group (uniform)
+  const uint32_t sub = RPI == 1 ? 0u : lane / LPR, wv = lane % LPR, tok = wv / DV;
+
+  // rows past nr and tokens past nt are outside the descriptor: loads return 0 (no effect on an abs-max), stores are dropped
+  const char* ibase = reinterpret_cast<const char*>(a.in.p[g]) + (int64_t)r0 * a.is_h + (int64_t)t0 * (D * 2);
+  const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ibase), 0,
+                                                                        (int)((nr - 1u) * a.is_h + nt * (D * 2)), 0x00020000);
+  const uint32_t ioff = tok < nt ? sub * a.is_h + wv * 16u : kOut;
+  Vec8<IDT> x[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    x[i].w = __builtin_amdgcn_raw_buffer_load_b128(irs, ioff, (uint32_t)(i * RPI) * a.is_h, PHASE == 1 ? 0 : 2 /* non-temporal */);
+
+  constexpr int DVSH = DV == 16 ? 4 : 3;
+  float s32;
+  if constexpr (PHASE == 2) {
+    s32 = fmaxf((tok < nt ? a.absmax[(int64_t)g * a.T + t0 + tok] : 0.0f) / QRange<BITS>::qmax, a.eps);
+  } else {
+    uint32_t m = 0u;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) m = max(m, x[i].absmax_bits());  // across the lane's rows
+    if constexpr (RPI == 2) m = max(m, (uint32_t)__shfl_xor((int)m, 32));
+    m = group_umax(m, DVSH);  // across the D/8 lanes of the token
+    if constexpr (PHASE == 1) {
+      if ((lane % DV) == 0u && sub == 0u && tok < nt)
+        atomicMax(reinterpret_cast<uint32_t*>(a.absmax) + (int64_t)g * a.T + t0 + tok, __float_as_uint(Vec8<IDT>::bits_to_f32(m)));
+      return;
+    }
+    s32 = fmaxf(Vec8<IDT>::bits_to_f32(m) / QRange<BITS>::qmax, a.eps);
+  }
+  const float rcp = 1.0f / s32;
+  if ((lane % DV) == 0u && sub == 0u && tok < nt && r0 == 0u) a.scales[(int64_t)g * a.ssg + t0 + tok] = Elem<IDT>::round_trip(s32);
+
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    uint32_t qb[8];
+    quotient_bits8<BITS>(x[i], s32, rcp, qb);
+    const uint32_t widx = (((uint32_t)(i * RPI) + sub) * LPR + wv) * (QV / 4);  // output order: row-major, wv * QV inside the run
+    if constexpr (BITS == 8) {
+      const u32x2 w = pack_i8(qb);
+      *reinterpret_cast<u32x2*>(&s_out[widx]) = w;
+    } else {
+      s_out[widx] = pack_i4(qb);
+    }
+  }
+  // one wave: its LDS queue is in order; only the compiler must not move the reads above the writes
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  uint8_t* obase = a.q + (int64_t)g * a.qs_g + (int64_t)r0 * a.qs_h + (int64_t)t0 * (D * BITS / 8);
+  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (int)((nr - 1u) * a.qs_h + nt * (D * BITS / 8)), 0x00020000);
+  // 16 B piece k = 1024 j + 16 lane of the staged tile: row k / ROWB, byte k % ROWB of the row's run
+  const uint32_t lrow = lane * 16u / ROWB, loff = lane * 16u % ROWB;
+  const uint32_t ooff = loff < nt * (uint32_t)(D * BITS / 8) ? lrow * a.qs_h + loff : kOut;
+#pragma unroll
+  for (int j = 0; j < NST; ++j) {
+    const u32x4 w = *reinterpret_cast<const u32x4*>(&s_out[j * 256 + lane * 4]);
+    const uint32_t off = (OUTB % 1024 == 0 || (uint32_t)j * 1024u + lane * 16u < (uint32_t)OUTB) ? ooff : kOut;
+    __builtin_amdgcn_raw_buffer_store_b128(w, ors, off, (uint32_t)(j * (1024 / ROWB)) * a.qs_h, 2 /* non-temporal */);
+  }
+}
+
+#if KVQ_AB
 // ---------------------------------------------------------------------------- pipelined one-wave tiles
 // The shipped prefill shape (R rows x 64 vectors per tile, one wave per tile: REGMAX above) as a
 // software pipeline: ONE wave walks TPW consecutive tiles and requests tile n + 1's R non-temporal
@@ -413,6 +529,8 @@ __global__ __launch_bounds__(kWave) void quant_tokens_pipe_k(const QuantArgs a) 
     }
   }
 }
+
+#endif  // KVQ_AB
 
 // ---------------------------------------------------------------------------- swept tile (any R)
 // Batched slices whose B*H*D exceeds the register tile (e.g. B = 64): the workgroup still owns
@@ -644,9 +762,9 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
   if (fused && a.rpc) {  // swept tile: B*H*D larger than the register tile
     const unsigned tiles = (a.T + a.TT - 1) / a.TT;
     if (a.vpr)
-      hipLaunchKernelGGL((quant_tokens_sweep_k<IDT, BITS, false>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
+      KVQ_LAUNCH((quant_tokens_sweep_k<IDT, BITS, false>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
     else
-      hipLaunchKernelGGL((quant_tokens_sweep_k<IDT, BITS, true>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
+      KVQ_LAUNCH((quant_tokens_sweep_k<IDT, BITS, true>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
   } else if (fused) {
     const unsigned tiles = (a.T + a.TT - 1) / a.TT;
     // LDS-staged 16 B stores need 16-byte aligned row runs in the store
@@ -655,17 +773,18 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
                          a.qs.t % 16 == 0 && aligned(a.q, 16);
     const bool rowu = a.vshift >= 8;
     // complete tiles go to the predicate-free FULL kernel, a ragged last tile to the general one
+#if KVQ_AB
     if (a.blk == 64 && a.nv == 4) {  // smallest tile: 2048 elements per wave, row runs <= one wave
       const unsigned n_small = a.nvec == 64u * 4u ? a.T / a.TT : 0u;
       if (n_small) {
         QuantArgs f = a;
         f.t_begin = 0;
-        hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, false, true, true, 64, true, 4>), dim3(n_small, a.G), dim3(64), 0, st, f);
+        KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, false, true, true, 64, true, 4>), dim3(n_small, a.G), dim3(64), 0, st, f);
       }
       if (tiles - n_small) {
         QuantArgs t = a;
         t.t_begin = n_small * a.TT;
-        hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, false, true, false, 64, false, 4>), dim3(tiles - n_small, a.G), dim3(64), 0, st, t);
+        KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, false, true, false, 64, false, 4>), dim3(tiles - n_small, a.G), dim3(64), 0, st, t);
       }
       return;
     }
@@ -676,21 +795,24 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
         QuantArgs f = a;
         f.t_begin = 0;
         if (regmax2)
-          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, 2, 16>), dim3(n_small, a.G), dim3(64), 0, st, f);
+          KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, 2, 16>), dim3(n_small, a.G), dim3(64), 0, st, f);
         else
-          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, 0, 16>), dim3(n_small, a.G), dim3(64), 0, st, f);
+          KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, 0, 16>), dim3(n_small, a.G), dim3(64), 0, st, f);
       }
       if (tiles - n_small) {
         QuantArgs t = a;
         t.t_begin = n_small * a.TT;
-        hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, false, 64, 0, 16>), dim3(tiles - n_small, a.G), dim3(64), 0, st, t);
+        KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, true, true, false, 64, 0, 16>), dim3(tiles - n_small, a.G), dim3(64), 0, st, t);
       }
       return;
     }
-    if (a.blk == 64 || a.blk == 128) {  // small workgroups (host guarantees ROWU + LDS_OUT eligibility)
+#endif
+    if constexpr (KVQ_AB || IDT != KVQ_F32)
+    if (a.blk == 64 || (KVQ_AB && a.blk == 128)) {  // small workgroups (host guarantees ROWU + LDS_OUT eligibility)
       unsigned n_small = a.nvec == (uint32_t)(a.blk * kNVMax) ? a.T / a.TT : 0u;
       const bool regmax = (1 << a.vshift) == a.blk && !tunables().quant_no_regmax;  // one round == one row
       unsigned piped = 0;  // tiles taken by the pipelined kernel (multiples of its tiles-per-wave)
+#if KVQ_AB
       if constexpr (IDT != KVQ_F32) {
         const int64_t tpw = tunables().quant_tpw;
         if (a.blk == 64 && regmax && a.R == 8u && (tpw == 2 || tpw == 4 || tpw == 8) && n_small >= (unsigned)tpw && a.bh_contig) {
@@ -698,47 +820,53 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
           QuantArgs f = a;
           f.t_begin = 0;
           const dim3 grid(piped / (unsigned)tpw, a.G);
-          if (tpw == 2) hipLaunchKernelGGL((quant_tokens_pipe_k<IDT, BITS, 8, 2>), grid, dim3(64), 0, st, f);
-          else if (tpw == 4) hipLaunchKernelGGL((quant_tokens_pipe_k<IDT, BITS, 8, 4>), grid, dim3(64), 0, st, f);
-          else hipLaunchKernelGGL((quant_tokens_pipe_k<IDT, BITS, 8, 8>), grid, dim3(64), 0, st, f);
+          if (tpw == 2) KVQ_LAUNCH((quant_tokens_pipe_k<IDT, BITS, 8, 2>), grid, dim3(64), 0, st, f);
+          else if (tpw == 4) KVQ_LAUNCH((quant_tokens_pipe_k<IDT, BITS, 8, 4>), grid, dim3(64), 0, st, f);
+          else KVQ_LAUNCH((quant_tokens_pipe_k<IDT, BITS, 8, 8>), grid, dim3(64), 0, st, f);
         }
       }
+#endif
       n_small -= piped;
       if (n_small) {
         QuantArgs f = a;
         f.t_begin = piped * a.TT;
         const dim3 grid(n_small, a.G);
+#if KVQ_AB
         if (a.blk == 64 && regmax && IDT != KVQ_F32 && a.R == 8u && a.D == 128u && a.TT == 4u && a.vshift == 6 && a.dvshift == 4 &&
             a.is.t == 128 && a.qs.t == 128 * BITS / 8 && !a.xcd_group && !tunables().quant_lds_pad && tunables().quant_geo128)
-        {  // nt_loads / quant_nt_stores pick the instantiation (A-B knobs; both non-temporal is what ships)
+        {  // round 2's shipped shape; nt_loads / quant_nt_stores pick the instantiation
           constexpr bool kGeo = IDT != KVQ_F32;
           if (a.nt_loads && a.nt_stores)
-            hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, 1, kNVMax, kGeo, true, true>), grid, dim3(64), 0, st, f);
+            KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, 1, kNVMax, kGeo, true, true>), grid, dim3(64), 0, st, f);
           else if (a.nt_loads)
-            hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, 1, kNVMax, kGeo, true, false>), grid, dim3(64), 0, st, f);
+            KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, 1, kNVMax, kGeo, true, false>), grid, dim3(64), 0, st, f);
           else if (a.nt_stores)
-            hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, 1, kNVMax, kGeo, false, true>), grid, dim3(64), 0, st, f);
+            KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, 1, kNVMax, kGeo, false, true>), grid, dim3(64), 0, st, f);
           else
-            hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, 1, kNVMax, kGeo, false, false>), grid, dim3(64), 0, st, f);
+            KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, 1, kNVMax, kGeo, false, false>), grid, dim3(64), 0, st, f);
         }
-        else if (a.blk == 64 && regmax)  // quant_lds_pad: occupancy A-B only (dynamic LDS the kernel never touches)
-          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, true>), grid, dim3(64),
-                             (size_t)tunables().quant_lds_pad, st, f);
-        else if (a.blk == 64)
-          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 64>), grid, dim3(64), 0, st, f);
-        else if (regmax)
-          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 128, true>), grid, dim3(128), 0, st, f);
+        else if (a.blk == 128 && regmax)
+          KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, true, true, true, 128, true>), grid, dim3(128), 0, st, f);
+        else if (a.blk == 128)
+          KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, true, true, true, 128>), grid, dim3(128), 0, st, f);
         else
-          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true, 128>), grid, dim3(128), 0, st, f);
+#endif
+        if (regmax)  // quant_lds_pad (A-B): dynamic LDS the kernel never touches, an occupancy cap
+          KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, true, true, true, 64, true>), grid, dim3(64),
+                             (size_t)tunables().quant_lds_pad, st, f);
+        else
+          KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, true, true, true, 64>), grid, dim3(64), 0, st, f);
       }
       if (tiles - n_small - piped) {
         QuantArgs t = a;
         t.t_begin = (n_small + piped) * a.TT;
         const dim3 grid(tiles - n_small - piped, a.G);
-        if (a.blk == 64)
-          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, false, 64>), grid, dim3(64), 0, st, t);
+#if KVQ_AB
+        if (a.blk == 128)
+          KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, true, true, false, 128>), grid, dim3(128), 0, st, t);
         else
-          hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, false, 128>), grid, dim3(128), 0, st, t);
+#endif
+          KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, true, true, false, 64>), grid, dim3(64), 0, st, t);
       }
       return;
     }
@@ -746,32 +874,35 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
     if (n_full) {
       QuantArgs f = a;
       f.t_begin = 0;
-      hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, true>), dim3(n_full, a.G), dim3(kBlock), 0, st, f);
+      KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, true, true, true>), dim3(n_full, a.G), dim3(kBlock), 0, st, f);
     }
     const unsigned rest = tiles - n_full;
     if (rest) {
       QuantArgs t = a;
       t.t_begin = n_full * a.TT;
+#if KVQ_AB  // the scalar-row instantiations of the ragged tile: the general index split below covers them
       if (rowu && lds_out)
-        hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, true, false>), dim3(rest, a.G), dim3(kBlock), 0, st, t);
+        KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, true, true, false>), dim3(rest, a.G), dim3(kBlock), 0, st, t);
       else if (rowu)
-        hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, true, false, false>), dim3(rest, a.G), dim3(kBlock), 0, st, t);
-      else if (lds_out)
-        hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, false, true, false>), dim3(rest, a.G), dim3(kBlock), 0, st, t);
+        KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, true, false, false>), dim3(rest, a.G), dim3(kBlock), 0, st, t);
       else
-        hipLaunchKernelGGL((quant_tokens_fused_k<IDT, BITS, false, false, false>), dim3(rest, a.G), dim3(kBlock), 0, st, t);
+#endif
+      if (lds_out)
+        KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, false, true, false>), dim3(rest, a.G), dim3(kBlock), 0, st, t);
+      else
+        KVQ_LAUNCH((quant_tokens_fused_k<IDT, BITS, false, false, false>), dim3(rest, a.G), dim3(kBlock), 0, st, t);
     }
   } else {
     const int64_t RD = (int64_t)a.R * a.D;
     const int64_t chunk_elems = (int64_t)kBlock * 16;
     const uint32_t cpt = (uint32_t)((RD + chunk_elems - 1) / chunk_elems);
     if (hipMemsetAsync(a.absmax_ws, 0, sizeof(float) * (size_t)a.G * a.T, st) != hipSuccess) return;  // surfaced by check_launch
-    hipLaunchKernelGGL((absmax_tokens_generic_k<IDT>), dim3(a.T * cpt, a.G), dim3(kBlock), 0, st, a, cpt, chunk_elems);
+    KVQ_LAUNCH((absmax_tokens_generic_k<IDT>), dim3(a.T * cpt, a.G), dim3(kBlock), 0, st, a, cpt, chunk_elems);
     const int64_t Dq = BITS == 8 ? a.D : (a.D + 1) / 2;
     const int64_t total = (int64_t)a.G * a.B * a.H * a.T * Dq;
     int64_t blocks = (total + kBlock - 1) / kBlock;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL((quant_tokens_generic_k<IDT, BITS>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a, total);
+    KVQ_LAUNCH((quant_tokens_generic_k<IDT, BITS>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a, total);
   }
 }
 
@@ -816,6 +947,62 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
   a.T = (uint32_t)d->T;
   a.D = (uint32_t)d->D;
   a.R = (uint32_t)R;
+
+  // ---- compile-time tile kernel: the BASELINE shapes (quant_tile_k) ---------------------------------------------
+  if (tunables().quant_tile && !tunables().quant_force_two_pass && in_dtype != KVQ_F32 && (d->B == 1 || (a.is.b == d->H * a.is.h && a.qs.b == d->H * a.qs.h)) &&
+      (d->T == 1 || (a.is.t == d->D && a.qs.t == Dq)) && (a.is.h * 2) % 16 == 0 && a.qs.h % 16 == 0 && a.qs.g % 16 == 0 &&
+      ((int64_t)d->D * BITS / 8) % 16 == 0 && aligned(q, 16) && a.is.h >= 0 && a.qs.h >= 0) {
+    int tt = 0;  // tokens per tile of the instantiation that serves (R, D); 0 = none
+    if (d->D == 128 && R == 8) tt = 4;
+    else if (d->D == 64 && (R == 8 || R == 12 || R == 16)) tt = tunables().quant_tile_tt == 4 && KVQ_AB ? 4 : 8;
+    const int64_t span_in = (R - 1) * a.is.h * 2 + (int64_t)tt * d->D * 2, span_q = (R - 1) * a.qs.h + (int64_t)tt * Dq;
+    if (tt && span_in < (int64_t(1) << 31) && span_q < (int64_t(1) << 31)) {
+      bool all_aligned = true;
+      for (int64_t i = 0; i < d->G; ++i)
+        all_aligned = all_aligned && aligned(in_ptrs ? in_ptrs[i] : static_cast<const char*>(in_base) + i * a.is.g * (int64_t)esz, 16) &&
+                      (in_ptrs ? in_ptrs[i] : in_base) != nullptr;
+      if (all_aligned) {
+        QuantTileArgs ta;
+        ta.qs_g = a.qs.g;
+        ta.ssg = ssg;
+        ta.is_h = (uint32_t)(a.is.h * 2);
+        ta.qs_h = (uint32_t)a.qs.h;
+        ta.T = (uint32_t)d->T;
+        ta.rows = (uint32_t)R;
+        ta.absmax = nullptr;
+        ta.eps = eps;
+        for (int64_t g0 = 0; g0 < d->G; g0 += kPtrsPerLaunch) {
+          const int64_t gn = d->G - g0 < kPtrsPerLaunch ? d->G - g0 : kPtrsPerLaunch;
+          for (int64_t i = 0; i < gn; ++i)
+            ta.in.p[i] = in_ptrs ? in_ptrs[g0 + i] : static_cast<const char*>(in_base) + (g0 + i) * a.is.g * (int64_t)esz;
+          ta.q = q + g0 * a.qs.g;
+          ta.scales = scales + g0 * ssg;
+          const dim3 grid((unsigned)((d->T + tt - 1) / tt), (unsigned)gn);
+#define KVQ_TILE(IDT_, R_, DV_, TT_) KVQ_LAUNCH((quant_tile_k<IDT_, BITS, R_, DV_, TT_>), grid, dim3(kWave), 0, st, ta)
+#if KVQ_AB
+#define KVQ_TILE64(IDT_, R_) do { if (tt == 4) KVQ_TILE(IDT_, R_, 8, 4); else KVQ_TILE(IDT_, R_, 8, 8); } while (0)
+#else
+#define KVQ_TILE64(IDT_, R_) KVQ_TILE(IDT_, R_, 8, 8)
+#endif
+#define KVQ_TILE_BY_SHAPE(IDT_)                         \
+  do {                                                  \
+    if (d->D == 128) KVQ_TILE(IDT_, 8, 16, 4);          \
+    else if (R == 8) KVQ_TILE64(IDT_, 8);               \
+    else if (R == 12) KVQ_TILE64(IDT_, 12);             \
+    else KVQ_TILE64(IDT_, 16);                          \
+  } while (0)
+          if (in_dtype == KVQ_F16) KVQ_TILE_BY_SHAPE(KVQ_F16);
+          else KVQ_TILE_BY_SHAPE(KVQ_BF16);
+#undef KVQ_TILE_BY_SHAPE
+#undef KVQ_TILE64
+#undef KVQ_TILE
+          const int rc = check_launch(name);
+          if (rc) return rc;
+        }
+        return 0;
+      }
+    }
+  }
 
   // fused single-pass eligibility (layout); pointer alignment is checked per launch chunk below
   const int dvshift = d->D % 8 == 0 ? ilog2_exact(d->D / 8) : -1;
@@ -875,11 +1062,13 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
     a.nvec = (uint32_t)(R * tt * (d->D / 8));
     // one-wave workgroups: tile of 64 * kNVMax vectors, every row run >= 64 vectors (ROWU), 16-byte
     // aligned row runs in the store (LDS_OUT)
-    const int64_t sblk = tunables().quant_block == 128 ? 128 : 64;
-    const int64_t snv = (sblk == 64 && tunables().quant_nv == 4) ? 4 : (sblk == 64 && tunables().quant_nv == 16) ? 16 : kNVMax;
+    const int64_t sblk = KVQ_AB && tunables().quant_block == 128 ? 128 : 64;
+    const int64_t snv = !KVQ_AB ? kNVMax : (sblk == 64 && tunables().quant_nv == 4) ? 4 : (sblk == 64 && tunables().quant_nv == 16) ? 16 : kNVMax;
     const int64_t tile64 = sblk * snv * 8;
     const int64_t dq16 = (int64_t)d->D * BITS / 8;
-    if ((tunables().quant_block == 64 || tunables().quant_block == 128) && R * d->D <= tile64 && dq16 % 16 == 0 &&
+    // (fp32 input — the reference's CPU dtype, never what a GPU model holds — keeps to the 256-thread kernels in the
+    // default library)
+    if ((KVQ_AB || in_dtype != KVQ_F32) && (tunables().quant_block == 64 || tunables().quant_block == 128) && R * d->D <= tile64 && dq16 % 16 == 0 &&
         a.qs.g % 16 == 0 && a.qs.h % 16 == 0 && a.qs.t % 16 == 0 && aligned(q, 16)) {
       uint32_t t64 = pow2_floor((uint64_t)(tile64 / (R * d->D)));
       if (t64 > kMaxTT) t64 = kMaxTT;
@@ -987,6 +1176,53 @@ static int split_phase(const char* name, int bits, const void* in_base, const vo
              (a.is.h * esz) % 16 == 0 && (a.is.t * esz) % 16 == 0;
   if (PHASE == 2)
     vec = vec && a.qs.g % qvec == 0 && a.qs.b % qvec == 0 && a.qs.h % qvec == 0 && a.qs.t % qvec == 0 && aligned(q, qvec);
+  // ---- one-wave tile kernels over 8-row groups (quant_tile_k PHASE 1 / 2): what a batch-sharded prefill chunk takes ----
+  const int64_t Rt = d->B * d->H;
+  bool tile = tunables().quant_tile && in_dtype != KVQ_F32 && (d->D == 128 || d->D == 64) && (d->T == 1 || a.is.t == d->D) &&
+              (d->B == 1 || a.is.b == d->H * a.is.h) && (a.is.h * 2) % 16 == 0 && a.is.h >= 0 &&
+              (Rt - 1) * a.is.h * 2 + 8 * d->D * 2 < (int64_t(1) << 31) && (Rt + 7) / 8 < 65536;
+  if (PHASE == 2)
+    tile = tile && (d->T == 1 || a.qs.t == d->D * bits / 8) && (d->B == 1 || a.qs.b == d->H * a.qs.h) && a.qs.h % 16 == 0 && a.qs.g % 16 == 0 &&
+           a.qs.h >= 0 && (d->D * bits / 8) % 16 == 0 && aligned(q, 16) && (Rt - 1) * a.qs.h + 8 * d->D < (int64_t(1) << 31);
+  for (int64_t i = 0; i < d->G && tile; ++i)
+    tile = aligned(in_ptrs ? in_ptrs[i] : static_cast<const char*>(in_base) + i * a.is.g * (int64_t)esz, 16) && (in_ptrs ? in_ptrs[i] : in_base) != nullptr;
+  if (tile) {
+    const int tt = d->D == 128 ? 4 : 8;
+    QuantTileArgs ta;
+    ta.qs_g = PHASE == 2 ? a.qs.g : 0;
+    ta.ssg = ssg;
+    ta.is_h = (uint32_t)(a.is.h * 2);
+    ta.qs_h = PHASE == 2 ? (uint32_t)a.qs.h : 0u;
+    ta.T = (uint32_t)d->T;
+    ta.rows = (uint32_t)Rt;
+    ta.eps = eps;
+    if (PHASE == 1 && hipMemsetAsync(absmax, 0, sizeof(float) * (size_t)(d->G * d->T), st) != hipSuccess) return check_launch(name);
+    for (int64_t g0 = 0; g0 < d->G; g0 += kPtrsPerLaunch) {
+      const int64_t gn = d->G - g0 < kPtrsPerLaunch ? d->G - g0 : kPtrsPerLaunch;
+      for (int64_t i = 0; i < gn; ++i)
+        ta.in.p[i] = in_ptrs ? in_ptrs[g0 + i] : static_cast<const char*>(in_base) + (g0 + i) * a.is.g * (int64_t)esz;
+      ta.absmax = absmax + g0 * d->T;
+      ta.q = PHASE == 2 ? q + g0 * a.qs.g : nullptr;
+      ta.scales = PHASE == 2 ? scales + g0 * ssg : nullptr;
+      const dim3 grid((unsigned)((d->T + tt - 1) / tt), (unsigned)gn, (unsigned)((Rt + 7) / 8));
+#define KVQ_PH(IDT_, BITS_, DV_, TT_) KVQ_LAUNCH((quant_tile_k<IDT_, BITS_, 8, DV_, TT_, PHASE>), grid, dim3(kWave), 0, st, ta)
+#define KVQ_PH_SHAPE(IDT_, BITS_) do { if (d->D == 128) KVQ_PH(IDT_, BITS_, 16, 4); else KVQ_PH(IDT_, BITS_, 8, 8); } while (0)
+      if (PHASE == 1 || bits == 8) {  // the abs-max phase never looks at BITS: one instantiation (8)
+        if (in_dtype == KVQ_F16) KVQ_PH_SHAPE(KVQ_F16, 8);
+        else KVQ_PH_SHAPE(KVQ_BF16, 8);
+      } else {
+        if constexpr (PHASE == 2) {
+          if (in_dtype == KVQ_F16) KVQ_PH_SHAPE(KVQ_F16, 4);
+          else KVQ_PH_SHAPE(KVQ_BF16, 4);
+        }
+      }
+#undef KVQ_PH_SHAPE
+#undef KVQ_PH
+      const int rc = check_launch(name);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   if (vec) {  // tile = TT tokens (power of two) x D/8 vectors <= 256 vectors per row run
     uint32_t tt = pow2_floor((uint64_t)(kBlock >> dvshift));
     while (tt > 1 && tt / 2 >= (uint64_t)d->T) tt /= 2;
@@ -1017,27 +1253,27 @@ static int split_phase(const char* name, int bits, const void* in_base, const vo
   switch (in_dtype) { case KVQ_F16: EXPR_F16; break; case KVQ_BF16: EXPR_BF16; break; default: EXPR_F32; break; }
     if (PHASE == 1) {
       if (vec_here) {
-        KVQ_BY_DTYPE(hipLaunchKernelGGL((absmax_tokens_tile_k<KVQ_F16>), grid, dim3(kBlock), 0, st, a),
-                     hipLaunchKernelGGL((absmax_tokens_tile_k<KVQ_BF16>), grid, dim3(kBlock), 0, st, a),
-                     hipLaunchKernelGGL((absmax_tokens_tile_k<KVQ_F32>), grid, dim3(kBlock), 0, st, a))
+        KVQ_BY_DTYPE(KVQ_LAUNCH((absmax_tokens_tile_k<KVQ_F16>), grid, dim3(kBlock), 0, st, a),
+                     KVQ_LAUNCH((absmax_tokens_tile_k<KVQ_BF16>), grid, dim3(kBlock), 0, st, a),
+                     KVQ_LAUNCH((absmax_tokens_tile_k<KVQ_F32>), grid, dim3(kBlock), 0, st, a))
       } else {
         if (hipMemsetAsync(a.absmax_ws, 0, sizeof(float) * (size_t)(gn * d->T), st) != hipSuccess) return check_launch(name);
         const int64_t RD = (int64_t)a.R * a.D, chunk_elems = (int64_t)kBlock * 16;
         const uint32_t cpt = (uint32_t)((RD + chunk_elems - 1) / chunk_elems);
         const dim3 ggrid((unsigned)(a.T * cpt), (unsigned)gn);
-        KVQ_BY_DTYPE(hipLaunchKernelGGL((absmax_tokens_generic_k<KVQ_F16>), ggrid, dim3(kBlock), 0, st, a, cpt, chunk_elems),
-                     hipLaunchKernelGGL((absmax_tokens_generic_k<KVQ_BF16>), ggrid, dim3(kBlock), 0, st, a, cpt, chunk_elems),
-                     hipLaunchKernelGGL((absmax_tokens_generic_k<KVQ_F32>), ggrid, dim3(kBlock), 0, st, a, cpt, chunk_elems))
+        KVQ_BY_DTYPE(KVQ_LAUNCH((absmax_tokens_generic_k<KVQ_F16>), ggrid, dim3(kBlock), 0, st, a, cpt, chunk_elems),
+                     KVQ_LAUNCH((absmax_tokens_generic_k<KVQ_BF16>), ggrid, dim3(kBlock), 0, st, a, cpt, chunk_elems),
+                     KVQ_LAUNCH((absmax_tokens_generic_k<KVQ_F32>), ggrid, dim3(kBlock), 0, st, a, cpt, chunk_elems))
       }
     } else if (vec_here) {
       if (bits == 8) {
-        KVQ_BY_DTYPE(hipLaunchKernelGGL((quant_tokens_scaled_tile_k<KVQ_F16, 8>), grid, dim3(kBlock), 0, st, a),
-                     hipLaunchKernelGGL((quant_tokens_scaled_tile_k<KVQ_BF16, 8>), grid, dim3(kBlock), 0, st, a),
-                     hipLaunchKernelGGL((quant_tokens_scaled_tile_k<KVQ_F32, 8>), grid, dim3(kBlock), 0, st, a))
+        KVQ_BY_DTYPE(KVQ_LAUNCH((quant_tokens_scaled_tile_k<KVQ_F16, 8>), grid, dim3(kBlock), 0, st, a),
+                     KVQ_LAUNCH((quant_tokens_scaled_tile_k<KVQ_BF16, 8>), grid, dim3(kBlock), 0, st, a),
+                     KVQ_LAUNCH((quant_tokens_scaled_tile_k<KVQ_F32, 8>), grid, dim3(kBlock), 0, st, a))
       } else {
-        KVQ_BY_DTYPE(hipLaunchKernelGGL((quant_tokens_scaled_tile_k<KVQ_F16, 4>), grid, dim3(kBlock), 0, st, a),
-                     hipLaunchKernelGGL((quant_tokens_scaled_tile_k<KVQ_BF16, 4>), grid, dim3(kBlock), 0, st, a),
-                     hipLaunchKernelGGL((quant_tokens_scaled_tile_k<KVQ_F32, 4>), grid, dim3(kBlock), 0, st, a))
+        KVQ_BY_DTYPE(KVQ_LAUNCH((quant_tokens_scaled_tile_k<KVQ_F16, 4>), grid, dim3(kBlock), 0, st, a),
+                     KVQ_LAUNCH((quant_tokens_scaled_tile_k<KVQ_BF16, 4>), grid, dim3(kBlock), 0, st, a),
+                     KVQ_LAUNCH((quant_tokens_scaled_tile_k<KVQ_F32, 4>), grid, dim3(kBlock), 0, st, a))
       }
     } else {
       const int64_t Dq = bits == 8 ? d->D : (d->D + 1) / 2;
@@ -1045,13 +1281,13 @@ static int split_phase(const char* name, int bits, const void* in_base, const vo
       int64_t gb = (total + kBlock - 1) / kBlock;
       if (gb > 256 * 32) gb = 256 * 32;
       if (bits == 8) {
-        KVQ_BY_DTYPE(hipLaunchKernelGGL((quant_tokens_generic_k<KVQ_F16, 8>), dim3((unsigned)gb), dim3(kBlock), 0, st, a, total),
-                     hipLaunchKernelGGL((quant_tokens_generic_k<KVQ_BF16, 8>), dim3((unsigned)gb), dim3(kBlock), 0, st, a, total),
-                     hipLaunchKernelGGL((quant_tokens_generic_k<KVQ_F32, 8>), dim3((unsigned)gb), dim3(kBlock), 0, st, a, total))
+        KVQ_BY_DTYPE(KVQ_LAUNCH((quant_tokens_generic_k<KVQ_F16, 8>), dim3((unsigned)gb), dim3(kBlock), 0, st, a, total),
+                     KVQ_LAUNCH((quant_tokens_generic_k<KVQ_BF16, 8>), dim3((unsigned)gb), dim3(kBlock), 0, st, a, total),
+                     KVQ_LAUNCH((quant_tokens_generic_k<KVQ_F32, 8>), dim3((unsigned)gb), dim3(kBlock), 0, st, a, total))
       } else {
-        KVQ_BY_DTYPE(hipLaunchKernelGGL((quant_tokens_generic_k<KVQ_F16, 4>), dim3((unsigned)gb), dim3(kBlock), 0, st, a, total),
-                     hipLaunchKernelGGL((quant_tokens_generic_k<KVQ_BF16, 4>), dim3((unsigned)gb), dim3(kBlock), 0, st, a, total),
-                     hipLaunchKernelGGL((quant_tokens_generic_k<KVQ_F32, 4>), dim3((unsigned)gb), dim3(kBlock), 0, st, a, total))
+        KVQ_BY_DTYPE(KVQ_LAUNCH((quant_tokens_generic_k<KVQ_F16, 4>), dim3((unsigned)gb), dim3(kBlock), 0, st, a, total),
+                     KVQ_LAUNCH((quant_tokens_generic_k<KVQ_BF16, 4>), dim3((unsigned)gb), dim3(kBlock), 0, st, a, total),
+                     KVQ_LAUNCH((quant_tokens_generic_k<KVQ_F32, 4>), dim3((unsigned)gb), dim3(kBlock), 0, st, a, total))
       }
     }
 #undef KVQ_BY_DTYPE

@@ -157,7 +157,6 @@ def dequant_tokens(q: torch.Tensor, scales: torch.Tensor, out: torch.Tensor, kin
         raise _lib.KvqError(f"kvq: scales must be fp32 {(G, T)} with unit token stride")
     lib = _lib.load()
     if G * B * H * T * D == 0:
-        lib.kvq_time_next_launch(None, None)  # one-shot: an empty table takes pending timing events with it
         return
     fn = lib.kvq_dequant_i8_tokens if bits == 8 else lib.kvq_dequant_i4_tokens
     rc = fn(c_void_p(q.data_ptr()), byref(strides4(q)), c_void_p(scales.data_ptr()), scales.stride(0),

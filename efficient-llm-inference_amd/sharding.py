@@ -234,14 +234,14 @@ def benchmark_sharded(benchmarker, prompts: Sequence[str], method: str, **kw) ->
 
 # --------------------------------------------------------------------------- the one exchange step
 
-def all_reduce_absmax(table: torch.Tensor) -> torch.Tensor:
+def all_reduce_absmax(table: torch.Tensor, force: bool = False) -> torch.Tensor:
     """``all_reduce(MAX)`` of the ``[G,T]`` fp32 abs-max table IN PLACE: the single data-path
     collective of the path. RCCL reduces the device tensor directly over xGMI
     (≤ 8 MiB at config 5; 256 B per decode step); under gloo (CPU tests, or a 1-GPU rehearsal)
     the table makes a round trip through host memory. MAX of non-negative floats is exact and
     order-independent, so every rank ends up with bit-identical scales."""
     _, ws = world()
-    if ws == 1:
+    if ws == 1 and not force:
         return table
     if table.dtype != torch.float32:
         raise TypeError("abs-max table must be fp32")
@@ -254,18 +254,86 @@ def all_reduce_absmax(table: torch.Tensor) -> torch.Tensor:
     return table
 
 
-def quantize_tokens_batch_sharded(x_local, kind: str, eps: float = 1e-8):
+# A layer chunk's input should still be in the 256 MiB Infinity Cache when the quantise phase re-reads it, with the next
+# chunk's abs-max pass (which overlaps this chunk's all_reduce) already streaming through: two chunks + their output.
+CHUNK_BYTES = 64 << 20
+
+
+class ShardedQuantBuffers:
+    """Persistent outputs + scratch of :func:`quantize_tokens_batch_sharded` for one KV set: the quantised rows
+    ``q [G,B_local,H,T,Dq]``, the stored scales ``[G,T]``, the abs-max table ``[G,T]`` (one slice per layer chunk is
+    what crosses the ranks), the layer-chunk plan and — on more than one rank — the side stream and events that put
+    chunk i's ``all_reduce(MAX)`` under chunk i + 1's abs-max pass. Built once per (shape, kind); reused every step."""
+
+    def __init__(self, x_local, kind: str, chunk_bytes: int = CHUNK_BYTES, force_overlap: bool = False):
+        from . import kernels as K
+        first = x_local[0]
+        G = len(x_local)
+        B, H, T, D = first.shape
+        dev = first.device
+        self.kind, self.shape = kind, (G, B, H, T, D)
+        self.q = torch.empty(G, B, H, T, K.packed_dim(kind, D), dtype=K.QDTYPE[kind], device=dev)
+        self.scales = torch.empty(G, T, dtype=torch.float32, device=dev)
+        self.absmax = torch.empty(G, T, dtype=torch.float32, device=dev)
+        per_group = max(1, B * H * T * D * first.element_size())
+        self.groups_per_chunk = max(1, min(G, chunk_bytes // per_group))
+        self.chunks = [(g0, min(G, g0 + self.groups_per_chunk)) for g0 in range(0, G, self.groups_per_chunk)]
+        self.n_chunks = len(self.chunks)
+        _, ws = world()
+        # force_overlap: take the side-stream path on ONE rank too (a 1-GPU box's only way to exercise it under RCCL)
+        self.overlap = (ws > 1 or force_overlap) and dev.type == "cuda" and backend() == "nccl"
+        if self.overlap:
+            self.comm_stream = torch.cuda.Stream(device=dev)
+            self.ev_absmax = [torch.cuda.Event() for _ in self.chunks]
+            self.ev_reduced = [torch.cuda.Event() for _ in self.chunks]
+
+
+def quantize_tokens_batch_sharded(x_local, kind: str, eps: float = 1e-8, out: "ShardedQuantBuffers" = None):
     """Quantise this rank's batch rows ``x_local`` (``[G,B_local,H,T,D]`` on the GPU, or a list of G
     ``[B_local,H,T,D]`` tensors) of a slice whose batch is split over the ranks, with the scale of
-    the WHOLE batch (reference ops.py:27,48: one ``abs().max()`` per ``[B,H,1,D]`` slice):
+    the WHOLE batch (reference ops.py:27,48: one ``abs().max()`` per ``[B,H,1,D]`` slice), layer chunk by layer chunk:
 
-        abs-max of the local rows (HIP) -> all_reduce(MAX) of the [G,T] table -> quantise with
-        those abs-max values (HIP)
+        abs-max of the chunk's local rows (HIP, plain loads: the rows stay in the Infinity Cache)
+        -> all_reduce(MAX) of the chunk's [Gc,T] table (RCCL on a side stream, under the NEXT chunk's abs-max pass)
+        -> quantise the chunk with those abs-max values (HIP; the re-read is served from the cache, not from HBM)
 
     Returns ``(q, scales)`` as `kernels.quant_tokens` does for the un-sharded batch: ``q`` holds
     this rank's rows, ``scales`` ``[G,T]`` (stored scales widened to fp32) is identical on every
-    rank and bit-identical to the un-sharded result."""
+    rank and bit-identical to the un-sharded result. ``out``: reuse these buffers (a decode / prefill loop builds them
+    once); the returned tensors are then ``out.q`` / ``out.scales``."""
     from . import kernels as K
-    amax = K.absmax_tokens(x_local)
-    all_reduce_absmax(amax)
-    return K.quant_tokens_with_absmax(x_local, amax, kind, eps)
+    if out is None:
+        out = ShardedQuantBuffers(x_local, kind)
+    G, B, H, T, D = out.shape
+    if len(x_local) != G or tuple(x_local[0].shape) != (B, H, T, D) or out.kind != kind:
+        raise ValueError(f"kvq: ShardedQuantBuffers were built for {out.shape} {out.kind}, got {len(x_local)} x {tuple(x_local[0].shape)} {kind}")
+    _, ws = world()
+
+    def quant(c):
+        g0, g1 = out.chunks[c]
+        K.quant_tokens_with_absmax(x_local[g0:g1], out.absmax[g0:g1], kind, eps, q=out.q[g0:g1], scales=out.scales[g0:g1])
+
+    pending = None  # chunk whose table is being reduced while the next chunk's abs-max runs
+    for c, (g0, g1) in enumerate(out.chunks):
+        K.absmax_tokens(x_local[g0:g1], out.absmax[g0:g1])
+        if ws == 1 and not out.overlap:
+            quant(c)
+            continue
+        if out.overlap:
+            main = torch.cuda.current_stream(out.q.device)
+            out.ev_absmax[c].record(main)
+            with torch.cuda.stream(out.comm_stream):
+                out.comm_stream.wait_event(out.ev_absmax[c])
+                all_reduce_absmax(out.absmax[g0:g1], force=True)
+                out.ev_reduced[c].record(out.comm_stream)
+            if pending is not None:
+                main.wait_event(out.ev_reduced[pending])
+                quant(pending)
+            pending = c
+        else:  # gloo (CPU tests, 1-GPU rehearsal): the table makes its round trip through host memory in stream order
+            all_reduce_absmax(out.absmax[g0:g1])
+            quant(c)
+    if pending is not None:
+        torch.cuda.current_stream(out.q.device).wait_event(out.ev_reduced[pending])
+        quant(pending)
+    return out.q, out.scales

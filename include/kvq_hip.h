@@ -215,10 +215,8 @@ int kvq_decode_attn(const void* q, int64_t q_stride_b, int64_t q_stride_h,
  * (append_from_past ops.py:323-330, to_past_key_values :345-355, attention) behind one call.
  * The caller guarantees capacity for slot T (k_st / v_st describe the whole [B,Hkv,Tcap,Dq] store)
  * and counts the token as stored afterwards. workspace as for kvq_decode_attn (>= 1 float).
- * Two launches: the new token is quantised by two extra workgroups of the merge launch. (Under
- * kvq_set_tunable("attn_fused", 1) grouped-query shapes take ONE launch — tiles, in-workgroup merge,
- * ticketed final merge, new-token quantise; csrc/kvq_attn.hip, decode_attn_fused_mfma_k — which
- * measured slower on MI355X and is therefore opt-in.) The workspace needs no initialisation either way. */
+ * Two launches: the new token is quantised by two extra workgroups of the merge launch.
+ * The workspace needs no initialisation. */
 int kvq_decode_step(const void* q, int64_t q_stride_b, int64_t q_stride_h,
                     const void* k_new, int64_t kn_stride_b, int64_t kn_stride_h,
                     const void* v_new, int64_t vn_stride_b, int64_t vn_stride_h,
@@ -245,8 +243,7 @@ int kvq_decode_step_dev(const void* q, int64_t q_stride_b, int64_t q_stride_h,
                         void* stream);
 
 /* kvq_decode_step (append != 0) or kvq_decode_attn with the new token given (append == 0) for n_layers
- * layers behind ONE host call: the per-layer launches are enqueued back to back on `stream` (each layer
- * one launch on the fused path), so a decode step costs one trip through the binding instead of one per
+ * layers behind ONE host call: the per-layer launches are enqueued back to back on `stream`, so a decode step costs one trip through the binding instead of one per
  * layer — the reference pays 2*T Python-level calls per layer and step here (ops.py:345-355). Every
  * pointer argument is a HOST array of n_layers device pointers; dims, strides, kinds and dtype are
  * shared by all layers; `workspace` is reused by consecutive launches (stream order makes that safe).
@@ -260,40 +257,43 @@ int kvq_decode_step_layers(int64_t n_layers, int append, const void* const* q, i
                            float eps, float* workspace, int64_t workspace_floats, const kvq_attn_dims_t* dims,
                            void* stream);
 
-/* Measurement aid: the NEXT kvq_dequant_i8_tokens / kvq_dequant_i4_tokens call of the calling thread binds these
- * two hipEvent_t (already created; either may be NULL) to its kernel's own dispatch (hipExtLaunchKernelGGL):
- * stop - start is then the kernel's duration as a profiler sees it, without the queue gaps that two hipEventRecord
- * calls around the launch include. One-shot: that call takes them whatever it does (either kernel, an empty table,
- * an error return), so they never reach a later launch. */
+/* Measurement aid: the NEXT kernel launch of the calling thread — whichever entry point makes it — binds these two
+ * hipEvent_t (already created; either may be NULL) to its own dispatch (hipExtLaunchKernelGGL): stop - start is then
+ * the kernel's duration as a profiler sees it, without the queue gaps two hipEventRecord calls around the launch
+ * include. One-shot (the launch takes them); kvq_time_next_launch(NULL, NULL) disarms a pair no launch took — a
+ * caller whose call can fail before it reaches the library must do that (the Python binding does, in a finally). */
 int kvq_time_next_launch(void* start_event, void* stop_event);
 
-/* ---- tuning knobs (benchmarks only; defaults are what ships) ----------------------------- */
+/* Measurement aid: which kernels ran. Every launch of the calling thread notes its kernel; kvq_kernel_log writes the
+ * distinct kernels launched since kvq_kernel_log_clear(), in first-launch order, one demangled name per line (what
+ * rocprofv3 --kernel-trace prints) into buf (n bytes, NUL-terminated, truncated to fit) and returns their count.
+ * bench.py labels every `roofline.kernel` with this, never with a name typed by hand. */
+void kvq_kernel_log_clear(void);
+int64_t kvq_kernel_log(char* buf, int64_t n);
 
-/* Keys (every one changes speed only, never results, except where noted):
- *   dequantise  "dequant_variant" (0..35, -1 = shipped default), "dequant_grid" (workgroups, 0 = one chunk each),
- *               "dequant_xcd_group" (consecutive chunks per XCD, 0 = round robin), "nt_loads" (0/1)
- *   quantise    "quant_force_two_pass" (0/1), "quant_direct_stores" (0/1), "quant_block" (64|128|256),
- *               "quant_nv" (8|4|16), "quant_lds_pad" (bytes of unused dynamic LDS: occupancy A-B),
- *               "quant_tpw" (tiles per wave of the pipelined one-wave kernel: 0 = one tile, 2|4|8),
- *               "quant_no_regmax" (0/1), "quant_xcd_group" (consecutive tiles per XCD, 0 = round robin),
- *               "quant_nt_stores" (1 non-temporal / 0 write-back output stores of the one-wave kernel, -1 = as nt_loads:
- *               default), "quant_geo128" (1 = tile geometry of the 8-row head_dim-128 shape as
- *               compile-time constants, default; 0 = as arguments)
- *   eviction    "pool_grid" (workgroup cap, 0 = none), "pool_block" (64|128|256), "pool_wave" (1 = one wave per
- *               output row where the shape allows, default; 0 = per-lane-group walk; equal output bits)
- *   attention   "attn_force_valu" (0/1), "attn_mfma_min_nq" (default 3), "attn_mfma_tc" (128|64),
- *               "attn_merge_fast" (1 = merge kernel that requests all operands up front, default; 0 = chained merge;
- *               equal output bits), "attn_stream_tpw" (tiles per wave of the streaming kernel: -1 never, 0 by size,
- *               > 0 that many), "attn_stream_tc" (64|32), "attn_stream_slots" (wave slots one round fills),
- *               "attn_stream_roll" (1 = a tile's registers are re-requested piece by piece for the tile after next,
- *               default; 0 = whole tiles between reductions; equal output bits),
- *               "attn_k_i8" (INT8 keys through the int8 MFMA: -1 streaming kernel only, 0 never, 1 always;
- *               tolerance-level difference), "attn_fused" (0/1: one launch per call where it applies; default 0 =
- *               partial + merge launches, measured faster), "attn_fused_tc" / "attn_fused_nw" (tokens per wave /
- *               waves per workgroup of the fused launch: 128/4, 128/8, 64/8, 32/16; 0 = by batch size).
- * Returns 0, or KVQ_E_DIMS for an unknown key. Process-global. */
+/* ---- tuning knobs ---------------------------------------------------------------------------- */
+
+/* Two kinds of keys.
+ * Test knobs (every build) route a call to SHIPPED code it would not take by size or shape; results never change:
+ *   "quant_force_two_pass" (0/1: generic two-pass quantise), "quant_direct_stores" (0/1: no LDS-staged stores in the
+ *   256-thread quantise kernel), "quant_tile" (1 = compile-time one-wave tile kernel where the shape has one, default;
+ *   0 = general kernels), "quant_block" (general quantise kernel: 64-thread one-wave tiles, default, or 256; 128 in A-B builds), "pool_wave" (1 = one wave per output row where the shape allows, default; 0 = per-lane-group
+ *   walk), "attn_force_valu" (0/1), "attn_stream_tpw" (tiles per wave of the streaming attention kernel: -1 never,
+ *   0 by size, > 0 that many), "attn_lds" (LDS-staged MFMA attention: -1 by shape, 0 never, 1 wherever it applies).
+ * A-B keys select variants that lost a measurement and exist only in the A-B library (`make -C csrc ab` ->
+ *   lib/ab/libkvq_hip.so, kvq_is_ab_build() == 1); the default library returns KVQ_E_DIMS for them:
+ *   dequantise  "dequant_variant" (0..35), "dequant_grid", "dequant_xcd_group"
+ *   quantise    "quant_nv" (8|4|16), "quant_lds_pad", "quant_tpw" (0|2|4|8),
+ *               "quant_no_regmax", "quant_xcd_group", "quant_geo128", "quant_nt_stores", "quant_tile_tt" (8|4), "nt_loads"
+ *   eviction    "pool_grid", "pool_block" (64|128|256)
+ *   attention   "attn_mfma_min_nq", "attn_mfma_tc" (128|64), "attn_merge_fast" (0 = chained merge by choice),
+ *               "attn_stream_tc" (64|32), "attn_stream_slots", "attn_stream_roll", "attn_k_i8" (-1|0|1; tolerance-level
+ *               difference), "attn_fused" (one launch per call; refused while the stream is being captured into a
+ *               HIP graph: its arrival epoch is a launch argument), "attn_fused_tc" / "attn_fused_nw".
+ * Returns 0, or KVQ_E_DIMS for an unknown key / an A-B key in the default library. Process-global. */
 int kvq_set_tunable(const char* key, int64_t value);
 int64_t kvq_get_tunable(const char* key);
+int kvq_is_ab_build(void);
 
 #ifdef __cplusplus
 }

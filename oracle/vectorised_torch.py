@@ -34,3 +34,27 @@ def dequantize_tokens(q: torch.Tensor, scales: torch.Tensor, kind: str, D: int, 
         u[..., 1::2] = q & 0x0F
         q = (u.to(torch.int16) - 8).to(torch.int8)[..., :D]                  # ops.py:129-131
     return (q.float() * scales.float()[:, None, None, :, None]).to(out_dtype)  # ops.py:90 / :133
+
+
+def trim_kv_sliding_window(x: torch.Tensor, window_size: int) -> torch.Tensor:
+    """x [..., T, D] -> the last ``window_size`` tokens, materialised (the reference returns the view
+    ``k[:, :, -W:, :]`` and pays the copy in HF's next ``cat``; src/cache/implementations.py:124-140)."""
+    T = x.size(-2)
+    return x if T <= window_size else x[..., T - window_size:, :].contiguous()
+
+
+def chunk_summarize_kv(x: torch.Tensor, chunk_size: int, keep_last: int) -> torch.Tensor:
+    """x [B,H,T,D]: the reference's own op chain (src/cache/implementations.py:313-345): zero-pad the old tokens to
+    a multiple of ``chunk_size``, ``view(B,H,n,chunk,D).mean(dim=3)``, ``cat`` with the recent tail."""
+    B, H, T, D = x.shape
+    keep = min(keep_last, T)
+    old_len = T - keep
+    if old_len <= 0:
+        return x
+    old, recent = x[:, :, :old_len, :], x[:, :, old_len:, :]
+    pad = (chunk_size - old_len % chunk_size) % chunk_size
+    if pad:
+        old = torch.cat([old, torch.zeros(B, H, pad, D, dtype=x.dtype)], dim=2)   # :326-333
+    n = old.size(2) // chunk_size
+    summ = old.view(B, H, n, chunk_size, D).mean(dim=3)                              # :338-339
+    return torch.cat([summ, recent], dim=2)                                          # :344

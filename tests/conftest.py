@@ -18,6 +18,25 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "ab: variant-equality tests of kernels that lost a measurement; they need the A-B library "
+                                       "(make -C efficient-llm-inference_amd/csrc ab) and run with `pytest -m ab` on the GPU box only")
+    if "ab" in (config.getoption("-m") or "").replace("(", " ").replace(")", " ").split() and not os.environ.get("KVQ_HIP_LIB"):
+        # `pytest -m ab`: the A-B library is what gets loaded (before anything imports the package's _lib)
+        os.environ["KVQ_HIP_LIB"] = os.path.join(ROOT, "efficient-llm-inference_amd", "lib", "ab", "libkvq_hip.so")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`ab` tests run only when the -m expression names them: `-m gpu` (the driver's run) and `-m "not gpu"` see the
+    shipped library's tests only."""
+    words = (config.getoption("-m") or "").replace("(", " ").replace(")", " ").split()
+    if "ab" in words:
+        return
+    keep, drop = [], []
+    for it in items:
+        (drop if it.get_closest_marker("ab") else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 def load_golden(name: str):

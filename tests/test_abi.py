@@ -77,9 +77,35 @@ def test_chunk_summary_len_matches_reference_trajectory(lib):
 
 
 def test_tunables(lib):
-    assert lib.kvq_set_tunable(b"dequant_variant", 3) == 0 and lib.kvq_get_tunable(b"dequant_variant") == 3
-    assert lib.kvq_set_tunable(b"dequant_variant", -1) == 0
+    # test knobs route a call to shipped code: settable in every build
+    assert lib.kvq_set_tunable(b"quant_force_two_pass", 1) == 0 and lib.kvq_get_tunable(b"quant_force_two_pass") == 1
+    assert lib.kvq_set_tunable(b"quant_force_two_pass", 0) == 0
     assert lib.kvq_set_tunable(b"nope", 1) == -2
+    # A-B keys select variants only `make ab` builds contain: the default library refuses them (and says why)
+    ab = lib.kvq_is_ab_build()
+    for key in (b"dequant_variant", b"quant_tpw", b"attn_fused", b"attn_stream_roll", b"quant_xcd_group", b"attn_merge_fast"):
+        before = lib.kvq_get_tunable(key)
+        rc = lib.kvq_set_tunable(key, before)
+        assert rc == (0 if ab else -2), key
+        if not ab:
+            assert b"A-B key" in lib.kvq_last_error_string()
+
+
+def test_default_library_is_the_shipped_subset():
+    """The default .so holds the shipped instantiations + generic fallbacks only (the A-B variants live in
+    lib/ab/libkvq_hip.so): it stays small, and it is not an A-B build unless KVQ_HIP_LIB says so."""
+    from efficient_llm_inference_amd import _lib
+    if os.environ.get("KVQ_HIP_LIB"):
+        pytest.skip("KVQ_HIP_LIB overrides the library")
+    assert not _lib.is_ab_build()
+    assert os.path.getsize(_lib.LIB_PATH) < 2.5 * 2**20, os.path.getsize(_lib.LIB_PATH)
+
+
+def test_kernel_log_is_empty_without_launches(lib):
+    import ctypes
+    lib.kvq_kernel_log_clear()
+    buf = ctypes.create_string_buffer(64)
+    assert lib.kvq_kernel_log(buf, 64) == 0 and buf.value == b""
 
 
 def test_no_cpu_fallback_in_product():

@@ -54,6 +54,13 @@ def test_gpus_flag_fails_loudly():
     # a rank that dies takes the job down with a non-zero exit code and no result line
     proc = _bench("--gpus", "2", "--launcher-selftest", env={"KVQ_SELFTEST_FAIL_RANK": "1"})
     assert proc.returncode != 0 and "rank 1" in proc.stderr and "{" not in proc.stdout
+    # a rank whose WORKLOAD raises after the rendezvous leaves at once (no 300 s wait in shutdown's barrier behind its
+    # peers' collective): the launcher reports it within seconds
+    import time
+    t0 = time.monotonic()
+    proc = _bench("--gpus", "2", "--launcher-selftest", env={"KVQ_SELFTEST_RAISE_RANK": "1"}, timeout=120)
+    assert proc.returncode != 0 and "rank 1" in proc.stderr and "workload failure" in proc.stderr and "{" not in proc.stdout
+    assert time.monotonic() - t0 < 90
     # a rank count that disagrees with the launcher's WORLD_SIZE is refused
     proc = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--launcher-selftest"], cwd=ROOT, capture_output=True,
                           text=True, env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
@@ -69,24 +76,49 @@ def test_bench_line_carries_the_contract_fields(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
-                           "--cpu-sample-layers", "1"], capture_output=True, text=True, timeout=600, cwd=root)
+                           "--cpu-sample-layers", "1"], capture_output=True, text=True, timeout=900, cwd=root)
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     j = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-                "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "dtype", "data", "config", "roofline", "cpu_baseline", "decode", "configs", "public_api"):
         assert key in j, key
     assert j["n_gpus"] == 1 and j["steps"] == 4 and j["warmup"] == 2 and j["higher_is_better"] is True and j["vs_baseline"] is None
     assert j["unit"] == "GB/s" and j["scaling"] == "weak" and j["data"] == "synthetic" and j["config"]["workload"] == "llama3_8b_mixed_seq16k"
     r = j["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
         assert key in r, key
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # value = bytes per step / step time; the INT4 launch is part of the step
     assert abs(j["value"] - j["config"]["bytes_per_step"] / (j["ms_per_step"] * 1e-3) / 1e9) / j["value"] < 2e-3
     assert r["avg_launch_ms"] < j["ms_per_step"] and 0.5 < r["frac"] < 1.0
+    # every `kernel` label is what the library launched (kvq_kernel_log), i.e. what a profiler prints
+    assert r["kernel"] == "dequant_tokens_fast_k<0, 4, 8, 4, true, true, false, 64>", r["kernel"]
+    assert j["roofline_k"]["kernel"] == "dequant_tokens_fast_k<0, 8, 8, 2, true, true, true, 64>"
+    assert j["roofline_quantise"]["quant_int4"]["kernel"] == "quant_tile_k<0, 4, 8, 16, 4, 0>"
+    assert j["roofline_quantise"]["quant_int8"]["kernel"] == "quant_tile_k<0, 8, 8, 16, 4, 0>"
+    assert j["public_api"]["ms_per_call"] >= j["ms_per_step"] * 0.9 and j["public_api"]["call"].startswith("QuantizedKVCache.to_past_key_values")
+    # the rest of BASELINE.json's metric rides in the same line
+    d = j["decode"]
+    assert "error" not in d, d
+    assert d["workload"] == "decode:gpt2:quant_int8:512:512" and d["tokens_per_sec"] > 0 and d["full_cache_tokens_per_sec"] > 0
+    assert d["total_new_tokens"] == 512 and 17.0 < d["est_kv_cache_mb"] < 19.0 and abs(d["full_cache_kv_mb"] - 36.0) < 1e-6
+    assert d["graph_decode_tokens_per_sec"] > 0 and d["fused_attention_tokens_per_sec"] > 0
+    c3 = j["configs"]["gpt2m_int4_seq4k"]
+    assert "error" not in c3, c3
+    assert c3["shape_LBHTD"] == [24, 1, 16, 4096, 64] and c3["rotating_sets"] >= 4
+    assert c3["roofline"]["kernel"].startswith("dequant_tokens_fast_k<0, 4,") and c3["roofline_quantise"]["kernel"] == "quant_tile_k<0, 4, 16, 8, 8, 0>"
+    assert 0.3 < c3["roofline"]["frac"] < 1.0 and 0.3 < c3["roofline_quantise"]["frac"] < 1.0
+    g2 = j["configs"]["gpt2_shape_seq32k"]
+    assert "error" not in g2 and g2["quant_int8"]["kernel"] == "quant_tile_k<0, 8, 12, 8, 8, 0>", g2
+    ev = j["configs"]["llama3_8b_evict_seq32k"]
+    assert "error" not in ev, ev
+    assert ev["roofline"]["kernel"].startswith("chunk_pool_wave_k<0, 4, 16>") and ev["roofline_window"]["kernel"].startswith("copy_rows_k<")
+    assert 0.5 < ev["roofline"]["frac"] < 1.0 and 0.3 < ev["roofline_window"]["frac"] < 1.0
     c = j["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
+    assert c["max_rel_err_vs_gpu"] == 0.0 and c["eviction"]["pool_value"] > 0
+    assert j["run_s"] < 200

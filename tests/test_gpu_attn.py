@@ -317,6 +317,7 @@ def tunable():
         _lib.set_tunable(key, old)
 
 
+@pytest.mark.ab
 @pytest.mark.parametrize("shape", FUSED_SHAPES)
 @pytest.mark.parametrize("kinds", [("int8", "int4"), ("int4", "int8"), ("int8", "int8"), ("int4", "int4")])
 def test_decode_attn_fused_shapes_match_oracle(K, tunable, shape, kinds):
@@ -331,6 +332,7 @@ def test_decode_attn_fused_shapes_match_oracle(K, tunable, shape, kinds):
             _run_case(K, *case, kinds[0], kinds[1], dtype, with_new)
 
 
+@pytest.mark.ab
 @pytest.mark.parametrize("case", [c for c in CASES if c[4] in (64, 128) and 3 <= c[1] // c[2] <= 16])
 def test_decode_attn_fused_default_shape_matches(K, tunable, case):
     """attn_fused = 1 with the shape picked by batch size (head_dim 64 included): same answers as the
@@ -340,6 +342,7 @@ def test_decode_attn_fused_default_shape_matches(K, tunable, case):
         _run_case(K, *case, kinds[0], kinds[1], "f16", True)
 
 
+@pytest.mark.ab
 @pytest.mark.parametrize("shape", FUSED_SHAPES)
 def test_decode_attn_fused_workspace_reuse(K, tunable, shape):
     """The arrival words of the fused launch are never zeroed by anyone: a workspace full of garbage
@@ -386,7 +389,7 @@ def test_decode_attn_fused_workspace_reuse(K, tunable, shape):
         assert (np.abs(got - ref) <= TOL["f16"] * (np.abs(ref) + np.abs(ref).max())).all(), (si, T)
 
 
-@pytest.mark.parametrize("tc", [64, 32])
+@pytest.mark.parametrize("tc", [64, pytest.param(32, marks=pytest.mark.ab)])
 @pytest.mark.parametrize("tpw", [1, 2, 3, 5])
 def test_decode_attn_streaming_kernel_matches_oracle(K, tunable, tc, tpw):
     """decode_attn_stream_mfma_k (one wave walks `tpw` tiles with the next tile's rows in flight, online
@@ -394,7 +397,8 @@ def test_decode_attn_streaming_kernel_matches_oracle(K, tunable, tc, tpw):
     ragged last tile, a last wave with fewer tiles, one-tile contexts, V scales that grow and shrink across
     tiles (the running reference scale), every kind pair, fp16 and bf16."""
     tunable("attn_stream_tpw", tpw)
-    tunable("attn_stream_tc", tc)
+    if tc != 64:
+        tunable("attn_stream_tc", tc)
     for case in [(1, 32, 8, 1000, 128), (2, 6, 2, 200, 128), (1, 16, 1, 300, 128), (1, 32, 8, 5000, 128), (3, 8, 2, 1, 128),
                  (1, 8, 2, 513, 128), (2, 32, 8, 2048, 128), (1, 8, 2, 64, 128), (1, 8, 2, 129, 128)]:
         for kinds in (("int8", "int4"), ("int4", "int8"), ("int8", "int8"), ("int4", "int4")):
@@ -422,12 +426,13 @@ def test_decode_attn_streaming_kernel_matches_oracle(K, tunable, tc, tpw):
     assert (np.abs(got - ref) <= TOL["f16"] * (np.abs(ref) + np.abs(ref).max())).all()
 
 
-@pytest.mark.parametrize("fused", [0, 1])
+@pytest.mark.parametrize("fused", [0, pytest.param(1, marks=pytest.mark.ab)])
 @pytest.mark.parametrize("append", [False, True])
 def test_decode_step_layers_equals_per_layer_calls(K, tunable, append, fused):
     """kvq_decode_step_layers: L launches behind one host call == L separate kvq_decode_attn /
     kvq_decode_step calls, bit for bit (same kernels, same workspace), incl. the appended slot."""
-    tunable("attn_fused", fused)
+    if fused:
+        tunable("attn_fused", fused)
     L, B, Hq, Hkv, T, D = 3, 2, 16, 4, 777, 128
     g = torch.Generator(device="cuda").manual_seed(5)
     cap = T + 2
@@ -513,6 +518,7 @@ def test_decode_step_dev_reads_token_count_from_device(K, shape, kinds):
         K.decode_step_dev(plan, qt, kn, vn, t_dev.long(), bound, out, ws, sm)  # not int32
 
 
+@pytest.mark.ab
 @pytest.mark.parametrize("stream", [(-1, 64), (2, 64), (3, 32)])
 def test_decode_attn_int8_keys_through_int8_mfma(K, tunable, stream):
     """attn_k_i8: INT8 keys go into v_mfma_i32_16x16x64_i8 as stored (no byte -> f16 conversion), the query as two
@@ -530,6 +536,7 @@ def test_decode_attn_int8_keys_through_int8_mfma(K, tunable, stream):
     _run_case(K, 1, 8, 2, 900, 128, "int8", "int4", "f16", True, q_scale=1e-3)
 
 
+@pytest.mark.ab
 @pytest.mark.parametrize("case", [(1, 32, 8, 16384, 128), (8, 32, 8, 4100, 128), (1, 12, 12, 300, 64), (1, 4, 4, 200, 256),
                                   (2, 6, 2, 130, 32), (3, 4, 2, 1, 64), (1, 32, 8, 32768, 128), (1, 32, 8, 700, 64),
                                   (16, 8, 8, 300, 128)])  # last: a new token too large for the register-resident quantise
@@ -628,6 +635,7 @@ def test_decode_attn_full_size_against_float64_attention_on_the_device(K, shape,
     assert bool(((got - ref).abs() <= bound).all()), float(((got - ref).abs() / bound).max())
 
 
+@pytest.mark.ab
 @pytest.mark.parametrize("tpw", [1, 2, 3, 8])
 @pytest.mark.parametrize("ki8", [0, 1])
 def test_streaming_kernel_rolling_requests_equal_whole_tile_requests(K, tunable, tpw, ki8):

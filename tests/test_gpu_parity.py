@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from oracle import kvq_oracle as O
-from tests.util import TD, bits, odt, seeded_kv, to_numpy, to_torch
+from tests.util import TD, bits, odt, seeded_kv, to_numpy, to_torch, tunables
 
 pytestmark = pytest.mark.gpu
 
@@ -136,34 +136,21 @@ CASES = [  # (G, B, H, T, D)
 ]
 
 
-DEFAULT_TPW = None  # the library's shipped tiles-per-wave, read once (tests restore it after A-B settings)
-
-
-def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3, direct_stores=False, block=256, nv=8, tpw=0):
-    from efficient_llm_inference_amd import _lib, kernels
-    global DEFAULT_TPW
-    if DEFAULT_TPW is None:
-        DEFAULT_TPW = _lib.get_tunable("quant_tpw")
+def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3, direct_stores=False, block=64, tile=1, **ab):
+    """quantise through the C ABI into a window of a larger store. Test knobs (every build): force_two_pass,
+    direct_stores, block (64 | 256: the one-wave or the 256-thread general kernel), tile (1 = the compile-time tile
+    kernel where the shape has one). **ab: A-B keys (quant_nv, quant_tpw, ...; `pytest -m ab` only)."""
+    from efficient_llm_inference_amd import kernels
     G, B, H, T, D = x_np.shape
     x = to_torch(x_np, dtype)
     Dq = kernels.packed_dim(kind, D)
     store = torch.zeros(G, B, H, T + tcap_pad, Dq, dtype=kernels.QDTYPE[kind], device="cuda")
     scales = torch.zeros(G, T + tcap_pad, dtype=torch.float32, device="cuda")
     ws = torch.empty(G * T + 8, dtype=torch.float32, device="cuda")
-    _lib.set_tunable("quant_force_two_pass", int(force_two_pass))
-    _lib.set_tunable("quant_direct_stores", int(direct_stores))
-    _lib.set_tunable("quant_block", int(block))
-    _lib.set_tunable("quant_nv", int(nv))
-    _lib.set_tunable("quant_tpw", int(tpw))
-    try:
+    with tunables(quant_force_two_pass=int(force_two_pass), quant_direct_stores=int(direct_stores), quant_block=int(block),
+                  quant_tile=int(tile), **ab):
         src = [x[g] for g in range(G)] if as_list else x
         kernels.quant_tokens(src, store[:, :, :, 1:T + 1], scales[:, 1:T + 1], ws, kind)
-    finally:
-        _lib.set_tunable("quant_force_two_pass", 0)
-        _lib.set_tunable("quant_direct_stores", 0)
-        _lib.set_tunable("quant_block", 64)
-        _lib.set_tunable("quant_nv", 8)
-        _lib.set_tunable("quant_tpw", DEFAULT_TPW)
     torch.cuda.synchronize()
     # the window [1, T+1) was written; the guard tokens around it must be untouched
     assert int(store[:, :, :, 0].to(torch.int32).abs().sum()) == 0 and int(store[:, :, :, T + 1:].to(torch.int32).abs().sum()) == 0
@@ -171,6 +158,7 @@ def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3
     return store, scales
 
 
+@pytest.mark.ab
 @pytest.mark.parametrize("case", [(4, 1, 8, 300, 128), (2, 1, 8, 64, 128), (1, 1, 8, 1031, 128), (3, 2, 4, 37, 128), (2, 1, 8, 40, 64)])
 @pytest.mark.parametrize("tpw", [0, 2, 4, 8])
 @pytest.mark.parametrize("kind", ["int8", "int4"])
@@ -183,7 +171,7 @@ def test_quant_pipelined_one_wave_tiles(E, case, tpw, kind):
     for dtype, dist, as_list in (("f16", "normal", False), ("f16", "heavy", True), ("bf16", "heavy", False), ("f16", "tiny", True)):
         x_np = seeded_kv(case, dtype, seed=zlib.crc32(repr((case, dtype, kind, dist, "pipe")).encode()), dist=dist)
         q_ref, _, s32_ref = O.quantize_tokens(x_np, kind, dtype=odt(dtype))
-        store, scales = _quant_via_kernels(E, x_np, dtype, kind, False, as_list, block=64, tpw=tpw)
+        store, scales = _quant_via_kernels(E, x_np, dtype, kind, False, as_list, block=64, tile=0, quant_tpw=tpw)
         assert np.array_equal(to_numpy(store[:, :, :, 1:T + 1]), q_ref), (dtype, dist, tpw)
         assert np.array_equal(bits(scales[:, 1:T + 1]), bits(s32_ref)), (dtype, dist, tpw)
 
@@ -194,15 +182,17 @@ def test_quant_pipelined_one_wave_tiles(E, case, tpw, kind):
 def test_oracle_quant_dequant_tokens(E, case, dtype, kind):
     from efficient_llm_inference_amd import kernels
     G, B, H, T, D = case
-    for dist, two_pass, as_list, direct, block, nv in (
-            ("normal", False, False, False, 256, 8), ("heavy", True, True, False, 256, 8), ("tiny", False, True, False, 256, 8),
-            ("heavy", False, False, True, 256, 8), ("heavy", False, True, False, 64, 8), ("normal", False, False, False, 128, 8),
-            ("heavy", False, False, False, 64, 4), ("normal", False, True, False, 64, 16)):
+    # every SHIPPED path a shape can take: the compile-time tile kernel (where the shape has one), the general one-wave
+    # kernel, the 256-thread kernel with and without LDS-staged stores, the generic two-pass pair
+    for dist, two_pass, as_list, direct, block, tile in (
+            ("normal", False, False, False, 256, 0), ("heavy", True, True, False, 256, 0), ("tiny", False, True, False, 256, 0),
+            ("heavy", False, False, True, 256, 0), ("heavy", False, True, False, 64, 0), ("heavy", False, False, False, 64, 1),
+            ("tiny", False, True, False, 64, 1)):
         x_np = seeded_kv(case, dtype, seed=zlib.crc32(repr((case, dtype, kind, dist)).encode()), dist=dist)
         q_ref, stored_ref, s32_ref = O.quantize_tokens(x_np, kind, dtype=odt(dtype))
-        store, scales = _quant_via_kernels(E, x_np, dtype, kind, two_pass, as_list, direct_stores=direct, block=block, nv=nv)
-        assert np.array_equal(to_numpy(store[:, :, :, 1:T + 1]), q_ref), (dist, two_pass)
-        assert np.array_equal(bits(scales[:, 1:T + 1]), bits(s32_ref)), (dist, two_pass)
+        store, scales = _quant_via_kernels(E, x_np, dtype, kind, two_pass, as_list, direct_stores=direct, block=block, tile=tile)
+        assert np.array_equal(to_numpy(store[:, :, :, 1:T + 1]), q_ref), (dist, two_pass, block, tile)
+        assert np.array_equal(bits(scales[:, 1:T + 1]), bits(s32_ref)), (dist, two_pass, block, tile)
         for od in DTYPES:
             out = torch.zeros(G, B, H, T + 2, D, dtype=TD[od], device="cuda")  # strided output window
             kernels.dequant_tokens(store[:, :, :, 1:T + 1], scales[:, 1:T + 1], out[:, :, :, :T], kind)
@@ -211,6 +201,30 @@ def test_oracle_quant_dequant_tokens(E, case, dtype, kind):
             assert float(out[:, :, :, T:].float().abs().sum()) == 0.0
 
 
+@pytest.mark.ab
+@pytest.mark.parametrize("case", [(4, 1, 8, 300, 128), (3, 1, 12, 129, 64), (2, 1, 16, 64, 64), (2, 2, 4, 33, 32), (2, 8, 8, 5, 128)])
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind", ["int8", "int4"])
+def test_quant_ab_tile_sizes_and_instantiations(E, case, dtype, kind):
+    """A-B library only: 128-thread tiles, 2048- / 8192-element one-wave tiles, round 2's GEO128 instantiation with its
+    non-temporal on / off variants, the half-wave row runs of the tile kernel at head_dim 64 — all bit-exact."""
+    G, B, H, T, D = case
+    for dist, as_list, block, ab in (("normal", False, 128, {}), ("heavy", False, 64, {"quant_nv": 4}), ("normal", True, 64, {"quant_nv": 16}),
+                                     ("heavy", False, 64, {"quant_geo128": 1}), ("heavy", True, 64, {"quant_geo128": 1, "nt_loads": 0}),
+                                     ("tiny", False, 64, {"quant_geo128": 1, "quant_nt_stores": 0}), ("heavy", False, 64, {"quant_no_regmax": 1})):
+        x_np = seeded_kv(case, dtype, seed=zlib.crc32(repr((case, dtype, kind, dist, "ab")).encode()), dist=dist)
+        q_ref, _, s32_ref = O.quantize_tokens(x_np, kind, dtype=odt(dtype))
+        store, scales = _quant_via_kernels(E, x_np, dtype, kind, False, as_list, block=block, tile=0, **ab)
+        assert np.array_equal(to_numpy(store[:, :, :, 1:T + 1]), q_ref), (dist, block, ab)
+        assert np.array_equal(bits(scales[:, 1:T + 1]), bits(s32_ref)), (dist, block, ab)
+    if D == 64 and dtype != "f32":
+        x_np = seeded_kv(case, dtype, seed=5, dist="heavy")
+        q_ref, _, s32_ref = O.quantize_tokens(x_np, kind, dtype=odt(dtype))
+        store, scales = _quant_via_kernels(E, x_np, dtype, kind, False, False, tile=1, quant_tile_tt=4)
+        assert np.array_equal(to_numpy(store[:, :, :, 1:T + 1]), q_ref) and np.array_equal(bits(scales[:, 1:T + 1]), bits(s32_ref))
+
+
+@pytest.mark.ab
 @pytest.mark.parametrize("kind", ["int8", "int4"])
 @pytest.mark.parametrize("od", DTYPES)
 def test_dequant_all_variants_bit_exact(E, kind, od):
@@ -445,6 +459,7 @@ def test_golden_cache_bf16_kv_fp16_compute(E, cname, mode):
     assert qc.estimated_bytes() == int(g[f"{cname}.{mode}.bytes"][0])
 
 
+@pytest.mark.ab
 @pytest.mark.parametrize("k", [2, 4, 8, 16])
 def test_xcd_grouped_item_order_is_a_permutation(E, k):
     """dequant_xcd_group / quant_xcd_group only re-order which workgroup takes which chunk / tile
@@ -459,7 +474,7 @@ def test_xcd_grouped_item_order_is_a_permutation(E, k):
             _lib.set_tunable("quant_xcd_group", k)
             _lib.set_tunable("dequant_xcd_group", k)
             try:
-                store, scales = _quant_via_kernels(E, x_np, "f16", kind, False, False, block=64)
+                store, scales = _quant_via_kernels(E, x_np, "f16", kind, False, False, block=64, tile=0)
                 assert np.array_equal(to_numpy(store[:, :, :, 1:T + 1]), q_ref) and np.array_equal(bits(scales[:, 1:T + 1]), bits(s32_ref))
                 q = to_torch(q_ref)
                 sc = to_torch(s32_ref)

@@ -42,14 +42,29 @@ def evict_asm(tmp_path_factory):
     return _asm(tmp_path_factory, "kvq_evict")
 
 
-@pytest.mark.parametrize("bits,nt_store", [(4, True), (8, True)])
-def test_shipped_quantise_tile_issues_non_temporal_loads(quant_asm, bits, nt_store):
-    # quant_tokens_fused_k<f16, BITS, ROWU, LDS_OUT, FULL, 64, REGMAX = 1, NV = 8, GEO128, NTL = true, NTS = true>
-    body = _kernel_body(quant_asm, r"_ZN3kvq20quant_tokens_fused_kILi0ELi%dELb1ELb1ELb1ELi64ELi1ELi8ELb1ELb1ELb%dEEEvNS_9QuantArgsE" % (bits, int(nt_store)))
-    loads = re.findall(r"global_load_dwordx4[^\n]*", body)
-    assert len(loads) == 8 and all(l.rstrip().endswith(" nt") for l in loads), loads
-    stores = re.findall(r"global_store_dwordx4[^\n]*", body)
-    assert stores and all(s.rstrip().endswith(" nt") == nt_store for s in stores), stores
+@pytest.mark.parametrize("bits", [4, 8])
+@pytest.mark.parametrize("geo", [(8, 16, 4), (8, 8, 8), (12, 8, 8), (16, 8, 8)])  # R rows, D/8, tokens per tile
+def test_shipped_quantise_tile_issues_non_temporal_accesses(quant_asm, bits, geo):
+    # quant_tile_k<f16, BITS, R, DV, TT, PHASE = 0>: R buffer loads of 16 B per lane, every one non-temporal; every
+    # LDS-staged 16-byte output store non-temporal (the 4-byte scale store is a plain global store)
+    r, dv, tt = geo
+    body = _kernel_body(quant_asm, r"_ZN3kvq12quant_tile_kILi0ELi%dELi%dELi%dELi%dELi0EEEvNS_13QuantTileArgsE" % (bits, r, dv, tt))
+    loads = re.findall(r"buffer_load_dwordx4[^\n]*", body)
+    assert len(loads) == r and all(l.rstrip().endswith(" nt") for l in loads), loads
+    stores = re.findall(r"buffer_store_dwordx4[^\n]*", body)
+    assert len(stores) == (r * tt * dv * bits + 1023) // 1024 and all(s.rstrip().endswith(" nt") for s in stores), stores
+
+
+def test_split_phase_tiles_keep_phase_one_rows_cacheable(quant_asm):
+    # the abs-max phase of a batch-sharded slice reads with PLAIN loads (its rows are re-read by the quantise phase from
+    # the Infinity Cache), the quantise phase with non-temporal ones (last use)
+    p1 = _kernel_body(quant_asm, r"_ZN3kvq12quant_tile_kILi0ELi8ELi8ELi16ELi4ELi1EEEvNS_13QuantTileArgsE")
+    p2 = _kernel_body(quant_asm, r"_ZN3kvq12quant_tile_kILi0ELi4ELi8ELi16ELi4ELi2EEEvNS_13QuantTileArgsE")
+    l1 = re.findall(r"buffer_load_dwordx4[^\n]*", p1)
+    l2 = re.findall(r"buffer_load_dwordx4[^\n]*", p2)
+    assert len(l1) == 8 and not any(l.rstrip().endswith(" nt") for l in l1), l1
+    assert len(l2) == 8 and all(l.rstrip().endswith(" nt") for l in l2), l2
+    assert not re.findall(r"buffer_store", p1) and re.findall(r"global_atomic_umax", p1)
 
 
 def test_pool_kernels_issue_non_temporal_loads(evict_asm):
@@ -57,11 +72,9 @@ def test_pool_kernels_issue_non_temporal_loads(evict_asm):
     loads = re.findall(r"buffer_load_dwordx4[^\n]*", wave)
     assert len(loads) == 16 and all(l.rstrip().endswith(" nt") for l in loads), loads
     vec_nt = _kernel_body(evict_asm, r"_ZN3kvq16chunk_pool_vec_kILi0ELb1EEEvNS_8PoolArgsEj")
-    vec_plain = _kernel_body(evict_asm, r"_ZN3kvq16chunk_pool_vec_kILi0ELb0EEEvNS_8PoolArgsEj")
-    # the unrolled batch of 16 loads carries the hint in one instantiation and not in the other (the tail loop's single
-    # load is a plain one in both)
+    # the unrolled batch of 16 loads carries the hint (the tail loop's single load is a plain one; the plain-load
+    # instantiation exists in A-B builds only)
     assert len(re.findall(r"global_load_dwordx4[^\n]* nt\n", vec_nt + "\n")) >= 16
-    assert not re.findall(r"global_load_dwordx4[^\n]* nt\n", vec_plain + "\n")
 
 
 def test_shipped_dequantise_variants_store_non_temporally(tmp_path_factory):

@@ -89,7 +89,8 @@ def test_sharded_batch_scales_world_size_2_gloo():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [SHAPE, (2, 2, 8, 33, 128), (2, 3, 3, 7, 5), (1, 4, 2, 6, 24), (130, 1, 2, 3, 16)])
+@pytest.mark.parametrize("shape", [SHAPE, (2, 2, 8, 33, 128), (2, 3, 3, 7, 5), (1, 4, 2, 6, 24), (130, 1, 2, 3, 16),
+                                   (2, 3, 4, 21, 64), (3, 1, 5, 9, 128), (1, 9, 8, 4, 64)])  # one-wave tile phases: ragged row groups / tokens
 @pytest.mark.parametrize("dtype", ["f16", "bf16", "f32"])
 def test_split_phases_equal_fused_kernels(shape, dtype):
     """One rank: kvq_absmax_tokens + kvq_quant_tokens_from_absmax == the oracle == kvq_quant_*_tokens, bit for bit
@@ -157,6 +158,15 @@ def test_sharded_batch_two_processes_share_gpu():
 
 
 def _rccl_worker(port, q):
+    try:
+        _rccl_worker_body(port, q)
+    except BaseException as exc:  # noqa: BLE001 - the parent must not wait 10 minutes for a result that never comes
+        import traceback
+        q.put(("error", traceback.format_exc()[-1500:], [], {"exc": repr(exc)}))
+        raise
+
+
+def _rccl_worker_body(port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     from efficient_llm_inference_amd import sharding
@@ -166,7 +176,20 @@ def _rccl_worker(port, q):
     t = torch.full((4,), 3.0, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=sharding._STATE["group"])
     sharding.barrier()
-    q.put((backend, sharding.backend(), t.cpu().tolist()))
+    # the layer-chunked quantise with its all_reduce(MAX) over RCCL on the side stream (forced: one rank): 5 chunks of
+    # one layer each, pipelined abs-max / reduce / quantise, reused buffers, two steps
+    ok = {}
+    x = _batch("f16", (5, 5, 8, 70, 128))
+    xt = to_torch(x, "f16")
+    for kind in ("int8", "int4"):
+        bufs = sharding.ShardedQuantBuffers(xt, kind, chunk_bytes=1, force_overlap=True)
+        for _ in range(2):
+            qq, sc = sharding.quantize_tokens_batch_sharded(xt, kind, out=bufs)
+        torch.cuda.synchronize()
+        q_ref, _, s32_ref = O.quantize_tokens(x, kind, dtype=odt("f16"))
+        ok[kind] = bool(bufs.overlap and bufs.n_chunks == 5 and np.array_equal(to_numpy(qq), q_ref)
+                        and np.array_equal(to_numpy(sc).view(np.uint32), s32_ref.view(np.uint32)))
+    q.put((backend, sharding.backend(), t.cpu().tolist(), ok))
     sharding.shutdown()
 
 
@@ -178,6 +201,8 @@ def test_rccl_group_comes_up_on_one_rank():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
     p.start()
-    backend, reported, vals = q.get(timeout=600)
+    backend, reported, vals, chunked = q.get(timeout=300)
+    assert backend != "error", reported
     p.join(timeout=120)
     assert p.exitcode == 0 and backend == reported == "nccl" and vals == [3.0] * 4
+    assert chunked == {"int8": True, "int4": True}, chunked
