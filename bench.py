@@ -530,20 +530,24 @@ def measure_shape(name, dev, rank, iters=24):
     rec = {"shape_LBHTD": [L, B, H, T, D], "config_mode": mode, "rotating_sets": n_rot, "rows_x_head_dim": f"{B * H} x {D}",
            "working_set_mb": round(n_rot * n_elts * (2 + 2 + 1.5) / 2**20, 1)}
     for kind in ("int8", "int4"):
+        # the quantised stores are small (50 MB per INT4 set at config 3): rotate enough of them that the kernel's READ
+        # side alone exceeds the 256 MiB Infinity Cache more than twice over (the fp16 side rotates n_rot buffers)
+        store_bytes = n_elts * (1.0 if kind == "int8" else 0.5)
+        n_st = max(n_rot, -(-(640 << 20) // int(store_bytes)))
         stores = []
-        for i in range(n_rot):
+        for i in range(n_st):
             st = _KVStore(kind, L, dev)
             st.reserve(T)
-            st.append(xs[i])
+            st.append(xs[i % n_rot])
             stores.append(st)
         ws = stores[0]._workspace(L * T)
         k_q = _kernels_of(lambda: K.quant_tokens(xs[0], stores[0].q[:, :, :, :T], stores[0].scales[:, :T], ws, kind))
         k_d = _kernels_of(lambda: stores[0].dequant(torch.float16, out=outs[0]))
-        q_ms = _time_launches(lambda i: K.quant_tokens(xs[i % n_rot], stores[i % n_rot].q[:, :, :, :T], stores[i % n_rot].scales[:, :T], ws, kind), iters)
-        d_ms = _time_launches(lambda i: stores[i % n_rot].dequant(torch.float16, out=outs[(i + 1) % n_rot]), iters)
+        q_ms = _time_launches(lambda i: K.quant_tokens(xs[i % n_rot], stores[i % n_st].q[:, :, :, :T], stores[i % n_st].scales[:, :T], ws, kind), iters)
+        d_ms = _time_launches(lambda i: stores[i % n_st].dequant(torch.float16, out=outs[i % n_rot]), iters)
         nbytes = n_elts * BYTES_PER_ELT[kind]
-        rec[f"dequant_{kind}"] = _roofline(k_d, nbytes, d_ms, _DISPATCH_TIMER)
-        rec[f"quant_{kind}"] = _roofline(k_q, nbytes, q_ms, _DISPATCH_TIMER)
+        rec[f"dequant_{kind}"] = _roofline(k_d, nbytes, d_ms, _DISPATCH_TIMER, rotating_stores=n_st)
+        rec[f"quant_{kind}"] = _roofline(k_q, nbytes, q_ms, _DISPATCH_TIMER, rotating_stores=n_st)
         del stores
     vk = MODE_KINDS[mode][1]
     rec["roofline"] = rec[f"dequant_{vk}"]            # the config's own kind (V set)

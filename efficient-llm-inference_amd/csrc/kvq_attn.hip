@@ -69,6 +69,7 @@ struct AttnArgs {
   int32_t dtype;      // KVQ_F16 | KVQ_BF16 (q, k_new, v_new, out)
   int32_t mfma;       // host: the MFMA partial kernel serves this call
   uint32_t stream_tpw;  // host: > 0 = the streaming MFMA kernel, that many 64-token tiles per wave
+  uint32_t lds;         // host: 1 = the LDS-staged streaming kernel (decode_attn_lds_mfma_k) serves the streaming plan
   // kvq_decode_step_dev: the stored-token count lives in DEVICE memory (a captured HIP graph replays
   // the same launch for every decode step). T above is then the host's upper bound: it sizes the grid and
   // the workspace; workgroups past the real count exit, the merge reads ceil(T / TS) partials.
@@ -202,10 +203,33 @@ __device__ inline float group_fadd(float v, int logw) {
   return v;
 }
 
+// Exchanges across the four 16-lane rows of a wave WITHOUT the LDS crossbar (__shfl_xor is ds_bpermute: an LDS round
+// trip on the wave's critical path): v_permlane16_swap / v_permlane32_swap of a value with a copy of itself leave
+// {own, partner} in the two results for the partner 16 (32) lanes away; max and + are commutative, so every lane
+// computes the same bits a __shfl_xor butterfly would.
+__device__ inline float xor16_max(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ inline float xor32_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ inline float xor16_add(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ inline float xor32_add(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// max over the wave, in every lane: DPP butterflies inside a 16-lane row, lane swaps across the rows
 __device__ inline float wave_fmax(float v) {
-#pragma unroll
-  for (int s = 32; s > 0; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
-  return v;
+  v = fmaxf(v, __uint_as_float(dpp_u32_attn<0xB1>(__float_as_uint(v))));   // lane ^ 1
+  v = fmaxf(v, __uint_as_float(dpp_u32_attn<0x4E>(__float_as_uint(v))));   // lane ^ 2
+  v = fmaxf(v, __uint_as_float(dpp_u32_attn<0x141>(__float_as_uint(v))));  // row_half_mirror
+  v = fmaxf(v, __uint_as_float(dpp_u32_attn<0x140>(__float_as_uint(v))));  // row_mirror
+  return xor32_max(xor16_max(v));
 }
 __device__ inline float wave_fsum(float v) {
 #pragma unroll
@@ -680,8 +704,7 @@ struct AttnTile {
       float qm = 0.0f;
 #pragma unroll
       for (int j = 0; j < 4 * KS; ++j) qm = fmaxf(qm, absmax_h2(w[j]));
-      qm = fmaxf(qm, __shfl_xor(qm, 16));
-      qm = fmaxf(qm, __shfl_xor(qm, 32));
+      qm = xor32_max(xor16_max(qm));
       aq = qm > 0.0f ? qm / 127.0f : 1.0f;
       const float inv = qm > 0.0f ? 127.0f / qm : 0.0f;
 #pragma unroll
@@ -754,8 +777,7 @@ struct AttnTile {
       m = fmaxf(m, sc[i][r]);
     }
   }
-  m = fmaxf(m, __shfl_xor(m, 16));
-  m = fmaxf(m, __shfl_xor(m, 32));
+  m = xor32_max(xor16_max(m));
   l = 0.0f;
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
@@ -767,8 +789,7 @@ struct AttnTile {
       sc[i][r] = p * sv[r];
     }
   }
-  l += __shfl_xor(l, 16);
-  l += __shfl_xor(l, 32);
+  l = xor32_add(xor16_add(l));
 
   // ---- O = P V: column x <-> d = DVN x + e(c) for MFMA c ---------------------------------------------
 #pragma unroll
@@ -940,8 +961,7 @@ struct AttnStream {
       float qm = 0.0f;
 #pragma unroll
       for (int j = 0; j < 4 * KS; ++j) qm = fmaxf(qm, absmax_h2(w[j]));
-      qm = fmaxf(qm, __shfl_xor(qm, 16));
-      qm = fmaxf(qm, __shfl_xor(qm, 32));
+      qm = xor32_max(xor16_max(qm));
       aq = qm > 0.0f ? qm / 127.0f : 1.0f;
       const float inv = qm > 0.0f ? 127.0f / qm : 0.0f;
 #pragma unroll
@@ -1129,8 +1149,7 @@ struct AttnStream {
         mt = fmaxf(mt, sc[i][q]);
       }
     }
-    mt = fmaxf(mt, __shfl_xor(mt, 16));
-    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    mt = xor32_max(xor16_max(mt));
     const float mnew = fmaxf(m, mt);                          // finite: every tile holds >= 1 token
     const float alpha = __builtin_amdgcn_exp2f(m - mnew);     // first tile: 2^(-inf) = 0
     float lt = 0.0f;
@@ -1144,8 +1163,7 @@ struct AttnStream {
         sc[i][q] = p * sv[q];
       }
     }
-    lt += __shfl_xor(lt, 16);
-    lt += __shfl_xor(lt, 32);
+    lt = xor32_add(xor16_add(lt));
     l = l * alpha + lt;
     m = mnew;
     // the accumulator rows of this lane are heads 4 g + q: their alpha lives in lanes x = 4 g + q
@@ -1270,6 +1288,292 @@ __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_stream_mf
     }
   }
 }
+
+// ---------------------------------------------------------------------------- LDS-staged streaming variant
+// The streaming kernel above asks HBM for its rows in MFMA-operand shape: a K load instruction touches sixteen rows,
+// 64 B of each (lane (x, g): 16 B at row x, byte 16 g), a V load four rows — half-line and sub-line pieces whose
+// address processing (TA) and DRAM efficiency cap the loads-only build of that kernel at 5.6 TB/s where contiguous
+// reads reach 7.0 (profiles/r02ab, r02ae). Here a 64-token tile — one CONTIGUOUS run of the store for a (batch row,
+// kv head): 8 KiB of INT8 keys, 4 KiB of INT4 values — travels as whole 1 KiB wave requests straight into LDS
+// (`buffer_load_dwordx4 ... lds`: LDS-DMA, no VGPRs, range-checked by the descriptor like every row load in this file),
+// NB - 1 tiles ahead of the one being reduced in a ring of NB LDS slots, and the MFMA operand fragments are read from
+// LDS in exactly the register layout AttnStream::consume already takes (same arithmetic, same operand order: results
+// are bit-identical to the streaming kernel's). In flight per wave: (NB - 1) x 12.5 KiB held by LDS instead of
+// registers; the K image is XOR-swizzled on the SOURCE address (LDS-DMA writes lane-linear) so that the ds_read_b128
+// fragment reads are bank-conflict free: slot s of row r holds 16-byte chunk s ^ f(r),
+//   INT8 keys (8 chunks per row): f(r) = (r >> 1) & 7        INT4 keys (4 chunks per row): f(r) = r & 8 ? 3 : 0
+// (derivation: the four 16-lane groups of ds_read_b128, MI355X_MICROARCH.md LDS table). The V rows are read as the
+// streaming kernel reads them from memory (4 or 8 bytes per lane; rows r and r + 4 share a bank half: 2-way, on an
+// LDS that is far from busy). Completion: every request of a tile is an LDS-DMA, so `s_waitcnt vmcnt(OPS x (NB-1))`
+// is "tile k has landed" (loads retire in order); tiles past the wave's last are requested with an empty descriptor
+// (nothing is read) so that the count is the same in every iteration.
+template <int KBITS>
+__device__ inline uint32_t k_swizzle(uint32_t row) {
+  if constexpr (KBITS == 8) return (row >> 1) & 7u;
+  else return (row & 8u) ? 3u : 0u;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {  // s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields at their maxima)
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+}
+
+// MFMA operand fragments of one tile out of its LDS image (K rows swizzled as k_swizzle says, V rows plain), in
+// AttnStream::Raw's register layout: lane (x, g) takes the 16 K bytes of row 16 i + x at chunk 4 c + g, and the V bytes
+// of its eight token rows per 32-token step.
+template <int KBITS, int VBITS, int TC, bool KI8>
+__device__ __forceinline__ void read_fragments(const uint8_t* img, typename AttnStream<KBITS, VBITS, TC, 128, KI8, false>::Raw& r) {
+  typedef AttnStream<KBITS, VBITS, TC, 128, KI8, false> ST;
+  constexpr int NT = ST::NT, NS = ST::NS, NL = ST::NL, VB = ST::VB;
+  constexpr int KROW = 128 * KBITS / 8, VROW = 128 * VBITS / 8;
+  const uint32_t lane = threadIdx.x & 63u, x = lane & 15u, g = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const uint32_t row = 16u * i + x;
+#pragma unroll
+    for (int c = 0; c < NL; ++c) {
+      const u32x4 w = *reinterpret_cast<const u32x4*>(img + row * KROW + (((4u * c + g) ^ k_swizzle<KBITS>(row)) << 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r.k[i][c][j] = w[j];
+    }
+  }
+  const uint8_t* vimg = img + TC * KROW;
+#pragma unroll
+  for (int sidx = 0; sidx < NS; ++sidx) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t row = 32u * sidx + 16u * (j >> 2) + (j & 3) + 4u * g;
+      if constexpr (VB == 8) {
+        const u32x2 w = *reinterpret_cast<const u32x2*>(vimg + row * VROW + 8u * x);
+        r.v[sidx][j][0] = w[0];
+        r.v[sidx][j][VB == 8 ? 1 : 0] = w[1];
+      } else {
+        r.v[sidx][j][0] = *reinterpret_cast<const uint32_t*>(vimg + row * VROW + 4u * x);
+      }
+    }
+  }
+}
+
+template <int KBITS, int VBITS, int TC, bool KI8, int NB>
+__global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_lds_mfma_k(const AttnArgs a, const uint32_t tpw) {
+  constexpr int HD = 128;
+  typedef AttnStream<KBITS, VBITS, TC, HD, KI8, false> ST;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  constexpr int DVN = ST::DVN;
+  static_assert(ST::CBK == 16, "head_dim 128 rows: 16-byte K fragments");
+  constexpr int KROW = HD * KBITS / 8, VROW = HD * VBITS / 8;   // stored bytes per token row
+  constexpr int KCPR = KROW / 16, VCPR = VROW / 16;              // 16-byte chunks per row
+  constexpr int KOPS = TC * KROW / 1024, VOPS = TC * VROW / 1024;  // 1 KiB wave requests per tile
+  constexpr int OPS = KOPS + VOPS + 2;                           // + the two scale rows
+  constexpr int SLOT = TC * (KROW + VROW) + 512;                 // K image, V image, 64 + 64 scale floats
+  static_assert(OPS * (NB - 1) < 64, "the ring's requests must fit the vmcnt counter");
+  extern __shared__ __attribute__((aligned(16))) uint8_t ring[];  // NB slots
+  __shared__ __attribute__((aligned(16))) float s_ks[TC];
+  __shared__ __attribute__((aligned(16))) float s_vs[TC];
+  __shared__ __attribute__((aligned(16))) float s_al[16];
+  const uint32_t lane = threadIdx.x, x = lane & 15u, g = lane >> 4;
+  const uint32_t split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  const uint32_t ntiles = (a.T + (uint32_t)TC - 1u) / (uint32_t)TC;
+  const uint32_t first = split * tpw;
+  const uint32_t last = first + tpw < ntiles ? first + tpw : ntiles;  // host: first < ntiles for every split
+  const uint32_t n = last - first;
+  const uint8_t* k_row0 = a.k + (int64_t)b * a.k_sb + (int64_t)hk * a.k_sh;
+  const uint8_t* v_row0 = a.v + (int64_t)b * a.v_sb + (int64_t)hk * a.v_sh;
+
+  // per-lane source offsets of the K requests: request j covers rows (1024 / KROW) j ..., lane l = slot l % KCPR of row
+  // l / KCPR; it fetches chunk slot ^ f(row). f depends on j only through its parity (INT8) or not at all (INT4).
+  uint32_t k_off[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const uint32_t row = (uint32_t)par * (1024u / KROW) + lane / KCPR;
+    k_off[par] = (lane / KCPR) * (uint32_t)a.k_st + (((lane % KCPR) ^ k_swizzle<KBITS>(row)) << 4);
+  }
+  const uint32_t v_off = (lane / VCPR) * (uint32_t)a.v_st + ((lane % VCPR) << 4);
+
+  auto request = [&](const uint32_t k) {  // tile k of this wave -> ring slot k % NB; nothing waits here
+    const uint32_t tt = first + (k < n ? k : 0u);
+    const uint32_t t0 = tt * (uint32_t)TC;
+    const uint32_t cnt = k < n ? (a.T - t0 < (uint32_t)TC ? a.T - t0 : (uint32_t)TC) : 0u;  // 0: empty descriptors, no traffic
+    uint8_t* slot = ring + (k % NB) * SLOT;
+    const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(k_row0 + (int64_t)t0 * a.k_st), 0, (int)(cnt * (uint32_t)a.k_st), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(v_row0 + (int64_t)t0 * a.v_st), 0, (int)(cnt * (uint32_t)a.v_st), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ksr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.k_scale + t0), 0, (int)(cnt * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.v_scale + t0), 0, (int)(cnt * 4u), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < KOPS; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(kr, (lds_ptr)(slot + 1024 * j), 16, k_off[j & 1], (uint32_t)(j * (1024 / KROW)) * (uint32_t)a.k_st, 0, KVQ_ATTN_KV_AUX);
+#pragma unroll
+    for (int j = 0; j < VOPS; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(vr, (lds_ptr)(slot + TC * KROW + 1024 * j), 16, v_off, (uint32_t)(j * (1024 / VROW)) * (uint32_t)a.v_st, 0, KVQ_ATTN_KV_AUX);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ksr, (lds_ptr)(slot + TC * (KROW + VROW)), 4, lane * 4u, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(vsr, (lds_ptr)(slot + TC * (KROW + VROW) + 256), 4, lane * 4u, 0, 0, 0);
+  };
+
+  ST st;
+#pragma unroll
+  for (int k = 0; k < NB - 1; ++k) request((uint32_t)k);
+  st.init(a, b, hk);
+  typename ST::Raw r;
+  const typename ST::Src none = st.src(a, b, hk, 0u, 0u);
+  for (uint32_t k = 0; k < n; ++k) {
+    // the slot tile k + NB - 1 goes to is the one tile k - 1 was read from: those reads have all been consumed
+    // (their values fed MFMAs of the previous iteration); the compiler is kept from moving anything across
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    request(k + (uint32_t)(NB - 1));
+    wait_vmcnt<OPS * (NB - 1)>();  // tile k has landed
+    asm volatile("" ::: "memory");
+    const uint32_t t0 = (first + k) * (uint32_t)TC;
+    const uint32_t nt = a.T - t0 < (uint32_t)TC ? a.T - t0 : (uint32_t)TC;
+    const uint8_t* slot = ring + (k % NB) * SLOT;
+    read_fragments<KBITS, VBITS, TC, KI8>(slot, r);
+    static_assert(TC <= kWave, "one scale per lane");
+    const float* sc = reinterpret_cast<const float*>(slot + TC * (KROW + VROW));
+    const float ksv = sc[lane < (uint32_t)TC ? lane : 0u], vsv = sc[64 + (lane < (uint32_t)TC ? lane : 0u)];
+    r.ks[0] = lane < nt ? ksv : 0.0f;  // rows past nt: the request's range check left the slot's old bytes there
+    r.vs[0] = lane < nt ? vsv : 0.0f;
+    st.consume(a, nt, r, none, s_ks, s_vs, s_al);
+  }
+  wait_vmcnt<0>();  // the empty tail requests retire before the wave's LDS is released
+  // ---- workspace: (m, l) per head, acc[heads][D] — the layout the merge kernels read ---------------------------
+  if (g == 0u && x < a.nq) {
+    float* o = a.ws + (((int64_t)b * a.Hq + hk * a.nq + x) * a.nsplit + split) * 2;
+    o[0] = st.m * 0.693147180559945309f;
+    o[1] = st.l;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t h = 4 * g + q;
+    if (h < a.nq) {
+      float o8[DVN];
+#pragma unroll
+      for (int c = 0; c < DVN; ++c) {
+        int e = c;
+        if constexpr (VBITS == 4) e = c < 4 ? 2 * c : 2 * (c - 4) + 1;
+        o8[e] = st.acc[c][q] * st.svref;
+      }
+      float* dst = a.ws + a.acc_off + (((int64_t)b * a.Hq + hk * a.nq + h) * a.nsplit + split) * a.D + DVN * x;
+#pragma unroll
+      for (int c = 0; c < DVN; c += 4) *reinterpret_cast<f32x4*>(dst + c) = f32x4{o8[c], o8[c + 1], o8[c + 2], o8[c + 3]};
+    }
+  }
+}
+
+#if KVQ_AB
+// ---------------------------------------------------------------------------- coalesced streaming variant
+// The same whole-line requests as the LDS-staged kernel, but into REGISTERS (a 1 KiB request per instruction, 16 B per
+// lane: `buffer_load_dwordx4`, a few cycles to issue where an LDS-DMA piece costs 60-185 on the issuing wave,
+// MI355X_MICROARCH.md latency table), and through ONE LDS image per wave on the way to the operand layout: when a tile
+// is due, its registers are written to the (swizzled) image with ds_write_b128, re-requested at once for the tile DEPTH
+// tiles ahead, and the fragments are read back as the LDS-staged kernel reads them. DEPTH register sets are in flight
+// while a tile is reduced (48 + 2 VGPRs each for INT8 keys + INT4 values).
+// Measured (batch 8, 16 K tokens, per layer call incl. merge; profiles/r03d_attn_lds_vs_coalesced.txt): 42.5-45.6 us
+// against 40.8 for the LDS-DMA ring and 44.7 for the fragment-shaped streaming kernel: A-B builds only.
+template <int KBITS, int VBITS, bool KI8, int DEPTH>
+__global__ __launch_bounds__(kWave, 2) void decode_attn_coal_mfma_k(const AttnArgs a, const uint32_t tpw) {
+  constexpr int HD = 128, TC = 64;
+  typedef AttnStream<KBITS, VBITS, TC, HD, KI8, false> ST;
+  constexpr int DVN = ST::DVN;
+  constexpr int KROW = HD * KBITS / 8, VROW = HD * VBITS / 8;
+  constexpr int KCPR = KROW / 16, VCPR = VROW / 16;
+  constexpr int KOPS = TC * KROW / 1024, VOPS = TC * VROW / 1024;
+  __shared__ __attribute__((aligned(16))) uint8_t img[TC * (KROW + VROW)];
+  __shared__ __attribute__((aligned(16))) float s_ks[TC];
+  __shared__ __attribute__((aligned(16))) float s_vs[TC];
+  __shared__ __attribute__((aligned(16))) float s_al[16];
+  const uint32_t lane = threadIdx.x, x = lane & 15u, g = lane >> 4;
+  const uint32_t split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  const uint32_t ntiles = (a.T + (uint32_t)TC - 1u) / (uint32_t)TC;
+  const uint32_t first = split * tpw;
+  const uint32_t last = first + tpw < ntiles ? first + tpw : ntiles;
+  const uint32_t n = last - first;
+  const uint8_t* k_row0 = a.k + (int64_t)b * a.k_sb + (int64_t)hk * a.k_sh;
+  const uint8_t* v_row0 = a.v + (int64_t)b * a.v_sb + (int64_t)hk * a.v_sh;
+  const uint32_t k_off = (lane / KCPR) * (uint32_t)a.k_st + ((lane % KCPR) << 4);
+  const uint32_t v_off = (lane / VCPR) * (uint32_t)a.v_st + ((lane % VCPR) << 4);
+  // where this lane's pieces go in the image: request j covers rows (1024 / KROW) j ...; slot = chunk ^ f(row)
+  uint32_t k_dst[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const uint32_t row = (uint32_t)par * (1024u / KROW) + lane / KCPR;
+    k_dst[par] = (lane / KCPR) * KROW + (((lane % KCPR) ^ k_swizzle<KBITS>(row)) << 4);
+  }
+  struct Flight {  // one tile as requested: whole lines, lane-linear
+    u32x4 k[KOPS], v[VOPS];
+    float ks, vs;
+  };
+  auto request = [&](const uint32_t k, Flight& f) {
+    const uint32_t tt = first + (k < n ? k : 0u);
+    const uint32_t t0 = tt * (uint32_t)TC;
+    const uint32_t cnt = k < n ? (a.T - t0 < (uint32_t)TC ? a.T - t0 : (uint32_t)TC) : 0u;  // 0: empty descriptors, no traffic
+    const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(k_row0 + (int64_t)t0 * a.k_st), 0, (int)(cnt * (uint32_t)a.k_st), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(v_row0 + (int64_t)t0 * a.v_st), 0, (int)(cnt * (uint32_t)a.v_st), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < KOPS; ++j) f.k[j] = __builtin_amdgcn_raw_buffer_load_b128(kr, k_off, (uint32_t)(j * (1024 / KROW)) * (uint32_t)a.k_st, KVQ_ATTN_KV_AUX);
+#pragma unroll
+    for (int j = 0; j < VOPS; ++j) f.v[j] = __builtin_amdgcn_raw_buffer_load_b128(vr, v_off, (uint32_t)(j * (1024 / VROW)) * (uint32_t)a.v_st, KVQ_ATTN_KV_AUX);
+    const uint32_t ic = lane < cnt ? lane : (cnt ? cnt - 1u : 0u);
+    f.ks = cnt ? a.k_scale[t0 + ic] : 0.0f;
+    f.vs = lane < cnt ? a.v_scale[t0 + ic] : 0.0f;
+  };
+  ST st;
+  Flight fl[DEPTH];
+#pragma unroll
+  for (int dpt = 0; dpt < DEPTH; ++dpt) request((uint32_t)dpt, fl[dpt]);
+  st.init(a, b, hk);
+  typename ST::Raw r;
+  const typename ST::Src none = st.src(a, b, hk, 0u, 0u);
+  auto step = [&](const uint32_t k, Flight& f) {
+    // the previous tile's fragment reads are complete (their values fed its MFMAs); keep the compiler from moving
+    // this tile's image writes above them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < KOPS; ++j) *reinterpret_cast<u32x4*>(img + (uint32_t)(j * 1024) + k_dst[j & 1]) = f.k[j];
+#pragma unroll
+    for (int j = 0; j < VOPS; ++j) *reinterpret_cast<u32x4*>(img + TC * KROW + (uint32_t)(j * 1024) + lane * 16u) = f.v[j];
+    r.ks[0] = f.ks;
+    r.vs[0] = f.vs;
+    request(k + (uint32_t)DEPTH, f);  // the registers are free again: the tile DEPTH ahead takes them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    read_fragments<KBITS, VBITS, TC, KI8>(img, r);
+    const uint32_t t0 = (first + k) * (uint32_t)TC;
+    const uint32_t nt = a.T - t0 < (uint32_t)TC ? a.T - t0 : (uint32_t)TC;
+    st.consume(a, nt, r, none, s_ks, s_vs, s_al);
+  };
+  for (uint32_t k = 0; k < n; k += (uint32_t)DEPTH) {
+#pragma unroll
+    for (int dpt = 0; dpt < DEPTH; ++dpt)
+      if (k + (uint32_t)dpt < n) step(k + (uint32_t)dpt, fl[dpt]);
+  }
+  // ---- workspace: (m, l) per head, acc[heads][D] — the layout the merge kernels read ---------------------------
+  if (g == 0u && x < a.nq) {
+    float* o = a.ws + (((int64_t)b * a.Hq + hk * a.nq + x) * a.nsplit + split) * 2;
+    o[0] = st.m * 0.693147180559945309f;
+    o[1] = st.l;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t h = 4 * g + q;
+    if (h < a.nq) {
+      float o8[DVN];
+#pragma unroll
+      for (int c = 0; c < DVN; ++c) {
+        int e = c;
+        if constexpr (VBITS == 4) e = c < 4 ? 2 * c : 2 * (c - 4) + 1;
+        o8[e] = st.acc[c][q] * st.svref;
+      }
+      float* dst = a.ws + a.acc_off + (((int64_t)b * a.Hq + hk * a.nq + h) * a.nsplit + split) * a.D + DVN * x;
+#pragma unroll
+      for (int c = 0; c < DVN; c += 4) *reinterpret_cast<f32x4*>(dst + c) = f32x4{o8[c], o8[c + 1], o8[c + 2], o8[c + 3]};
+    }
+  }
+}
+
+#endif  // KVQ_AB (coalesced streaming variant)
 
 #if KVQ_AB
 // ---------------------------------------------------------------------------- fused single launch
@@ -1853,6 +2157,8 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_fast_k(const Att
   }
 }
 
+constexpr int64_t kLdsSlots = 256 * 4;  // one-wave workgroups of the LDS-staged kernel resident at once (4 per CU)
+
 // tokens per workgroup: one loop iteration (D/16 lanes per token, kAttnUnroll tokens per lane) while
 // the grid stays below ~4096 workgroups, whole multiples of it beyond; never more than
 // kAttnMaxSplit splits
@@ -1864,16 +2170,32 @@ static bool use_mfma(const kvq_attn_dims_t* d) {
 // streaming kernel: tiles per wave (0 = one-tile kernel). Chosen so that every wave of the launch is resident
 // at once (one round) when the batch offers more 64-token tiles than the chip has wave slots.
 static int stream_tc() { return KVQ_AB && tunables().attn_stream_tc == 32 ? 32 : 64; }
+// LDS-staged streaming kernel (contiguous 1 KiB requests into an LDS ring): head_dim 128 grouped-query shapes.
+// attn_lds: -1 (default) / 1 = the LDS-DMA ring kernel serves every streaming plan; 0 = never (A-B builds: the register-
+// staged streaming kernel instead; the default library then has no streaming kernel and takes one-tile splits);
+// 2 (A-B builds) = the coalesced register-staged kernel
+static bool use_lds(const kvq_attn_dims_t* d) {
+  return tunables().attn_lds != 0 && use_mfma(d) && d->D == 128;
+}
+static int lds_tc() { return KVQ_AB && tunables().attn_lds_tc == 32 ? 32 : 64; }
+// tokens per tile of whichever streaming kernel serves these dims
+static int tile_tc(const kvq_attn_dims_t* d) { return use_lds(d) ? lds_tc() : stream_tc(); }
 static uint32_t stream_tpw(const kvq_attn_dims_t* d) {
   if (!use_mfma(d) || d->D != 128 || d->T <= 0) return 0;
   const int64_t forced = tunables().attn_stream_tpw;  // -1 = never, 0 = by size, > 0 = that many
   if (forced < 0) return 0;
-  const int kStreamTC = stream_tc();
+  const int kStreamTC = tile_tc(d);
   const int64_t ntiles = (d->T + kStreamTC - 1) / kStreamTC;
-  // wave slots of one round: 2 waves per SIMD at 64-token tiles, 3 at 32-token tiles
-  const int64_t slots = tunables().attn_stream_slots > 0 ? tunables().attn_stream_slots : 256 * 4 * (kStreamTC == 64 ? 2 : 3);
+  // wave slots of one round: the LDS-staged kernel holds its tiles in LDS, 4 one-wave workgroups per CU; (A-B) register-
+  // staged kernels: 2 waves per SIMD at 64-token tiles, 3 at 32-token tiles
+  const bool ring = use_lds(d) && !(KVQ_AB && tunables().attn_lds == 2);
+  if (!ring && !KVQ_AB) return 0;  // the default library's only streaming kernel is the ring kernel
+  int64_t slots = ring ? kLdsSlots : 256 * 4 * (kStreamTC == 64 ? 2 : 3);
+  if (KVQ_AB && tunables().attn_stream_slots > 0) slots = tunables().attn_stream_slots;
   int64_t tpw = forced > 0 ? forced : (ntiles * d->B * d->Hkv + slots - 1) / slots;
-  if (tpw < 2 && forced <= 0) return 0;
+  // by size: the ring pays from three tiles per wave on (batch 1 at 16 K tokens = two tiles per wave: 14.9 us per layer
+  // call against 13.7 for one-tile splits); the register-staged kernels from two
+  if (forced <= 0 && tpw < (ring ? 3 : 2)) return 0;
   if (tpw > ntiles) tpw = ntiles;
   return (uint32_t)tpw;
 }
@@ -1883,7 +2205,7 @@ static bool plan_onetile(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nspli
 static bool plan(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit, uint32_t* tpw_out = nullptr) {
   if (tpw_out) *tpw_out = 0;
   if (const uint32_t tpw = stream_tpw(d)) {  // one wave per tpw tiles of 64 (32) tokens
-    const int64_t per = (int64_t)tpw * stream_tc();
+    const int64_t per = (int64_t)tpw * tile_tc(d);
     *ts = (uint32_t)per;
     *nsplit = (uint32_t)((d->T + per - 1) / per);
     if (*nsplit <= (uint32_t)kAttnMaxSplit) {
@@ -1992,8 +2314,37 @@ static void launch_partial(const AttnArgs& a, hipStream_t st) {
   // int8 planes whose cost is amortised over the wave's tiles (50.6 vs 52.3 us per call at batch 8). A-B builds can
   // force that operand form on (attn_k_i8 = 1) or off (0) everywhere.
   constexpr bool kI8 = KBITS == 8;
-  if (a.mfma && a.stream_tpw) {
 #if KVQ_AB
+  if (a.mfma && a.stream_tpw && a.lds == 2u) {  // coalesced requests into registers, one LDS image per wave
+    if (tunables().attn_lds_nb == 1) { KVQ_LAUNCH((decode_attn_coal_mfma_k<KBITS, VBITS, kI8, 1>), grid, dim3(kWave), 0, st, a, a.stream_tpw); return; }
+    KVQ_LAUNCH((decode_attn_coal_mfma_k<KBITS, VBITS, kI8, 2>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
+    return;
+  }
+#endif
+  if (a.mfma && a.stream_tpw && a.lds) {
+    // ring depth 2: one tile in flight behind the one being reduced, four one-wave workgroups per CU (25.6 KiB each for
+    // INT8 keys + INT4 values). Measured at batch 8, 16 K tokens (per layer call incl. merge, profiles/r03d_*): depth 2
+    // 40.8 us, depth 3 44.7 us, depth 4 (three workgroups per CU) 86 us; 32-token tiles 42.1-51.6 us.
+    constexpr int kSlot = 64 * (128 * KBITS / 8 + 128 * VBITS / 8) + 512;
+    int nb = 2;
+#if KVQ_AB
+    if (tunables().attn_lds_nb >= 2 && tunables().attn_lds_nb <= 4) nb = (int)tunables().attn_lds_nb;
+    if (lds_tc() == 32) {
+      constexpr int kSlot32 = 32 * (128 * KBITS / 8 + 128 * VBITS / 8) + 512;
+      if (nb == 2) KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 32, kI8, 2>), grid, dim3(kWave), (size_t)(2 * kSlot32), st, a, a.stream_tpw);
+      else if (nb == 3) KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 32, kI8, 3>), grid, dim3(kWave), (size_t)(3 * kSlot32), st, a, a.stream_tpw);
+      else KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 32, kI8, 4>), grid, dim3(kWave), (size_t)(4 * kSlot32), st, a, a.stream_tpw);
+      return;
+    }
+    if (nb == 4) { KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 64, kI8, 4>), grid, dim3(kWave), (size_t)(4 * kSlot), st, a, a.stream_tpw); return; }
+    if (nb == 3) { KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 64, kI8, 3>), grid, dim3(kWave), (size_t)(3 * kSlot), st, a, a.stream_tpw); return; }
+#endif
+    (void)nb;
+    KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 64, kI8, 2>), grid, dim3(kWave), (size_t)(2 * kSlot), st, a, a.stream_tpw);
+    return;
+  }
+#if KVQ_AB
+  if (a.mfma && a.stream_tpw) {
     const int64_t ki8 = tunables().attn_k_i8;
     const bool i8 = kI8 && ki8 != 0;
     if constexpr (kI8) {
@@ -2003,10 +2354,10 @@ static void launch_partial(const AttnArgs& a, hipStream_t st) {
     if (!i8 && stream_tc() == 64 && tunables().attn_stream_roll) { KVQ_LAUNCH((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128, false, true>), grid, dim3(kWave), 0, st, a, a.stream_tpw); return; }
     if (!i8 && stream_tc() == 64) { KVQ_LAUNCH((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128>), grid, dim3(kWave), 0, st, a, a.stream_tpw); return; }
     if (!i8) { KVQ_LAUNCH((decode_attn_stream_mfma_k<KBITS, VBITS, 32, 128>), grid, dim3(kWave), 0, st, a, a.stream_tpw); return; }
-#endif
     KVQ_LAUNCH((decode_attn_stream_mfma_k<KBITS, VBITS, 64, 128, kI8, true>), grid, dim3(kWave), 0, st, a, a.stream_tpw);
     return;
   }
+#endif
   if (a.mfma) {
 #if KVQ_AB
     if constexpr (kI8) {
@@ -2136,6 +2487,7 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
   a.dtype = dtype;
   a.mfma = use_mfma(d) ? 1 : 0;
   a.stream_tpw = 0u;
+  a.lds = (!t_dev && use_lds(d)) ? (KVQ_AB && tunables().attn_lds == 2 ? 2u : 1u) : 0u;
   a.t_dev = t_dev;
   if (!(t_dev ? plan_onetile(d, &a.TS, &a.nsplit) : plan(d, &a.TS, &a.nsplit, &a.stream_tpw))) {
     set_error("%s: T=%lld needs more than %d splits of %d tokens", name, (long long)d->T, kAttnMaxSplit, kAttnMaxTS);

@@ -645,6 +645,7 @@ __global__ __launch_bounds__(kBlock) void absmax_tokens_generic_k(const QuantArg
   if (i1 > RD) i1 = RD;
   const void* in = a.in.p[g];
   float m = 0.0f;
+#pragma unroll 1  // generic fallback: four 64-bit divisions per element; unrolled it is 5,600 instructions per instantiation
   for (int64_t i = i0 + threadIdx.x; i < i1; i += kBlock) {
     const int64_t d = i % a.D;
     const int64_t r = i / a.D;
@@ -760,11 +761,13 @@ static uint32_t pow2_floor(uint64_t v) {
 template <int IDT, int BITS>
 static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
   if (fused && a.rpc) {  // swept tile: B*H*D larger than the register tile
-    const unsigned tiles = (a.T + a.TT - 1) / a.TT;
-    if (a.vpr)
-      KVQ_LAUNCH((quant_tokens_sweep_k<IDT, BITS, false>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
-    else
-      KVQ_LAUNCH((quant_tokens_sweep_k<IDT, BITS, true>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
+    if constexpr (KVQ_AB || IDT != KVQ_F32) {  // (fp32 batched slices take the generic pair in the default library: host)
+      const unsigned tiles = (a.T + a.TT - 1) / a.TT;
+      if (a.vpr)
+        KVQ_LAUNCH((quant_tokens_sweep_k<IDT, BITS, false>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
+      else
+        KVQ_LAUNCH((quant_tokens_sweep_k<IDT, BITS, true>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
+    }
   } else if (fused) {
     const unsigned tiles = (a.T + a.TT - 1) / a.TT;
     // LDS-staged 16 B stores need 16-byte aligned row runs in the store
@@ -954,7 +957,7 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
       ((int64_t)d->D * BITS / 8) % 16 == 0 && aligned(q, 16) && a.is.h >= 0 && a.qs.h >= 0) {
     int tt = 0;  // tokens per tile of the instantiation that serves (R, D); 0 = none
     if (d->D == 128 && R == 8) tt = 4;
-    else if (d->D == 64 && (R == 8 || R == 12 || R == 16)) tt = tunables().quant_tile_tt == 4 && KVQ_AB ? 4 : 8;
+    else if (d->D == 64 && (R == 8 || ((R == 12 || R == 16) && (KVQ_AB || in_dtype == KVQ_F16)))) tt = tunables().quant_tile_tt == 4 && KVQ_AB ? 4 : 8;  // 12 / 16 rows: the gpt2 family (fp16)
     const int64_t span_in = (R - 1) * a.is.h * 2 + (int64_t)tt * d->D * 2, span_q = (R - 1) * a.qs.h + (int64_t)tt * Dq;
     if (tt && span_in < (int64_t(1) << 31) && span_q < (int64_t(1) << 31)) {
       bool all_aligned = true;
@@ -992,7 +995,12 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
     else KVQ_TILE64(IDT_, 16);                          \
   } while (0)
           if (in_dtype == KVQ_F16) KVQ_TILE_BY_SHAPE(KVQ_F16);
+#if KVQ_AB
           else KVQ_TILE_BY_SHAPE(KVQ_BF16);
+#else
+          else if (d->D == 128) KVQ_TILE(KVQ_BF16, 8, 16, 4);
+          else KVQ_TILE64(KVQ_BF16, 8);
+#endif
 #undef KVQ_TILE_BY_SHAPE
 #undef KVQ_TILE64
 #undef KVQ_TILE
@@ -1012,7 +1020,7 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
   const bool anydv = d->D % 8 == 0 && (dvshift < 0 || d->D / 8 > kWave);
   const bool big = anydv || R * d->D > kTileElems;  // swept-tile kernel instead of the register tile
   bool fused = !tunables().quant_force_two_pass && d->D % 8 == 0 && d->D <= kTileElems &&
-               (d->T == 1 || (a.is.t == d->D && a.qs.t == Dq)) && (big || bh_contig) &&
+               (d->T == 1 || (a.is.t == d->D && a.qs.t == Dq)) && (big ? (KVQ_AB || in_dtype != KVQ_F32) : bh_contig) &&
                (a.is.b * esz) % 16 == 0 && a.qs.b % qvec == 0 &&
                (a.is.h * esz) % 16 == 0 && (a.is.t * esz) % 16 == 0 && a.qs.h % qvec == 0 &&
                a.qs.t % qvec == 0 && a.qs.g % qvec == 0 && aligned(q, qvec);

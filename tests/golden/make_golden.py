@@ -18,6 +18,14 @@ Groups:
          to_past_key_values, estimated_bytes) for int8 / int4 / mixed
   G6     trim_kv_sliding_window  (T<W, T==W, T>W)
   G7     chunk_summarize_kv      (old%chunk==0, !=0, T<=keep_last, keep_last=0, re-application)
+  G9     g9_benchmarker.npz (round 3): the REFERENCE's KVCacheBenchmarker run on the build's offline gpt2-tiny
+         (random init, seed 42, byte tokenizer; CPU fp32). Part A (adapter-free; the reference's no_cache / full_cache
+         paths run unmodified on the installed transformers): benchmark_method dict key order, value kinds,
+         total_new_tokens, generated token ids. Part B (the quant_* / sliding / chunked / paged / sparse loops call
+         DynamicCache.from_legacy_cache / to_legacy_cache, which transformers >= 5 removed): the same reference code
+         run with a GENERATOR-SIDE adapter that gives DynamicCache those two methods back; only float-independent
+         observables are kept (n_new, est_mb, paged alloc / used MB and block counts, the cache length the model saw
+         at every forward, dict key order / value kinds).
   G8     round-2 additions: window_size == 0 edge of the trims (the reference's ``-0:`` slice keeps
          everything), budget-policy index lists at more lengths, and known-answer tests of the
          quality helpers text_similarity / token_agreement_rate (src/evaluation/quality.py:124-150)
@@ -296,6 +304,101 @@ def gen_round2():
     print("g8_round2:", len(out), "arrays")
 
 
+def gen_benchmarker():
+    """G9 (g9_benchmarker.npz): see the module docstring. Needs the repo root on sys.path for the OFFLINE MODEL only
+    (efficient_llm_inference_amd.benchmarking.offline: a random-init HF GPT2LMHeadModel + byte tokenizer — the
+    reference's examples download 'gpt2', which this container cannot); every benchmarker line that runs is the
+    reference's."""
+    import math
+    repo = os.path.dirname(os.path.dirname(OUT))
+    if repo not in sys.path:
+        sys.path.insert(1, repo)
+    import transformers
+    from efficient_llm_inference_amd.benchmarking.offline import load_model
+    from src.benchmarking.benchmarker import KVCacheBenchmarker as RefBM
+    model, tok = load_model("gpt2-tiny", "cpu", torch.float32)
+
+    class Recorder:
+        """the model as the reference calls it, noting (new tokens fed, cache length seen) per forward"""
+        def __init__(self, m):
+            self.m, self.config, self.calls = m, m.config, []
+        def __call__(self, **kw):
+            past = kw.get("past_key_values")
+            plen = 0
+            if past is not None:
+                plen = int(past.get_seq_length()) if hasattr(past, "get_seq_length") else int(past[0][0].size(2))
+            self.calls.append((int(kw["input_ids"].shape[-1]), plen))
+            return self.m(**kw)
+
+    def kinds(d):  # value kind per key: n None, a NaN, f float, i int, s str
+        out = []
+        for v in d.values():
+            out.append("n" if v is None else "s" if isinstance(v, str) else "i" if isinstance(v, (int, np.integer)) and not isinstance(v, bool)
+                       else "a" if isinstance(v, float) and math.isnan(v) else "f")
+        return "".join(out)
+
+    prompts = ["The quick brown fox", "<23>", "<31>"]
+    out = {"prompts": np.array(prompts), "model": np.array(["gpt2-tiny seed 42 fp32 cpu (benchmarking/offline.py)"]),
+           "transformers": np.array([transformers.__version__])}
+    rec = Recorder(model)
+    ref = RefBM(rec, tok, device="cpu")
+    ids = lambda text: np.frombuffer(text.encode("utf-8", "surrogatepass"), dtype=np.uint8).copy()  # noqa: E731
+
+    # ---- part A: adapter-free ------------------------------------------------------------------------------------
+    NEW_A = 16
+    for method in ("no_cache", "full_cache"):
+        rec.calls.clear()
+        res = ref.benchmark_method(prompts, method=method, max_new_tokens=NEW_A)
+        out[f"A.{method}.keys"] = np.array(list(res.keys()))
+        out[f"A.{method}.kinds"] = np.array([kinds(res)])
+        out[f"A.{method}.total_new_tokens"] = np.array([res["total_new_tokens"]], dtype=np.int64)
+        out[f"A.{method}.calls"] = np.array(rec.calls, dtype=np.int64)
+    out["A.max_new_tokens"] = np.array([NEW_A], dtype=np.int64)
+    for i, p in enumerate(prompts):
+        for name, fn in (("with_cache", ref.generate_with_cache), ("no_cache", ref.generate_no_cache)):
+            text, n_new = fn(p, NEW_A)
+            out[f"A.generate_{name}.{i}.text_utf8"] = ids(text)
+            out[f"A.generate_{name}.{i}.n_new"] = np.array([n_new], dtype=np.int64)
+
+    # ---- part B: the reference's loops behind a generator-side DynamicCache adapter --------------------------------
+    DC = transformers.DynamicCache
+    added = []
+    if not hasattr(DC, "from_legacy_cache"):
+        DC.from_legacy_cache = classmethod(lambda cls, past: cls(ddp_cache_data=past))
+        added.append("from_legacy_cache")
+    if not hasattr(DC, "to_legacy_cache"):
+        DC.to_legacy_cache = lambda self: tuple((layer.keys, layer.values) for layer in self.layers)
+        added.append("to_legacy_cache")
+    out["B.adapter"] = np.array(["generator-side: DynamicCache." + ", DynamicCache.".join(added) if added else "none needed"])
+    kw = dict(max_new_tokens=12, window_size=8, block_size=4, chunk_size=4, keep_last=6, prefix_len=2, stride=2, keep_per_block=1, old_budget=3)
+    out["B.kwargs"] = np.array([f"{k}={v}" for k, v in kw.items()])
+    try:
+        for method in ("sliding_window", "quant_int8", "quant_int4", "quant_mixed", "paged_attention", "chunked_cache",
+                       "prefix_window", "strided_cache", "block_cache", "budget_cache"):
+            rec.calls.clear()
+            res = ref.benchmark_method(prompts, method=method, **kw)
+            out[f"B.{method}.keys"] = np.array(list(res.keys()))
+            out[f"B.{method}.kinds"] = np.array([kinds(res)])
+            out[f"B.{method}.total_new_tokens"] = np.array([res["total_new_tokens"]], dtype=np.int64)
+            out[f"B.{method}.est_kv_cache_mb_avg"] = np.array([res["est_kv_cache_mb_avg"]], dtype=np.float64)
+            out[f"B.{method}.calls"] = np.array(rec.calls, dtype=np.int64)
+            for k2 in ("window_size", "block_size", "chunk_size", "prefix_len", "stride", "keep_per_block", "old_budget"):
+                out[f"B.{method}.{k2}"] = np.array([-1 if res[k2] is None else res[k2]], dtype=np.int64)
+        for i, p in enumerate(prompts):
+            for mode in ("int8", "int4", "mixed"):
+                _, n_new, est_mb = ref.generate_with_quantized_kv(p, 12, mode=mode)
+                out[f"B.generate_with_quantized_kv.{mode}.{i}"] = np.array([n_new, est_mb], dtype=np.float64)
+            _, n_new, est_mb = ref.generate_with_chunked_cache(p, 12, chunk_size=4, keep_last=6)
+            out[f"B.generate_with_chunked_cache.{i}"] = np.array([n_new, est_mb], dtype=np.float64)
+            _, n_new, alloc_mb, used_mb, nblocks = ref.generate_with_paged_attention(p, 12, block_size=4)
+            out[f"B.generate_with_paged_attention.{i}"] = np.array([n_new, alloc_mb, used_mb, nblocks], dtype=np.float64)
+    finally:
+        for name in added:
+            delattr(DC, name)
+    np.savez_compressed(os.path.join(OUT, "g9_benchmarker.npz"), **out)
+    print("g9_benchmarker:", len(out), "arrays; adapter:", out["B.adapter"][0])
+
+
 if __name__ == "__main__":
     torch.manual_seed(42)
     gen_slices()
@@ -305,3 +408,4 @@ if __name__ == "__main__":
     gen_evict()
     gen_sparse()
     gen_round2()
+    gen_benchmarker()

@@ -98,7 +98,7 @@ def test_default_library_is_the_shipped_subset():
     if os.environ.get("KVQ_HIP_LIB"):
         pytest.skip("KVQ_HIP_LIB overrides the library")
     assert not _lib.is_ab_build()
-    assert os.path.getsize(_lib.LIB_PATH) < 2.5 * 2**20, os.path.getsize(_lib.LIB_PATH)
+    assert os.path.getsize(_lib.LIB_PATH) < 2_000_000, os.path.getsize(_lib.LIB_PATH)
 
 
 def test_kernel_log_is_empty_without_launches(lib):

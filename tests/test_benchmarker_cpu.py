@@ -12,9 +12,13 @@ import torch.multiprocessing as mp
 
 from tests.conftest import ROOT
 
-REF_KEYS = ["method", "elapsed_sec", "total_new_tokens", "tokens_per_sec", "cpu_mem_used_mb", "gpu_peak_mb",
-            "window_size", "block_size", "chunk_size", "est_kv_cache_mb_avg", "prefix_len", "stride",
-            "keep_per_block", "old_budget"]  # reference benchmarker.py:811-832, in order
+from tests.conftest import load_golden
+from tests.util import CallRecorder, value_kinds
+
+# the dict the REFERENCE's benchmark_method returned when tests/golden/make_golden.py ran it (reference
+# benchmarker.py:811-832): key order from the reference run, not from reading
+G9 = load_golden("g9_benchmarker.npz")
+REF_KEYS = [str(k) for k in G9["A.full_cache.keys"]]
 
 
 @pytest.fixture(scope="module")
@@ -31,6 +35,34 @@ def test_full_cache_plumbing_on_cpu(bench_cpu):
     assert res["method"] == "full_cache" and res["total_new_tokens"] == 128
     assert res["tokens_per_sec"] > 0 and math.isnan(res["est_kv_cache_mb_avg"]) and res["gpu_peak_mb"] is None
     assert res["window_size"] is None and res["chunk_size"] is None
+
+
+@pytest.mark.parametrize("method", ["no_cache", "full_cache"])
+def test_benchmark_method_equals_the_reference_run(method):
+    """Part A of g9_benchmarker.npz: the reference's own KVCacheBenchmarker.benchmark_method, run unmodified on the
+    offline gpt2-tiny (CPU fp32), against this package's on the same model: same keys in the same order, same value
+    kinds (None / NaN / float / int / str), same token count, same forwards (tokens fed, cache length seen) in the same
+    order."""
+    from efficient_llm_inference_amd import KVCacheBenchmarker
+    from efficient_llm_inference_amd.benchmarking.offline import load_model
+    model, tok = load_model("gpt2-tiny", "cpu", torch.float32)
+    rec = CallRecorder(model)
+    bm = KVCacheBenchmarker(rec, tok, device="cpu")
+    prompts = [str(p) for p in G9["prompts"]]
+    res = bm.benchmark_method(prompts, method=method, max_new_tokens=int(G9["A.max_new_tokens"][0]))
+    assert list(res.keys()) == [str(k) for k in G9[f"A.{method}.keys"]]
+    assert value_kinds(res) == str(G9[f"A.{method}.kinds"][0])
+    assert res["total_new_tokens"] == int(G9[f"A.{method}.total_new_tokens"][0])
+    assert rec.calls == [tuple(c) for c in G9[f"A.{method}.calls"].tolist()]
+
+
+def test_generate_functions_equal_the_reference_run(bench_cpu):
+    """generate_with_cache / generate_no_cache: the text (hence every greedy token) and n_new the reference produced"""
+    for i, p in enumerate(str(p) for p in G9["prompts"]):
+        for name, fn in (("with_cache", bench_cpu.generate_with_cache), ("no_cache", bench_cpu.generate_no_cache)):
+            text, n_new = fn(p, int(G9["A.max_new_tokens"][0]))
+            assert n_new == int(G9[f"A.generate_{name}.{i}.n_new"][0])
+            assert text.encode("utf-8", "surrogatepass") == G9[f"A.generate_{name}.{i}.text_utf8"].tobytes(), (name, i)
 
 
 def test_cache_equals_no_cache_tokens(bench_cpu):

@@ -389,16 +389,19 @@ def test_decode_attn_fused_workspace_reuse(K, tunable, shape):
         assert (np.abs(got - ref) <= TOL["f16"] * (np.abs(ref) + np.abs(ref).max())).all(), (si, T)
 
 
+@pytest.mark.parametrize("lds", [-1, pytest.param(0, marks=pytest.mark.ab)])  # 0 (A-B library): the register-staged kernel
 @pytest.mark.parametrize("tc", [64, pytest.param(32, marks=pytest.mark.ab)])
 @pytest.mark.parametrize("tpw", [1, 2, 3, 5])
-def test_decode_attn_streaming_kernel_matches_oracle(K, tunable, tc, tpw):
+def test_decode_attn_streaming_kernel_matches_oracle(K, tunable, tc, tpw, lds):
     """decode_attn_stream_mfma_k (one wave walks `tpw` tiles with the next tile's rows in flight, online
     softmax across tiles): forced on small shapes through the tunables — odd / even tile counts per wave, a
     ragged last tile, a last wave with fewer tiles, one-tile contexts, V scales that grow and shrink across
     tiles (the running reference scale), every kind pair, fp16 and bf16."""
     tunable("attn_stream_tpw", tpw)
+    tunable("attn_lds", lds)
     if tc != 64:
         tunable("attn_stream_tc", tc)
+        tunable("attn_lds", 0)  # 32-token tiles are the register-staged kernel's
     for case in [(1, 32, 8, 1000, 128), (2, 6, 2, 200, 128), (1, 16, 1, 300, 128), (1, 32, 8, 5000, 128), (3, 8, 2, 1, 128),
                  (1, 8, 2, 513, 128), (2, 32, 8, 2048, 128), (1, 8, 2, 64, 128), (1, 8, 2, 129, 128)]:
         for kinds in (("int8", "int4"), ("int4", "int8"), ("int8", "int8"), ("int4", "int4")):
@@ -424,6 +427,64 @@ def test_decode_attn_streaming_kernel_matches_oracle(K, tunable, tc, tpw):
     K.decode_attn(to_torch(q), to_torch(kq[0]), to_torch(ks[0]), "int8", to_torch(vq[0]), to_torch(vs[0]), "int4", T, out, ws, sm)
     got = to_numpy(out).astype(np.float64)
     assert (np.abs(got - ref) <= TOL["f16"] * (np.abs(ref) + np.abs(ref).max())).all()
+
+
+LDS_CASES = [(1, 32, 8, 1000, 128), (2, 6, 2, 200, 128), (1, 16, 1, 300, 128), (1, 32, 8, 5000, 128), (3, 8, 2, 1, 128),
+             (1, 8, 2, 513, 128), (2, 32, 8, 2048, 128), (1, 8, 2, 64, 128), (1, 8, 2, 129, 128), (8, 32, 8, 4100, 128)]
+
+
+@pytest.mark.parametrize("which", [1, pytest.param(2, marks=pytest.mark.ab)])
+@pytest.mark.parametrize("tpw", [0, 1, 2, 3, 5, 9])
+def test_decode_attn_lds_staged_kernel(K, tunable, tpw, which):
+    """decode_attn_lds_mfma_k (a tile = whole 1 KiB LDS-DMA requests into a ring of LDS slots, operand fragments read
+    back from the XOR-swizzled image): forced on small shapes through attn_stream_tpw — against the oracle for every
+    kind pair, fp16 and bf16, with and without the new token, ragged last tiles, one-tile contexts, waves with fewer
+    tiles than the ring is deep. tpw = 0: the split the library picks by size. which = 2 (A-B library):
+    decode_attn_coal_mfma_k, the same whole-line requests into registers and one LDS image per wave."""
+    from efficient_llm_inference_amd import _lib
+    tunable("attn_stream_tpw", tpw)
+    tunable("attn_lds", which)
+    for case in LDS_CASES:
+        for kinds in (("int8", "int4"), ("int4", "int8"), ("int8", "int8"), ("int4", "int4")):
+            _run_case(K, *case, kinds[0], kinds[1], "f16", True)
+        _run_case(K, *case, "int8", "int4", "bf16", True)
+        _run_case(K, *case, "int8", "int4", "f16", False)
+    if tpw:
+        _lib.kernel_log_clear()
+        _run_case(K, 2, 32, 8, 1500, 128, "int8", "int4", "f16", True)
+        assert _lib.kernel_log()[0].startswith(("decode_attn_lds_mfma_k<8, 4, 64, true, 2>", "decode_attn_coal_mfma_k<")[which - 1]), _lib.kernel_log()
+
+
+@pytest.mark.ab
+@pytest.mark.parametrize("which", [1, 2])
+@pytest.mark.parametrize("tpw", [1, 2, 3, 5, 9])
+def test_lds_staged_kernels_equal_the_register_staged_streaming_kernel(K, tunable, tpw, which):
+    """A-B library: the LDS-DMA ring kernel and the coalesced kernel are BIT-identical to the register-staged streaming
+    kernel (attn_lds = 0) on the same inputs: the fragments in registers are the same bytes, the arithmetic is the same
+    code (AttnStream::consume)."""
+    from efficient_llm_inference_amd import _lib
+    tunable("attn_stream_tpw", tpw)
+    g = torch.Generator(device="cuda").manual_seed(11 + tpw)
+    for (B, Hq, Hkv, T, D) in ((2, 32, 8, 1500, 128), (1, 16, 2, 449, 128)):
+        for kk, vk in (("int8", "int4"), ("int4", "int8"), ("int8", "int8")):
+            ks = torch.randint(-127, 128, (B, Hkv, T + 5, K.packed_dim(kk, D)), device="cuda", dtype=torch.int8, generator=g).view(K.QDTYPE[kk])
+            vs = torch.randint(-127, 128, (B, Hkv, T + 5, K.packed_dim(vk, D)), device="cuda", dtype=torch.int8, generator=g).view(K.QDTYPE[vk])
+            ksc = torch.rand(T + 5, device="cuda", generator=g) * 0.02 + 0.002
+            vsc = torch.rand(T + 5, device="cuda", generator=g) * 0.3 + 0.01
+            q = torch.randn(B, Hq, D, device="cuda", dtype=torch.float16, generator=g)
+            kn = torch.randn(B, Hkv, D, device="cuda", dtype=torch.float16, generator=g)
+            vn = torch.randn(B, Hkv, D, device="cuda", dtype=torch.float16, generator=g)
+            outs, names = [], []
+            for lds in (which, 0):
+                tunable("attn_lds", lds)
+                ws = torch.full((K.decode_attn_workspace(B, Hq, Hkv, T, D),), float("nan"), dtype=torch.float32, device="cuda")
+                out = torch.empty(B, Hq, D, dtype=torch.float16, device="cuda")
+                _lib.kernel_log_clear()
+                K.decode_attn(q, ks, ksc, kk, vs, vsc, vk, T, out, ws, D ** -0.5, kn, vn)
+                names.append(_lib.kernel_log()[0])
+                outs.append(out)
+            assert names[0].startswith(("decode_attn_lds_mfma_k<", "decode_attn_coal_mfma_k<")[which - 1]) and names[1].startswith("decode_attn_stream_mfma_k<"), names
+            assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), (B, Hq, Hkv, T, kk, vk, tpw)
 
 
 @pytest.mark.parametrize("fused", [0, pytest.param(1, marks=pytest.mark.ab)])
@@ -524,6 +585,7 @@ def test_decode_attn_int8_keys_through_int8_mfma(K, tunable, stream):
     """attn_k_i8: INT8 keys go into v_mfma_i32_16x16x64_i8 as stored (no byte -> f16 conversion), the query as two
     int8 planes. One-tile and streaming kernels, INT8 and INT4 values, fp16 and bf16, padded heads, peaked softmax."""
     tunable("attn_k_i8", 1)
+    tunable("attn_lds", 0)  # the register-staged streaming kernel
     tunable("attn_stream_tpw", stream[0])
     tunable("attn_stream_tc", stream[1])
     for case in [(1, 32, 8, 1000, 128), (2, 6, 2, 200, 128), (1, 16, 1, 300, 128), (1, 32, 8, 5000, 128), (3, 8, 2, 1, 128),
@@ -643,6 +705,7 @@ def test_streaming_kernel_rolling_requests_equal_whole_tile_requests(K, tunable,
     the tile is being reduced. Only the load schedule changes: output bits equal the whole-tile schedule's — odd and
     even tile counts, a ragged last tile, waves with one tile, every kind pair, both key paths."""
     tunable("attn_stream_tpw", tpw)
+    tunable("attn_lds", 0)  # the register-staged streaming kernel
     tunable("attn_stream_tc", 64)
     tunable("attn_k_i8", ki8)
     for B, Hq, Hkv, T, D in [(1, 32, 8, 1000, 128), (2, 6, 2, 200, 128), (8, 32, 8, 4100, 128), (1, 8, 2, 64, 128), (3, 8, 2, 1, 128)]:

@@ -375,3 +375,65 @@ def test_graph_decode_equals_eager_fused_decode(arch, mode):
     bench.graph_decode = True
     with pytest.raises(RuntimeError):
         bench.generate_with_quantized_kv("<40>", 4, mode=mode)
+
+
+G9_METHODS = ["sliding_window", "quant_int8", "quant_int4", "quant_mixed", "paged_attention", "chunked_cache",
+              "prefix_window", "strided_cache", "block_cache", "budget_cache"]
+
+
+@pytest.fixture(scope="module")
+def g9_rig():
+    """the offline gpt2-tiny in fp32 on the GPU: the reference run of g9_benchmarker.npz was CPU fp32, and the byte
+    counts it reports (scale itemsize = the KV dtype's, ops.py:271-290; tensor bytes of the chunked cache) follow the
+    KV dtype"""
+    from efficient_llm_inference_amd import KVCacheBenchmarker
+    from efficient_llm_inference_amd.benchmarking.offline import load_model
+    from tests.util import CallRecorder
+    model, tok = load_model("gpt2-tiny", "cuda", torch.float32)
+    rec = CallRecorder(model)
+    return KVCacheBenchmarker(rec, tok, device="cuda"), rec
+
+
+@pytest.mark.parametrize("method", G9_METHODS)
+def test_decode_loops_equal_the_reference_run(g9_rig, method):
+    """Part B of g9_benchmarker.npz: the reference's quant_* / sliding / chunked / paged / sparse loops (run by
+    tests/golden/make_golden.py behind a generator-side DynamicCache.from_legacy_cache / to_legacy_cache adapter)
+    against this package's, float-independent observables only: dict keys + order, value kinds, token count, the
+    estimated cache MB, the policy parameters echoed back, and the cache length the model saw at every forward."""
+    from tests.conftest import load_golden
+    from tests.util import value_kinds
+    g = load_golden("g9_benchmarker.npz")
+    bm, rec = g9_rig
+    kw = {k: int(v) for k, v in (str(s).split("=") for s in g["B.kwargs"])}
+    prompts = [str(p) for p in g["prompts"]]
+    rec.calls.clear()
+    res = bm.benchmark_method(prompts, method=method, **kw)
+    assert list(res.keys()) == [str(k) for k in g[f"B.{method}.keys"]]
+    want = str(g[f"B.{method}.kinds"][0])
+    got = value_kinds(res)
+    assert got[:5] + got[6:] == want[:5] + want[6:], (got, want)  # [5] = gpu_peak_mb: None on the reference's CPU run
+    assert res["total_new_tokens"] == int(g[f"B.{method}.total_new_tokens"][0])
+    ref_mb = float(g[f"B.{method}.est_kv_cache_mb_avg"][0])
+    if method == "paged_attention":
+        # the reference picks the block dtype by DEVICE STRING (benchmarker.py:521: fp16 on "cuda", fp32 on "cpu"): the
+        # fixture's CPU run counted 4-byte elements, this GPU run counts 2-byte ones — same blocks, half the bytes
+        ref_mb *= 0.5
+    assert (np.isnan(ref_mb) and np.isnan(res["est_kv_cache_mb_avg"])) or abs(res["est_kv_cache_mb_avg"] - ref_mb) <= 1e-12 * ref_mb, (res["est_kv_cache_mb_avg"], ref_mb)
+    for k2 in ("window_size", "block_size", "chunk_size", "prefix_len", "stride", "keep_per_block", "old_budget"):
+        assert (-1 if res[k2] is None else res[k2]) == int(g[f"B.{method}.{k2}"][0]), k2
+    assert rec.calls == [tuple(c) for c in g[f"B.{method}.calls"].tolist()], method
+
+
+def test_generate_functions_equal_the_reference_run(g9_rig):
+    from tests.conftest import load_golden
+    g = load_golden("g9_benchmarker.npz")
+    bm, _ = g9_rig
+    for i, p in enumerate(str(p) for p in g["prompts"]):
+        for mode in ("int8", "int4", "mixed"):
+            _, n_new, est_mb = bm.generate_with_quantized_kv(p, 12, mode=mode)
+            assert [n_new, est_mb] == g[f"B.generate_with_quantized_kv.{mode}.{i}"].tolist(), (mode, i)
+        _, n_new, est_mb = bm.generate_with_chunked_cache(p, 12, chunk_size=4, keep_last=6)
+        assert [n_new, est_mb] == g[f"B.generate_with_chunked_cache.{i}"].tolist(), i
+        _, n_new, alloc_mb, used_mb, nblocks = bm.generate_with_paged_attention(p, 12, block_size=4)
+        r_new, r_alloc, r_used, r_blocks = g[f"B.generate_with_paged_attention.{i}"].tolist()
+        assert [n_new, alloc_mb, used_mb, nblocks] == [r_new, r_alloc / 2, r_used / 2, r_blocks], i  # fp16 blocks on "cuda" (reference :521)

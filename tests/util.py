@@ -75,3 +75,33 @@ class tunables:
             _lib.set_tunable(k, v)
         self.old = {}
         return False
+
+
+class CallRecorder:
+    """The model as a benchmarker calls it, noting (tokens fed, cache length seen) per forward — how
+    tests/golden/make_golden.py::gen_benchmarker recorded the REFERENCE's loops (g9_benchmarker.npz ``*.calls``)."""
+
+    def __init__(self, model):
+        self.__dict__["m"] = model
+        self.__dict__["calls"] = []
+
+    def __getattr__(self, name):
+        return getattr(self.__dict__["m"], name)
+
+    def __call__(self, *a, **kw):
+        past = kw.get("past_key_values")
+        plen = 0
+        if past is not None:
+            plen = int(past.get_seq_length()) if hasattr(past, "get_seq_length") else int(past[0][0].size(2))
+        self.calls.append((int(kw["input_ids"].shape[-1]), plen))
+        return self.__dict__["m"](*a, **kw)
+
+
+def value_kinds(d) -> str:
+    """one letter per dict value: n None, a NaN, f float, i int, s str (the fixture's ``*.kinds``)"""
+    import math
+    out = []
+    for v in d.values():
+        out.append("n" if v is None else "s" if isinstance(v, str) else "i" if isinstance(v, (int, np.integer)) and not isinstance(v, bool)
+                   else "a" if isinstance(v, float) and math.isnan(v) else "f")
+    return "".join(out)
