@@ -89,7 +89,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="llama3_8b_mixed_seq16k",
                     help="one of %s, or decode:<arch>:<method>[:<prompt_tokens>:<new_tokens>] "
-                         "(e.g. decode:gpt2:quant_int8:512:512; steps = prompts per rank)" % sorted(list(WORKLOADS) + list(ATTN) + list(EVICT) + list(SHARDQ)))
+                         "(e.g. decode:gpt2:quant_int8:512:512; steps = prompts per rank), or shape:<%s>" % (sorted(list(WORKLOADS) + list(ATTN) + list(EVICT) + list(SHARDQ)), "|".join(SHAPE_RECORDS)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subrecords", action="store_true",
                     help="headline workload only: skip the decode / configs / sharded_quant sub-records of the default line "
@@ -794,6 +794,12 @@ def main():
             run_evict(args, rank, world, dev)
         elif args.workload in SHARDQ:
             run_sharded_quant(args, rank, world, dev)
+        elif args.workload.startswith("shape:") and args.workload[6:] in SHAPE_RECORDS:  # one sub-record on its own (profiling)
+            rec = measure_shape(args.workload[6:], dev, rank, iters=max(4, args.steps))
+            if rank == 0:
+                print(json.dumps({"metric": "per-shape dequantise / quantise rooflines", "value": rec["roofline"]["achieved"], "unit": "GB/s",
+                                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+                                  "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": args.workload}, **rec}), flush=True)
         elif args.workload in WORKLOADS:
             run_dequant(args, rank, world, dev, backend)
         else:

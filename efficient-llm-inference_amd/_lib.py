@@ -37,6 +37,7 @@ EXPORTS = (
     "kvq_quant_i8_tokens",
     "kvq_quant_i4_tokens",
     "kvq_absmax_tokens",
+    "kvq_absmax_tokens_acc",
     "kvq_quant_tokens_from_absmax",
     "kvq_window_compact",
     "kvq_chunk_meanpool",
@@ -104,8 +105,10 @@ def _declare(lib):
         f = getattr(lib, name)
         f.restype = c_int
         f.argtypes = [P, POINTER(c_void_p), ST, c_int, P, ST, P, c_int64, P, c_float, DM, P]
-    lib.kvq_absmax_tokens.restype = c_int
-    lib.kvq_absmax_tokens.argtypes = [P, POINTER(c_void_p), ST, c_int, P, DM, P]
+    for name in ("kvq_absmax_tokens", "kvq_absmax_tokens_acc"):
+        f = getattr(lib, name)
+        f.restype = c_int
+        f.argtypes = [P, POINTER(c_void_p), ST, c_int, P, DM, P]
     lib.kvq_quant_tokens_from_absmax.restype = c_int
     lib.kvq_quant_tokens_from_absmax.argtypes = [c_int, P, POINTER(c_void_p), ST, c_int, P, ST, P, c_int64, P, c_float, DM, P]
     lib.kvq_window_compact.restype = c_int

@@ -55,6 +55,7 @@ struct QuantArgs {
   int32_t nv;        // vectors per lane per tile (8, or 4 for the small one-wave tile)
   int32_t bh_contig; // rows addressable as r * stride_h on both sides
   uint32_t xcd_group;  // consecutive tiles per XCD for the fused one-tile kernel (0 / 1 = round robin)
+  int32_t acc;         // abs-max phase: keep what the table already holds (max with it) instead of overwriting
 };
 
 // ---------------------------------------------------------------------------- fused single pass
@@ -722,7 +723,11 @@ __global__ __launch_bounds__(kBlock) void absmax_tokens_tile_k(const QuantArgs a
   m = group_umax(m, a.dvshift);
   if (ok && (wv & ((1u << a.dvshift) - 1u)) == 0u) atomicMax(&s_amax[tl], m);
   __syncthreads();
-  if (tid < a.TT && t0 + tid < a.T) a.absmax_ws[(int64_t)g * a.T + t0 + tid] = Vec8<IDT>::bits_to_f32(s_amax[tid]);
+  if (tid < a.TT && t0 + tid < a.T) {
+    float* dst = a.absmax_ws + (int64_t)g * a.T + t0 + tid;
+    const float v = Vec8<IDT>::bits_to_f32(s_amax[tid]);
+    *dst = a.acc ? fmaxf(*dst, v) : v;  // the tile's tokens are nobody else's: no atomic needed
+  }
 }
 
 template <int IDT, int BITS>
@@ -1146,7 +1151,7 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
 template <int PHASE>
 static int split_phase(const char* name, int bits, const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st,
                        int in_dtype, uint8_t* q, const kvq_strides_t* q_st, float* scales, int64_t ssg, float* absmax,
-                       float eps, const kvq_dims_t* d, void* stream) {
+                       float eps, const kvq_dims_t* d, void* stream, bool accumulate = false) {
   if (!in_st || !d || !absmax || (!in_base && !in_ptrs) || (PHASE == 2 && (!q || !q_st || !scales))) {
     set_error("%s: NULL argument", name);
     return KVQ_E_NULL;
@@ -1172,6 +1177,7 @@ static int split_phase(const char* name, int bits, const void* in_base, const vo
   if (d->G * d->B * d->H * d->T * d->D == 0) return 0;
   const int esz = in_dtype == KVQ_F32 ? 4 : 2;
   QuantArgs a = {};
+  a.acc = accumulate ? 1 : 0;
   a.is = to_strides(in_st);
   if (PHASE == 2) a.qs = to_strides(q_st);
   a.ssg = ssg;
@@ -1204,7 +1210,7 @@ static int split_phase(const char* name, int bits, const void* in_base, const vo
     ta.T = (uint32_t)d->T;
     ta.rows = (uint32_t)Rt;
     ta.eps = eps;
-    if (PHASE == 1 && hipMemsetAsync(absmax, 0, sizeof(float) * (size_t)(d->G * d->T), st) != hipSuccess) return check_launch(name);
+    if (PHASE == 1 && !accumulate && hipMemsetAsync(absmax, 0, sizeof(float) * (size_t)(d->G * d->T), st) != hipSuccess) return check_launch(name);
     for (int64_t g0 = 0; g0 < d->G; g0 += kPtrsPerLaunch) {
       const int64_t gn = d->G - g0 < kPtrsPerLaunch ? d->G - g0 : kPtrsPerLaunch;
       for (int64_t i = 0; i < gn; ++i)
@@ -1265,7 +1271,7 @@ static int split_phase(const char* name, int bits, const void* in_base, const vo
                      KVQ_LAUNCH((absmax_tokens_tile_k<KVQ_BF16>), grid, dim3(kBlock), 0, st, a),
                      KVQ_LAUNCH((absmax_tokens_tile_k<KVQ_F32>), grid, dim3(kBlock), 0, st, a))
       } else {
-        if (hipMemsetAsync(a.absmax_ws, 0, sizeof(float) * (size_t)(gn * d->T), st) != hipSuccess) return check_launch(name);
+        if (!accumulate && hipMemsetAsync(a.absmax_ws, 0, sizeof(float) * (size_t)(gn * d->T), st) != hipSuccess) return check_launch(name);
         const int64_t RD = (int64_t)a.R * a.D, chunk_elems = (int64_t)kBlock * 16;
         const uint32_t cpt = (uint32_t)((RD + chunk_elems - 1) / chunk_elems);
         const dim3 ggrid((unsigned)(a.T * cpt), (unsigned)gn);
@@ -1329,6 +1335,12 @@ int kvq_absmax_tokens(const void* in_base, const void* const* in_ptrs, const kvq
                       float* absmax, const kvq_dims_t* dims, void* stream) {
   return split_phase<1>("kvq_absmax_tokens", 8, in_base, in_ptrs, in_st, in_dtype, nullptr, nullptr, nullptr, 0, absmax, 0.0f,
                         dims, stream);
+}
+
+int kvq_absmax_tokens_acc(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st, int in_dtype,
+                          float* absmax, const kvq_dims_t* dims, void* stream) {
+  return split_phase<1>("kvq_absmax_tokens_acc", 8, in_base, in_ptrs, in_st, in_dtype, nullptr, nullptr, nullptr, 0, absmax, 0.0f,
+                        dims, stream, true);
 }
 
 int kvq_quant_tokens_from_absmax(int bits, const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st,

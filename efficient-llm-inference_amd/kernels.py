@@ -92,19 +92,25 @@ def quant_tokens(x: TensorOrList, q: torch.Tensor, scales: torch.Tensor, absmax_
     check(rc, f"quant_tokens[{kind}]")
 
 
-def absmax_tokens(x: TensorOrList, out: torch.Tensor = None) -> torch.Tensor:
+def absmax_tokens(x: TensorOrList, out: torch.Tensor = None, accumulate: bool = False) -> torch.Tensor:
     """Phase 1 of the sharded-batch quantise (kvq_absmax_tokens): ``[G,T]`` fp32 table of
     ``max |x[g, :, :, t, :]|`` over THIS rank's batch rows; returns ``out`` (allocated when None).
+    ``accumulate``: ``out`` already holds non-negative values and the result is the max with them
+    (kvq_absmax_tokens_acc: no fill launch; the caller zeroed the table, e.g. once for a layer-chunked pass).
     Reference: the ``x32.abs().max()`` of quantize_int8 / int4_per_tensor (ops.py:27,48) before it is
     completed across ranks by ``sharding.all_reduce_absmax``."""
     base, arr, ist, (G, B, H, T, D), dt, dev, _keep = _in_views(x)
     if out is None:
+        if accumulate:
+            raise _lib.KvqError("kvq: absmax_tokens(accumulate=True) needs the table to accumulate into")
         out = torch.empty(G, T, dtype=torch.float32, device=dev)
     require_gpu(out, "absmax")
     if tuple(out.shape) != (G, T) or out.dtype != torch.float32 or not out.is_contiguous():
         raise _lib.KvqError(f"kvq: absmax table must be contiguous fp32 {(G, T)}")
-    check(_lib.load().kvq_absmax_tokens(base, arr, byref(ist), dtype_code(dt), c_void_p(out.data_ptr()),
-                                        byref(dims5(G, B, H, T, D)), _lib.current_stream(dev)), "absmax_tokens")
+    lib = _lib.load()
+    fn = lib.kvq_absmax_tokens_acc if accumulate else lib.kvq_absmax_tokens
+    check(fn(base, arr, byref(ist), dtype_code(dt), c_void_p(out.data_ptr()), byref(dims5(G, B, H, T, D)), _lib.current_stream(dev)),
+          "absmax_tokens")
     return out
 
 

@@ -314,8 +314,9 @@ def quantize_tokens_batch_sharded(x_local, kind: str, eps: float = 1e-8, out: "S
         K.quant_tokens_with_absmax(x_local[g0:g1], out.absmax[g0:g1], kind, eps, q=out.q[g0:g1], scales=out.scales[g0:g1])
 
     pending = None  # chunk whose table is being reduced while the next chunk's abs-max runs
+    out.absmax.zero_()  # ONE fill for the whole pass; every chunk's abs-max launch accumulates into its slice
     for c, (g0, g1) in enumerate(out.chunks):
-        K.absmax_tokens(x_local[g0:g1], out.absmax[g0:g1])
+        K.absmax_tokens(x_local[g0:g1], out.absmax[g0:g1], accumulate=True)
         if ws == 1 and not out.overlap:
             quant(c)
             continue

@@ -135,6 +135,12 @@ int kvq_quant_i4_tokens(const void* in_base, const void* const* in_ptrs, const k
 int kvq_absmax_tokens(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st, int in_dtype,
                       float* absmax, const kvq_dims_t* dims, void* stream);
 
+/* kvq_absmax_tokens without the fill: absmax[g*T + t] = max(absmax[g*T + t], max |x| over this rank's [B_local,H,D]).
+ * The caller initialises the table (non-negative values; zeros for a plain abs-max): a layer-chunked pass zeroes its
+ * whole [G,T] table with ONE fill instead of one per chunk (a fill is a launch: 4.5 us each on MI355X). */
+int kvq_absmax_tokens_acc(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st, int in_dtype,
+                          float* absmax, const kvq_dims_t* dims, void* stream);
+
 /* bits: 8 (int8 store, strides in bytes = elements) or 4 (packed store, (D+1)/2 bytes per row). */
 int kvq_quant_tokens_from_absmax(int bits, const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st,
                                  int in_dtype, uint8_t* q, const kvq_strides_t* q_st, float* scales,

@@ -101,6 +101,13 @@ def test_split_phases_equal_fused_kernels(shape, dtype):
     x = to_torch(x_np, dtype)
     amax = K.absmax_tokens(x)
     assert np.array_equal(bits(amax), bits(O.absmax_tokens(x_np, odt(dtype))))
+    # kvq_absmax_tokens_acc: no fill launch, the result is the max with what the caller's table holds
+    acc = torch.zeros_like(amax)
+    K.absmax_tokens(x, acc, accumulate=True)
+    assert torch.equal(acc, amax)
+    floor = torch.full_like(amax, float(amax.median()))
+    K.absmax_tokens(x, floor, accumulate=True)
+    assert torch.equal(floor, torch.maximum(amax, torch.full_like(amax, float(amax.median()))))
     for kind in ("int8", "int4"):
         q_ref, _, s32_ref = O.quantize_tokens(x_np, kind, dtype=odt(dtype))
         for src in (x, [x[g] for g in range(G)] if G <= 256 else x):
