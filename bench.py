@@ -204,9 +204,10 @@ def cpu_baseline(L, B, H, T, D, sample_layers, reps=5, gpu_check=None):
                   cat (oracle/literal_loop.py), torch-CPU, every host core
     plus the two eviction ops as the reference writes them (whole-tensor torch ops) on one [B,H,T,D] tensor.
     The top-level value / cores / kind / sample are the port's dequantise figure.
-    gpu_check: (q uint8 [1,B,H,T,D/2], scales f32 [1,T], out f16 [1,B,H,T,D]) host copies of one layer of what the
-    GPU dequantised in this run: the port dequantises the same bytes and the largest relative difference is reported
-    (`max_rel_err_vs_gpu`, expected 0.0 — the accuracy gate of SURVEY §8d)."""
+    gpu_check: host copies of layer 0 as the GPU quantised / dequantised / evicted it in this run (x_k, q_k, s_k, out_k, the
+    same for v, evict_x / evict_pool / evict_window, kinds): the port recomputes every op from the same bytes and reports
+    bit-exactness and the largest relative difference per op (`parity`; `max_rel_err_vs_gpu` = the INT4 dequantise's —
+    the accuracy gate of SURVEY §8d, expected 0.0)."""
     import numpy as np
     import torch as _t
     from oracle import c_oracle as C
@@ -236,14 +237,36 @@ def cpu_baseline(L, B, H, T, D, sample_layers, reps=5, gpu_check=None):
             "quantise_sample": f"fp16->INT4 per-token quantise of {nq_layers}/{L} layers ({nq} elements, median {dq_s:.3f} s)",
             "int8": {"dequantise_value": gbps(nq, d8, "int8"), "quantise_value": gbps(nq, dq8, "int8"),
                      "sample": f"{nq_layers}/{L} layers of the K set ({nq} elements; medians {d8:.3f} / {dq8:.3f} s)"}}
+    parity = None
     if gpu_check is not None:
-        gq, gs, gout = gpu_check
-        ref16 = C.dequantize_tokens(gq, gs, "int4", D, "f16")
-        ref, got = ref16.astype(np.float32), gout.astype(np.float32)
-        denom = np.maximum(np.abs(ref), np.float32(1e-30))
-        port["max_rel_err_vs_gpu"] = float(np.max(np.abs(got - ref) / denom))
-        port["max_rel_err_sample"] = (f"layer 0 of the V set as the GPU dequantised it in this run ({got.size} elements); bit patterns equal: "
-                                      f"{bool(np.array_equal(gout.view(np.uint16), ref16.view(np.uint16)))}")
+        # SURVEY §8d's accuracy gate, op by op: what the GPU produced in this run for layer 0 against the port on the same
+        # bytes (expected: bit-exact everywhere; max_rel_err is over the dequantised / pooled values)
+        from oracle import kvq_oracle as O
+
+        def rel(got, ref):
+            g32, r32 = got.astype(np.float32), ref.astype(np.float32)
+            return float(np.max(np.abs(g32 - r32) / np.maximum(np.abs(r32), np.float32(1e-30))))
+
+        parity = {}
+        for name, kind in (("k", gpu_check["kinds"][0]), ("v", gpu_check["kinds"][1])):
+            x, gq, gs, gout = (gpu_check[f"{key}_{name}"] for key in ("x", "q", "s", "out"))
+            rq, rs = C.quantize_tokens(x, kind)
+            rdq = C.dequantize_tokens(gq, gs, kind, D, "f16")
+            parity[f"quantise_{kind}"] = {"bit_exact": bool(np.array_equal(rq.view(np.uint8), gq.view(np.uint8)) and np.array_equal(rs.view(np.uint32), gs.view(np.uint32))),
+                                          "max_rel_err": rel(C.dequantize_tokens(rq, rs, kind, D, "f16"), rdq)}
+            parity[f"dequantise_{kind}"] = {"bit_exact": bool(np.array_equal(gout.view(np.uint16), rdq.view(np.uint16))), "max_rel_err": rel(gout, rdq)}
+        xe = gpu_check["evict_x"]
+        rp = O.chunk_summarize_kv(xe, 64, 256)
+        parity["chunk_summarize_kv"] = {"bit_exact": bool(np.array_equal(gpu_check["evict_pool"].view(np.uint16), rp.view(np.uint16))),
+                                        "max_rel_err": rel(gpu_check["evict_pool"], rp)}
+        rw = O.trim_kv_sliding_window(xe, 256)
+        parity["trim_kv_sliding_window"] = {"bit_exact": bool(np.array_equal(gpu_check["evict_window"].view(np.uint16), rw.view(np.uint16))),
+                                            "max_rel_err": rel(gpu_check["evict_window"], rw)}
+        parity["sample"] = (f"layer 0 of the K and V sets as the GPU quantised / dequantised them in this run ({gpu_check['x_k'].size} elements each), "
+                            f"eviction on its first {xe.shape[-2]} tokens; reference = oracle/kvq_oracle.c / kvq_oracle.py")
+        vk = gpu_check["kinds"][1]
+        port["max_rel_err_vs_gpu"] = parity[f"dequantise_{vk}"]["max_rel_err"]
+        port["max_rel_err_sample"] = parity["sample"]
 
     # ---- vectorised: whole-tensor torch-CPU, all cores ------------------------------------------
     _t.set_num_threads(cores)
@@ -253,10 +276,14 @@ def cpu_baseline(L, B, H, T, D, sample_layers, reps=5, gpu_check=None):
     dv = _median_time(lambda: VT.dequantize_tokens(qv, sv, "int4", D, _t.float16), reps)
     dvq = _median_time(lambda: VT.quantize_tokens(xv, "int4"), reps)
     nvv = nv_layers * B * H * T * D
+    qv8, sv8 = VT.quantize_tokens(xv, "int8")
+    dv8 = _median_time(lambda: VT.dequantize_tokens(qv8, sv8, "int8", D, _t.float16), max(2, reps // 2))
+    dvq8 = _median_time(lambda: VT.quantize_tokens(xv, "int8"), max(2, reps // 2))
     vect = {"value": gbps(nvv, dv), "unit": "GB/s", "cores": cores, "reps": reps, "kind": "port",
             "sample": f"INT4->fp16 dequantise of {nv_layers}/{L} layers [{nv_layers},{B},{H},{T},{D}] as whole-tensor "
                       f"torch-CPU ops ({nvv} elements, median {dv:.3f} s), oracle/vectorised_torch.py",
             "quantise_value": gbps(nvv, dvq), "quantise_sample": f"same tensors, fp16->INT4 (median {dvq:.3f} s)",
+            "int8": {"dequantise_value": gbps(nvv, dv8, "int8"), "quantise_value": gbps(nvv, dvq8, "int8")},
             "torch_threads": _t.get_num_threads()}
 
     # ---- literal: the reference's per-slice loop, sub-sampled in T -------------------------------
@@ -266,7 +293,11 @@ def cpu_baseline(L, B, H, T, D, sample_layers, reps=5, gpu_check=None):
     dl = _median_time(lambda: LL.dequantize_slices(qs, ss, "int4", D, _t.float16), reps)
     dlq = _median_time(lambda: LL.quantize_slices(xl, "int4"), reps)
     n_lit = B * H * Ts * D
+    qs8, ss8 = LL.quantize_slices(xl, "int8")
+    dl8 = _median_time(lambda: LL.dequantize_slices(qs8, ss8, "int8", D, _t.float16), max(2, reps // 2))
+    dlq8 = _median_time(lambda: LL.quantize_slices(xl, "int8"), max(2, reps // 2))
     lit = {"value": gbps(n_lit, dl), "unit": "GB/s", "cores": cores, "reps": reps, "kind": "port",
+           "int8": {"dequantise_value": gbps(n_lit, dl8, "int8"), "quantise_value": gbps(n_lit, dlq8, "int8")},
            "sample": f"per-slice dequantise + {Ts}-way cat of one layer's V [{B},{H},{Ts},{D}] (T sub-sampled {Ts}/{T}; the "
                      f"loop is linear in T) with torch-CPU ops (median {dl:.3f} s), oracle/literal_loop.py",
            "quantise_value": gbps(n_lit, dlq), "quantise_sample": f"same slices, per-slice fp16->INT4 (median {dlq:.3f} s)",
@@ -286,7 +317,8 @@ def cpu_baseline(L, B, H, T, D, sample_layers, reps=5, gpu_check=None):
                        f"oracle/vectorised_torch.py"}
     out = {"value": port["value"], "unit": "GB/s", "cores": 1, "kind": "port", "sample": port["sample"], "reps": reps,
            "host_cores_available": cores, "port": port, "vectorised": vect, "literal": lit, "eviction": evict}
-    if "max_rel_err_vs_gpu" in port:
+    if parity is not None:
+        out["parity"] = parity
         out["max_rel_err_vs_gpu"] = port["max_rel_err_vs_gpu"]
     return out
 
@@ -955,12 +987,22 @@ def run_dequant(args, rank, world, dev, backend):
     del pkv
 
     gpu_check = None
-    if rank == 0 and not args.no_cpu_baseline and world == 1:  # one layer of what the GPU just dequantised, for the port to check
+    if rank == 0 and not args.no_cpu_baseline and world == 1:  # layer 0 of what the GPU just produced, for the port to check
         c0 = caches[0]
+        c0._k.dequant(torch.float16, out=outs[0][0])
         c0._v.dequant(torch.float16, out=outs[0][1])
+        Te = min(T, 4096)
+        xe = past[0][0][:, :, :Te].contiguous()
+        (pool_k, _), = E.chunk_summarize_kv(((xe, xe),), chunk_size=64, keep_last=256)
+        (win_k, _), = E.trim_kv_sliding_window(((xe, xe),), 256)
         torch.cuda.synchronize()
-        gpu_check = (c0._v.q[:1, :, :, :T].contiguous().cpu().numpy(), c0._v.scales[:1, :T].contiguous().cpu().numpy(),
-                     outs[0][1][:1].cpu().numpy())
+        host = lambda t: t.contiguous().cpu().numpy()  # noqa: E731
+        gpu_check = {"kinds": (kk, vk), "evict_x": host(xe), "evict_pool": host(pool_k), "evict_window": host(win_k)}
+        for name, st_, o, xsrc in (("k", c0._k, outs[0][0], past[0][0]), ("v", c0._v, outs[0][1], past[0][1])):
+            gpu_check[f"x_{name}"] = host(xsrc)[None]
+            gpu_check[f"q_{name}"] = host(st_.q[:1, :, :, :T])
+            gpu_check[f"s_{name}"] = host(st_.scales[:1, :T])
+            gpu_check[f"out_{name}"] = host(o[:1])
 
     line = None
     if rank == 0:

@@ -344,6 +344,14 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
 // ragged last tile costs nothing: lanes of tokens past T carry an out-of-range offset (loads return 0, which cannot
 // raise an abs-max; stores are dropped), so ONE instantiation serves complete and ragged tiles.
 // Same arithmetic, same order of operations per element as quant_tokens_fused_k (quotient_bits8 / pack_*): bit-identical.
+// cache-policy bits of the tile kernel's row loads / output stores (buffer aux immediate: 1 = sc0, 2 = nt, 16 = sc1).
+// What ships is nt for both; `make calib_aux` builds the other combinations for A-B runs (profiles/r03f_*).
+#ifndef KVQ_TILE_LD_AUX
+#define KVQ_TILE_LD_AUX 2
+#endif
+#ifndef KVQ_TILE_ST_AUX
+#define KVQ_TILE_ST_AUX 2
+#endif
 struct QuantTileArgs {
   PtrTable in;      // per-group input base pointers
   uint8_t* q;       // store base of this launch's first group
@@ -396,7 +404,7 @@ __global__ __launch_bounds__(kWave) void quant_tile_k(const QuantTileArgs a) {
   Vec8<IDT> x[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i)
-    x[i].w = __builtin_amdgcn_raw_buffer_load_b128(irs, ioff, (uint32_t)(i * RPI) * a.is_h, PHASE == 1 ? 0 : 2 /* non-temporal */);
+    x[i].w = __builtin_amdgcn_raw_buffer_load_b128(irs, ioff, (uint32_t)(i * RPI) * a.is_h, PHASE == 1 ? 0 : KVQ_TILE_LD_AUX /* non-temporal */);
 
   constexpr int DVSH = DV == 16 ? 4 : 3;
   float s32;
@@ -444,7 +452,7 @@ __global__ __launch_bounds__(kWave) void quant_tile_k(const QuantTileArgs a) {
   for (int j = 0; j < NST; ++j) {
     const u32x4 w = *reinterpret_cast<const u32x4*>(&s_out[j * 256 + lane * 4]);
     const uint32_t off = (OUTB % 1024 == 0 || (uint32_t)j * 1024u + lane * 16u < (uint32_t)OUTB) ? ooff : kOut;
-    __builtin_amdgcn_raw_buffer_store_b128(w, ors, off, (uint32_t)(j * (1024 / ROWB)) * a.qs_h, 2 /* non-temporal */);
+    __builtin_amdgcn_raw_buffer_store_b128(w, ors, off, (uint32_t)(j * (1024 / ROWB)) * a.qs_h, KVQ_TILE_ST_AUX /* non-temporal */);
   }
 }
 

@@ -27,7 +27,30 @@ def test_cpu_baseline_leg():
     for leg in ("port", "vectorised", "literal"):  # the three CPU figures, each with cores + reps
         assert cb[leg]["value"] > 0 and cb[leg]["cores"] >= 1 and cb[leg]["reps"] >= 2, leg
     assert cb["vectorised"]["cores"] == (os.cpu_count() or 1)
+    assert cb["eviction"]["pool_value"] > 0 and cb["eviction"]["window_value"] > 0 and cb["vectorised"]["int8"]["quantise_value"] > 0
     json.dumps(cb)
+    # the per-op parity section: handed what a correct GPU run would hand it (here: the oracle's own outputs), every op
+    # reports bit-exact; one flipped output byte is seen
+    import numpy as np
+    from oracle import c_oracle as C
+    from oracle import kvq_oracle as O
+    rng = np.random.default_rng(3)
+    B, H, T, D = 1, 2, 512, 64
+    chk = {"kinds": ("int8", "int4")}
+    for name, kind in (("k", "int8"), ("v", "int4")):
+        x = rng.standard_normal((1, B, H, T, D), dtype=np.float32).astype(np.float16)
+        q, sc = C.quantize_tokens(x, kind)
+        chk.update({f"x_{name}": x, f"q_{name}": q, f"s_{name}": sc, f"out_{name}": C.dequantize_tokens(q, sc, kind, D, "f16")})
+    xe = chk["x_k"][0]
+    chk.update(evict_x=xe, evict_pool=O.chunk_summarize_kv(xe, 64, 256), evict_window=O.trim_kv_sliding_window(xe, 256))
+    cb = bench.cpu_baseline(L=1, B=B, H=H, T=T, D=D, sample_layers=1, reps=2, gpu_check=chk)
+    ops = [k for k in cb["parity"] if k != "sample"]
+    assert sorted(ops) == ["chunk_summarize_kv", "dequantise_int4", "dequantise_int8", "quantise_int4", "quantise_int8", "trim_kv_sliding_window"]
+    assert all(cb["parity"][k]["bit_exact"] and cb["parity"][k]["max_rel_err"] == 0.0 for k in ops) and cb["max_rel_err_vs_gpu"] == 0.0
+    chk["out_v"] = chk["out_v"].copy()
+    chk["out_v"].view(np.uint16)[0, 0, 0, 3, 5] ^= 1
+    cb = bench.cpu_baseline(L=1, B=B, H=H, T=T, D=D, sample_layers=1, reps=2, gpu_check=chk)
+    assert not cb["parity"]["dequantise_int4"]["bit_exact"] and cb["parity"]["dequantise_int4"]["max_rel_err"] > 0
 
 
 def test_bench_refuses_without_gpu():
@@ -121,4 +144,5 @@ def test_bench_line_carries_the_contract_fields(tmp_path):
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
     assert c["max_rel_err_vs_gpu"] == 0.0 and c["eviction"]["pool_value"] > 0
+    assert all(v["bit_exact"] and v["max_rel_err"] == 0.0 for k, v in c["parity"].items() if k != "sample"), c["parity"]
     assert j["run_s"] < 200

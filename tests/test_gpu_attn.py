@@ -434,7 +434,7 @@ LDS_CASES = [(1, 32, 8, 1000, 128), (2, 6, 2, 200, 128), (1, 16, 1, 300, 128), (
 
 
 @pytest.mark.parametrize("which", [1, pytest.param(2, marks=pytest.mark.ab)])
-@pytest.mark.parametrize("tpw", [0, 1, 2, 3, 5, 9])
+@pytest.mark.parametrize("tpw", [0, 1, 3, 9])
 def test_decode_attn_lds_staged_kernel(K, tunable, tpw, which):
     """decode_attn_lds_mfma_k (a tile = whole 1 KiB LDS-DMA requests into a ring of LDS slots, operand fragments read
     back from the XOR-swizzled image): forced on small shapes through attn_stream_tpw — against the oracle for every
@@ -445,10 +445,12 @@ def test_decode_attn_lds_staged_kernel(K, tunable, tpw, which):
     tunable("attn_stream_tpw", tpw)
     tunable("attn_lds", which)
     for case in LDS_CASES:
-        for kinds in (("int8", "int4"), ("int4", "int8"), ("int8", "int8"), ("int4", "int4")):
+        big = case[0] * case[3] > 20000  # the batch-8 case: the float64 oracle on the host is what takes the time
+        for kinds in (("int8", "int4"),) if big else (("int8", "int4"), ("int4", "int8"), ("int8", "int8"), ("int4", "int4")):
             _run_case(K, *case, kinds[0], kinds[1], "f16", True)
-        _run_case(K, *case, "int8", "int4", "bf16", True)
-        _run_case(K, *case, "int8", "int4", "f16", False)
+        if not big:
+            _run_case(K, *case, "int8", "int4", "bf16", True)
+            _run_case(K, *case, "int8", "int4", "f16", False)
     if tpw:
         _lib.kernel_log_clear()
         _run_case(K, 2, 32, 8, 1500, 128, "int8", "int4", "f16", True)
