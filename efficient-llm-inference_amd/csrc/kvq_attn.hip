@@ -231,10 +231,13 @@ __device__ inline float wave_fmax(float v) {
   v = fmaxf(v, __uint_as_float(dpp_u32_attn<0x140>(__float_as_uint(v))));  // row_mirror
   return xor32_max(xor16_max(v));
 }
+// sum over the wave, in every lane (same exchanges as wave_fmax: no LDS round trips; every lane adds in the same order)
 __device__ inline float wave_fsum(float v) {
-#pragma unroll
-  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
-  return v;
+  v += __uint_as_float(dpp_u32_attn<0xB1>(__float_as_uint(v)));
+  v += __uint_as_float(dpp_u32_attn<0x4E>(__float_as_uint(v)));
+  v += __uint_as_float(dpp_u32_attn<0x141>(__float_as_uint(v)));
+  v += __uint_as_float(dpp_u32_attn<0x140>(__float_as_uint(v)));
+  return xor32_add(xor16_add(v));
 }
 
 // Workgroup timeline (one round trip to HBM on the critical path when TS == TL * kAttnUnroll):
@@ -771,11 +774,19 @@ struct AttnTile {
   for (int i = 0; i < NT; ++i) {
     const f32x4 ks = *reinterpret_cast<const f32x4*>(&s_ks[16 * i + 4 * g]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      sc[i][r] *= ks[r];
-      if (!full && (uint32_t)(16 * i + 4 * g + r) >= nt) sc[i][r] = -INFINITY;
-      m = fmaxf(m, sc[i][r]);
-    }
+    for (int r = 0; r < 4; ++r) sc[i][r] *= ks[r];
+  }
+  if (!full) {  // uniform: only a ragged last tile pays for the masks
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if ((uint32_t)(16 * i + 4 * g + r) >= nt) sc[i][r] = -INFINITY;
+  }
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m = fmaxf(m, sc[i][r]);
   }
   m = xor32_max(xor16_max(m));
   l = 0.0f;
@@ -1143,11 +1154,19 @@ struct AttnStream {
     for (int i = 0; i < NT; ++i) {
       const f32x4 ks = *reinterpret_cast<const f32x4*>(&s_ks[16 * i + 4 * g]);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        sc[i][q] *= ks[q];
-        if (!full && (uint32_t)(16 * i + 4 * g + q) >= nt) sc[i][q] = -INFINITY;
-        mt = fmaxf(mt, sc[i][q]);
-      }
+      for (int q = 0; q < 4; ++q) sc[i][q] *= ks[q];
+    }
+    if (!full) {  // uniform: only a ragged last tile pays for the masks
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if ((uint32_t)(16 * i + 4 * g + q) >= nt) sc[i][q] = -INFINITY;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mt = fmaxf(mt, sc[i][q]);
     }
     mt = xor32_max(xor16_max(mt));
     const float mnew = fmaxf(m, mt);                          // finite: every tile holds >= 1 token

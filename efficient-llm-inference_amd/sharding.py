@@ -254,9 +254,14 @@ def all_reduce_absmax(table: torch.Tensor, force: bool = False) -> torch.Tensor:
     return table
 
 
-# A layer chunk's input should still be in the 256 MiB Infinity Cache when the quantise phase re-reads it, with the next
-# chunk's abs-max pass (which overlaps this chunk's all_reduce) already streaming through: two chunks + their output.
-CHUNK_BYTES = 64 << 20
+# Layer chunks exist to put chunk i's all_reduce(MAX) under chunk i + 1's abs-max pass; each chunk costs three launches
+# (abs-max, collective, quantise). Round 3 first sized them to the 256 MiB Infinity Cache (<= 64 MiB of local input, so
+# that the quantise phase's re-read would be served from it): measured on one MI355X the re-read runs at HBM speed all
+# the same (19.0 us for the INT8 phase of a 64 MiB chunk = 5.3 TB/s of its 100.9 MB; profiles/r03p_*), and the 64
+# short launches per set cost more than they save — so: ONE chunk on a single rank (nothing to overlap), CHUNKS_PER_SET
+# chunks when a collective has to hide. KVQ_SHARD_CHUNK_BYTES overrides (A-B runs).
+CHUNKS_PER_SET = 4
+CHUNK_BYTES = int(os.environ.get("KVQ_SHARD_CHUNK_BYTES", "0"))  # 0 = by rank count (above)
 
 
 class ShardedQuantBuffers:
@@ -265,7 +270,7 @@ class ShardedQuantBuffers:
     what crosses the ranks), the layer-chunk plan and — on more than one rank — the side stream and events that put
     chunk i's ``all_reduce(MAX)`` under chunk i + 1's abs-max pass. Built once per (shape, kind); reused every step."""
 
-    def __init__(self, x_local, kind: str, chunk_bytes: int = CHUNK_BYTES, force_overlap: bool = False):
+    def __init__(self, x_local, kind: str, chunk_bytes: int = None, force_overlap: bool = False):
         from . import kernels as K
         first = x_local[0]
         G = len(x_local)
@@ -276,10 +281,15 @@ class ShardedQuantBuffers:
         self.scales = torch.empty(G, T, dtype=torch.float32, device=dev)
         self.absmax = torch.empty(G, T, dtype=torch.float32, device=dev)
         per_group = max(1, B * H * T * D * first.element_size())
-        self.groups_per_chunk = max(1, min(G, chunk_bytes // per_group))
+        _, ws = world()
+        if chunk_bytes is None:
+            chunk_bytes = CHUNK_BYTES
+        if chunk_bytes > 0:
+            self.groups_per_chunk = max(1, min(G, chunk_bytes // per_group))
+        else:
+            self.groups_per_chunk = G if (ws == 1 and not force_overlap) else max(1, -(-G // CHUNKS_PER_SET))
         self.chunks = [(g0, min(G, g0 + self.groups_per_chunk)) for g0 in range(0, G, self.groups_per_chunk)]
         self.n_chunks = len(self.chunks)
-        _, ws = world()
         # force_overlap: take the side-stream path on ONE rank too (a 1-GPU box's only way to exercise it under RCCL)
         self.overlap = (ws > 1 or force_overlap) and dev.type == "cuda" and backend() == "nccl"
         if self.overlap:

@@ -457,6 +457,34 @@ def test_decode_attn_lds_staged_kernel(K, tunable, tpw, which):
         assert _lib.kernel_log()[0].startswith(("decode_attn_lds_mfma_k<8, 4, 64, true, 2>", "decode_attn_coal_mfma_k<")[which - 1]), _lib.kernel_log()
 
 
+def test_streaming_plan_rejected_falls_back_to_one_tile_splits(K, tunable):
+    """A forced one-tile-per-wave streaming plan needs T / 64 splits; beyond the merge kernels' 4096 the plan falls back
+    to one-tile splits of 128 tokens — and the launcher must take the kernel of THAT layout (round 2's launcher kept
+    the streaming kernel on the one-tile grid: tokens skipped or counted twice)."""
+    from efficient_llm_inference_amd import _lib
+    tunable("attn_stream_tpw", 1)
+    B, Hq, Hkv, T, D = 1, 4, 1, 262144 + 64 * 3 + 5, 128
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ks = torch.randint(-127, 128, (B, Hkv, T, D), device="cuda", dtype=torch.int8, generator=g)
+    vs = torch.randint(0, 256, (B, Hkv, T, D // 2), device="cuda", dtype=torch.uint8, generator=g)
+    ksc = torch.rand(T, device="cuda", generator=g) * 0.02 + 0.002
+    vsc = torch.rand(T, device="cuda", generator=g) * 0.3 + 0.01
+    q = torch.randn(B, Hq, D, device="cuda", dtype=torch.float16, generator=g)
+    out = torch.empty_like(q)
+    ws = torch.empty(K.decode_attn_workspace(B, Hq, Hkv, T, D), dtype=torch.float32, device="cuda")
+    _lib.kernel_log_clear()
+    K.decode_attn(q, ks, ksc, "int8", vs, vsc, "int4", T, out, ws, D ** -0.5)
+    assert _lib.kernel_log()[0].startswith("decode_attn_partial_mfma_k<8, 4, 128, 128"), _lib.kernel_log()
+    # float64 attention over the dequantised values, on the device
+    kf = ks[0, 0].double() * ksc.double()[:, None]
+    v8 = torch.stack([(vs[0, 0] >> 4).to(torch.int16), (vs[0, 0] & 15).to(torch.int16)], dim=-1).reshape(T, D) - 8
+    vf = v8.double() * vsc.double()[:, None]
+    p = torch.softmax((q[0].double() @ kf.T) * D ** -0.5, dim=-1)
+    ref = p @ vf
+    err = (out[0].double() - ref).abs()
+    assert bool((err <= 2e-3 * (ref.abs() + ref.abs().max())).all()), float(err.max())
+
+
 @pytest.mark.ab
 @pytest.mark.parametrize("which", [1, 2])
 @pytest.mark.parametrize("tpw", [1, 2, 3, 5, 9])
