@@ -1386,7 +1386,7 @@ __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_lds_mfma_
   constexpr int KOPS = TC * KROW / 1024, VOPS = TC * VROW / 1024;  // 1 KiB wave requests per tile
   constexpr int OPS = KOPS + VOPS + 2;                           // + the two scale rows
   constexpr int SLOT = TC * (KROW + VROW) + 512;                 // K image, V image, 64 + 64 scale floats
-  static_assert(OPS * (NB - 1) < 64, "the ring's requests must fit the vmcnt counter");
+  static_assert(NB >= 1 && OPS * (NB - 1) < 64, "the ring's requests must fit the vmcnt counter");
   extern __shared__ __attribute__((aligned(16))) uint8_t ring[];  // NB slots
   __shared__ __attribute__((aligned(16))) float s_ks[TC];
   __shared__ __attribute__((aligned(16))) float s_vs[TC];
@@ -1394,9 +1394,15 @@ __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_lds_mfma_
   const uint32_t lane = threadIdx.x, x = lane & 15u, g = lane >> 4;
   const uint32_t split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
   const uint32_t ntiles = (a.T + (uint32_t)TC - 1u) / (uint32_t)TC;
-  const uint32_t first = split * tpw;
-  const uint32_t last = first + tpw < ntiles ? first + tpw : ntiles;  // host: first < ntiles for every split
-  const uint32_t n = last - first;
+  // which tiles are this wave's: a contiguous run of tpw tiles (a.lds != 3), or every nsplit-th tile (a.lds == 3: the
+  // waves of a (batch row, kv head) then read ADJACENT tiles at about the same time, as neighbouring workgroups of the
+  // dequantise kernels do; the online softmax does not care about the order)
+  const bool strided = a.lds == 3u;
+  const uint32_t first = strided ? split : split * tpw;
+  const uint32_t step = strided ? a.nsplit : 1u;
+  uint32_t n;
+  if (strided) n = first < ntiles ? (ntiles - first + step - 1u) / step : 0u;
+  else n = (first + tpw < ntiles ? first + tpw : ntiles) - first;  // host: first < ntiles for every split
   const uint8_t* k_row0 = a.k + (int64_t)b * a.k_sb + (int64_t)hk * a.k_sh;
   const uint8_t* v_row0 = a.v + (int64_t)b * a.v_sb + (int64_t)hk * a.v_sh;
 
@@ -1411,7 +1417,7 @@ __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_lds_mfma_
   const uint32_t v_off = (lane / VCPR) * (uint32_t)a.v_st + ((lane % VCPR) << 4);
 
   auto request = [&](const uint32_t k) {  // tile k of this wave -> ring slot k % NB; nothing waits here
-    const uint32_t tt = first + (k < n ? k : 0u);
+    const uint32_t tt = first + (k < n ? k : 0u) * step;
     const uint32_t t0 = tt * (uint32_t)TC;
     const uint32_t cnt = k < n ? (a.T - t0 < (uint32_t)TC ? a.T - t0 : (uint32_t)TC) : 0u;  // 0: empty descriptors, no traffic
     uint8_t* slot = ring + (k % NB) * SLOT;
@@ -1430,19 +1436,24 @@ __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_lds_mfma_
   };
 
   ST st;
+  constexpr int PRE = NB > 1 ? NB - 1 : 1;  // tiles requested before the loop
 #pragma unroll
-  for (int k = 0; k < NB - 1; ++k) request((uint32_t)k);
+  for (int k = 0; k < PRE; ++k) request((uint32_t)k);
   st.init(a, b, hk);
   typename ST::Raw r;
   const typename ST::Src none = st.src(a, b, hk, 0u, 0u);
   for (uint32_t k = 0; k < n; ++k) {
-    // the slot tile k + NB - 1 goes to is the one tile k - 1 was read from: those reads have all been consumed
-    // (their values fed MFMAs of the previous iteration); the compiler is kept from moving anything across
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    request(k + (uint32_t)(NB - 1));
-    wait_vmcnt<OPS * (NB - 1)>();  // tile k has landed
+    if constexpr (NB > 1) {
+      // the slot tile k + NB - 1 goes to is the one tile k - 1 was read from: those reads have all been consumed
+      // (their values fed MFMAs of the previous iteration); the compiler is kept from moving anything across
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      request(k + (uint32_t)(NB - 1));
+      wait_vmcnt<OPS * (NB - 1)>();  // tile k has landed
+    } else {
+      wait_vmcnt<0>();  // ONE slot: tile k has landed; the next request goes out as soon as its bytes are in registers
+    }
     asm volatile("" ::: "memory");
-    const uint32_t t0 = (first + k) * (uint32_t)TC;
+    const uint32_t t0 = (first + k * step) * (uint32_t)TC;
     const uint32_t nt = a.T - t0 < (uint32_t)TC ? a.T - t0 : (uint32_t)TC;
     const uint8_t* slot = ring + (k % NB) * SLOT;
     read_fragments<KBITS, VBITS, TC, KI8>(slot, r);
@@ -1451,6 +1462,13 @@ __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_lds_mfma_
     const float ksv = sc[lane < (uint32_t)TC ? lane : 0u], vsv = sc[64 + (lane < (uint32_t)TC ? lane : 0u)];
     r.ks[0] = lane < nt ? ksv : 0.0f;  // rows past nt: the request's range check left the slot's old bytes there
     r.vs[0] = lane < nt ? vsv : 0.0f;
+    if constexpr (NB == 1) {
+      // every fragment is in registers once the LDS reads have returned: the slot is free for tile k + 1, whose
+      // requests then have the whole reduction of tile k to land in
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.ks[0]), "+v"(r.vs[0]) : : "memory");
+      request(k + 1u);
+      asm volatile("" ::: "memory");
+    }
     st.consume(a, nt, r, none, s_ks, s_vs, s_al);
   }
   wait_vmcnt<0>();  // the empty tail requests retire before the wave's LDS is released
@@ -2340,14 +2358,15 @@ static void launch_partial(const AttnArgs& a, hipStream_t st) {
     return;
   }
 #endif
-  if (a.mfma && a.stream_tpw && a.lds) {
+  if (a.mfma && a.stream_tpw && a.lds) {  // (a.lds == 3, A-B: the same kernel with strided tile ownership)
     // ring depth 2: one tile in flight behind the one being reduced, four one-wave workgroups per CU (25.6 KiB each for
     // INT8 keys + INT4 values). Measured at batch 8, 16 K tokens (per layer call incl. merge, profiles/r03d_*): depth 2
     // 40.8 us, depth 3 44.7 us, depth 4 (three workgroups per CU) 86 us; 32-token tiles 42.1-51.6 us.
     constexpr int kSlot = 64 * (128 * KBITS / 8 + 128 * VBITS / 8) + 512;
     int nb = 2;
 #if KVQ_AB
-    if (tunables().attn_lds_nb >= 2 && tunables().attn_lds_nb <= 4) nb = (int)tunables().attn_lds_nb;
+    if (tunables().attn_lds_nb >= 1 && tunables().attn_lds_nb <= 4) nb = (int)tunables().attn_lds_nb;
+    if (nb == 1) { KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 64, kI8, 1>), grid, dim3(kWave), (size_t)kSlot, st, a, a.stream_tpw); return; }
     if (lds_tc() == 32) {
       constexpr int kSlot32 = 32 * (128 * KBITS / 8 + 128 * VBITS / 8) + 512;
       if (nb == 2) KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 32, kI8, 2>), grid, dim3(kWave), (size_t)(2 * kSlot32), st, a, a.stream_tpw);
@@ -2506,7 +2525,7 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
   a.dtype = dtype;
   a.mfma = use_mfma(d) ? 1 : 0;
   a.stream_tpw = 0u;
-  a.lds = (!t_dev && use_lds(d)) ? (KVQ_AB && tunables().attn_lds == 2 ? 2u : 1u) : 0u;
+  a.lds = (!t_dev && use_lds(d)) ? (KVQ_AB && tunables().attn_lds == 2 ? 2u : (KVQ_AB && tunables().attn_lds == 3 ? 3u : 1u)) : 0u;
   a.t_dev = t_dev;
   if (!(t_dev ? plan_onetile(d, &a.TS, &a.nsplit) : plan(d, &a.TS, &a.nsplit, &a.stream_tpw))) {
     set_error("%s: T=%lld needs more than %d splits of %d tokens", name, (long long)d->T, kAttnMaxSplit, kAttnMaxTS);

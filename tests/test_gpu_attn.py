@@ -433,7 +433,7 @@ LDS_CASES = [(1, 32, 8, 1000, 128), (2, 6, 2, 200, 128), (1, 16, 1, 300, 128), (
              (1, 8, 2, 513, 128), (2, 32, 8, 2048, 128), (1, 8, 2, 64, 128), (1, 8, 2, 129, 128), (8, 32, 8, 4100, 128)]
 
 
-@pytest.mark.parametrize("which", [1, pytest.param(2, marks=pytest.mark.ab)])
+@pytest.mark.parametrize("which", [1, pytest.param(2, marks=pytest.mark.ab), pytest.param(3, marks=pytest.mark.ab)])  # 3: strided tile ownership
 @pytest.mark.parametrize("tpw", [0, 1, 3, 9])
 def test_decode_attn_lds_staged_kernel(K, tunable, tpw, which):
     """decode_attn_lds_mfma_k (a tile = whole 1 KiB LDS-DMA requests into a ring of LDS slots, operand fragments read
@@ -454,7 +454,7 @@ def test_decode_attn_lds_staged_kernel(K, tunable, tpw, which):
     if tpw:
         _lib.kernel_log_clear()
         _run_case(K, 2, 32, 8, 1500, 128, "int8", "int4", "f16", True)
-        assert _lib.kernel_log()[0].startswith(("decode_attn_lds_mfma_k<8, 4, 64, true, 2>", "decode_attn_coal_mfma_k<")[which - 1]), _lib.kernel_log()
+        assert _lib.kernel_log()[0].startswith(("decode_attn_lds_mfma_k<8, 4, 64, true, 2>", "decode_attn_coal_mfma_k<", "decode_attn_lds_mfma_k<8, 4, 64, true, 2>")[which - 1]), _lib.kernel_log()
 
 
 def test_streaming_plan_rejected_falls_back_to_one_tile_splits(K, tunable):
@@ -486,7 +486,7 @@ def test_streaming_plan_rejected_falls_back_to_one_tile_splits(K, tunable):
 
 
 @pytest.mark.ab
-@pytest.mark.parametrize("which", [1, 2])
+@pytest.mark.parametrize("which", [1, 2, 11, 13])  # 1: ring (shipped depth), 2: coalesced, 11 / 13: ring of depth 1 / 3
 @pytest.mark.parametrize("tpw", [1, 2, 3, 5, 9])
 def test_lds_staged_kernels_equal_the_register_staged_streaming_kernel(K, tunable, tpw, which):
     """A-B library: the LDS-DMA ring kernel and the coalesced kernel are BIT-identical to the register-staged streaming
@@ -494,6 +494,9 @@ def test_lds_staged_kernels_equal_the_register_staged_streaming_kernel(K, tunabl
     code (AttnStream::consume)."""
     from efficient_llm_inference_amd import _lib
     tunable("attn_stream_tpw", tpw)
+    if which > 10:
+        tunable("attn_lds_nb", which - 10)
+        which = 1
     g = torch.Generator(device="cuda").manual_seed(11 + tpw)
     for (B, Hq, Hkv, T, D) in ((2, 32, 8, 1500, 128), (1, 16, 2, 449, 128)):
         for kk, vk in (("int8", "int4"), ("int4", "int8"), ("int8", "int8")):
