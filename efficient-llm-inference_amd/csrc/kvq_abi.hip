@@ -99,6 +99,7 @@ static const TunableKey kTunableKeys[] = {
     {"quant_nt_stores", &Tunables::quant_nt_stores, true},
     {"quant_geo128", &Tunables::quant_geo128, true},
     {"quant_tile_tt", &Tunables::quant_tile_tt, true},
+    {"quant_tile_tpw", &Tunables::quant_tile_tpw, true},
     {"attn_mfma_min_nq", &Tunables::attn_mfma_min_nq, true},
     {"attn_mfma_tc", &Tunables::attn_mfma_tc, true},
     {"attn_fused", &Tunables::attn_fused, true},

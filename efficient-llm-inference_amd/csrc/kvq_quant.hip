@@ -457,6 +457,77 @@ __global__ __launch_bounds__(kWave) void quant_tile_k(const QuantTileArgs a) {
 }
 
 #if KVQ_AB
+// ---------------------------------------------------------------------------- tile kernel, merged stores
+// quant_tile_k's INT4 output leaves a wave as 256-byte pieces per head row (4 tokens x 64 B); the calibration builds of
+// round 2 put that write phase at 3.2 TB/s where 512-byte pieces run at 6.2 (profiles/NOTES.md §3.2). Here ONE wave
+// quantises TPW consecutive tiles (TPW x TT tokens) — every tile's R row loads issued up front, each tile reduced as
+// its own loads arrive (counted vmcnt) — and stages ALL their output in LDS, so that a row's run leaves as one
+// TPW x 256-byte (INT4) / TPW x 512-byte (INT8) piece. Same arithmetic per element as quant_tile_k; a row run is one
+// wave wide (TT * D/8 == 64). Measured SLOWER than one tile per wave (INT4 242-245 us against 231, INT8 294-309 against
+// 272: profiles/r03m_quant_tile_merged_stores.txt) — twice the loads per wave in flight and half the waves cost more than
+// the larger pieces return: A-B builds only.
+template <int IDT, int BITS, int R, int DV, int TT, int TPW>
+__global__ __launch_bounds__(kWave) void quant_tile_merged_k(const QuantTileArgs a) {
+  static_assert(IDT != KVQ_F32 && TT * DV == 64, "two-byte inputs, one row run per load instruction");
+  constexpr int D = DV * 8;
+  constexpr int QV = BITS;
+  constexpr int ROWB1 = 64 * QV;            // one tile's bytes of a row run in the store
+  constexpr int ROWB = TPW * ROWB1;         // the wave's bytes of a row run
+  constexpr int OUTB = R * ROWB;
+  constexpr int NST = OUTB / 1024;
+  static_assert(OUTB % 1024 == 0 && (1024 % ROWB == 0 || ROWB % 1024 == 0), "whole 1 KiB store instructions");
+  constexpr uint32_t kOut = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) uint32_t s_out[OUTB / 4];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t g = blockIdx.y;
+  const uint32_t t0 = blockIdx.x * (uint32_t)(TT * TPW);
+  const uint32_t nt = a.T - t0 < (uint32_t)(TT * TPW) ? a.T - t0 : (uint32_t)(TT * TPW);  // uniform: tokens of this wave
+  const uint32_t tok = lane / DV;
+  const char* ibase = reinterpret_cast<const char*>(a.in.p[g]) + (int64_t)t0 * (D * 2);
+  const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ibase), 0, (int)((R - 1) * a.is_h + nt * (D * 2)), 0x00020000);
+  Vec8<IDT> x[TPW][R];
+#pragma unroll
+  for (int p = 0; p < TPW; ++p) {
+    const uint32_t ioff = (uint32_t)(p * TT) + tok < nt ? (uint32_t)p * 1024u + lane * 16u : kOut;
+#pragma unroll
+    for (int i = 0; i < R; ++i) x[p][i].w = __builtin_amdgcn_raw_buffer_load_b128(irs, ioff, (uint32_t)i * a.is_h, KVQ_TILE_LD_AUX);
+  }
+  constexpr int DVSH = DV == 16 ? 4 : 3;
+#pragma unroll
+  for (int p = 0; p < TPW; ++p) {
+    uint32_t m = 0u;
+#pragma unroll
+    for (int i = 0; i < R; ++i) m = max(m, x[p][i].absmax_bits());
+    m = group_umax(m, DVSH);
+    const float s32 = fmaxf(Vec8<IDT>::bits_to_f32(m) / QRange<BITS>::qmax, a.eps);
+    const float rcp = 1.0f / s32;
+    if ((lane % DV) == 0u && (uint32_t)(p * TT) + tok < nt) a.scales[(int64_t)g * a.ssg + t0 + (uint32_t)(p * TT) + tok] = Elem<IDT>::round_trip(s32);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      uint32_t qb[8];
+      quotient_bits8<BITS>(x[p][i], s32, rcp, qb);
+      const uint32_t widx = ((uint32_t)i * (TPW * 64) + (uint32_t)p * 64u + lane) * (QV / 4);  // [row][tile][vector]
+      if constexpr (BITS == 8) *reinterpret_cast<u32x2*>(&s_out[widx]) = pack_i8(qb);
+      else s_out[widx] = pack_i4(qb);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  uint8_t* obase = a.q + (int64_t)g * a.qs_g + (int64_t)t0 * (D * BITS / 8);
+  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (int)((R - 1) * a.qs_h + nt * (D * BITS / 8)), 0x00020000);
+#pragma unroll
+  for (int j = 0; j < NST; ++j) {
+    const uint32_t k = (uint32_t)j * 1024u + lane * 16u;  // byte of the staged tile: row k / ROWB, byte k % ROWB of the row's run
+    const uint32_t row = k / ROWB, off = k % ROWB;
+    const u32x4 w = *reinterpret_cast<const u32x4*>(&s_out[k / 4]);
+    __builtin_amdgcn_raw_buffer_store_b128(w, ors, off < nt * (uint32_t)(D * BITS / 8) ? row * a.qs_h + off : kOut, 0, KVQ_TILE_ST_AUX);
+  }
+}
+
+#endif  // KVQ_AB (merged stores)
+
+#if KVQ_AB
 // ---------------------------------------------------------------------------- pipelined one-wave tiles
 // The shipped prefill shape (R rows x 64 vectors per tile, one wave per tile: REGMAX above) as a
 // software pipeline: ONE wave walks TPW consecutive tiles and requests tile n + 1's R non-temporal
@@ -994,6 +1065,20 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
           ta.q = q + g0 * a.qs.g;
           ta.scales = scales + g0 * ssg;
           const dim3 grid((unsigned)((d->T + tt - 1) / tt), (unsigned)gn);
+#if KVQ_AB  // merged stores: TPW tiles per wave (measured slower: 242 / 294 us against 231 / 272, profiles/r03m_*)
+          const int64_t tpw = tunables().quant_tile_tpw;
+          if ((tpw == 2 || tpw == 4) && R == 8 && in_dtype == KVQ_F16) {
+            const int ttw = (int)(tt * tpw);
+            const dim3 grid2((unsigned)((d->T + ttw - 1) / ttw), (unsigned)gn);
+            if (d->D == 128 && tpw == 2) KVQ_LAUNCH((quant_tile_merged_k<KVQ_F16, BITS, 8, 16, 4, 2>), grid2, dim3(kWave), 0, st, ta);
+            else if (d->D == 128) KVQ_LAUNCH((quant_tile_merged_k<KVQ_F16, BITS, 8, 16, 4, 4>), grid2, dim3(kWave), 0, st, ta);
+            else if (tpw == 2) KVQ_LAUNCH((quant_tile_merged_k<KVQ_F16, BITS, 8, 8, 8, 2>), grid2, dim3(kWave), 0, st, ta);
+            else KVQ_LAUNCH((quant_tile_merged_k<KVQ_F16, BITS, 8, 8, 8, 4>), grid2, dim3(kWave), 0, st, ta);
+            const int rc2 = check_launch(name);
+            if (rc2) return rc2;
+            continue;
+          }
+#endif
 #define KVQ_TILE(IDT_, R_, DV_, TT_) KVQ_LAUNCH((quant_tile_k<IDT_, BITS, R_, DV_, TT_>), grid, dim3(kWave), 0, st, ta)
 #if KVQ_AB
 #define KVQ_TILE64(IDT_, R_) do { if (tt == 4) KVQ_TILE(IDT_, R_, 8, 4); else KVQ_TILE(IDT_, R_, 8, 8); } while (0)

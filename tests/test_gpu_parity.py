@@ -202,7 +202,7 @@ def test_oracle_quant_dequant_tokens(E, case, dtype, kind):
 
 
 @pytest.mark.ab
-@pytest.mark.parametrize("case", [(4, 1, 8, 300, 128), (3, 1, 12, 129, 64), (2, 1, 16, 64, 64), (2, 2, 4, 33, 32), (2, 8, 8, 5, 128)])
+@pytest.mark.parametrize("case", [(4, 1, 8, 300, 128), (3, 1, 12, 129, 64), (2, 1, 16, 64, 64), (2, 2, 4, 33, 32), (2, 8, 8, 5, 128), (2, 1, 8, 77, 64)])
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("kind", ["int8", "int4"])
 def test_quant_ab_tile_sizes_and_instantiations(E, case, dtype, kind):
@@ -217,6 +217,12 @@ def test_quant_ab_tile_sizes_and_instantiations(E, case, dtype, kind):
         store, scales = _quant_via_kernels(E, x_np, dtype, kind, False, as_list, block=block, tile=0, **ab)
         assert np.array_equal(to_numpy(store[:, :, :, 1:T + 1]), q_ref), (dist, block, ab)
         assert np.array_equal(bits(scales[:, 1:T + 1]), bits(s32_ref)), (dist, block, ab)
+    if B * H == 8 and dtype == "f16":  # merged-store tile kernel: 2 / 4 tiles per wave, ragged token counts included
+        for tpw, dist in ((2, "heavy"), (4, "tiny"), (2, "normal")):
+            x_np = seeded_kv(case, dtype, seed=7 + tpw, dist=dist)
+            q_ref, _, s32_ref = O.quantize_tokens(x_np, kind, dtype=odt(dtype))
+            store, scales = _quant_via_kernels(E, x_np, dtype, kind, False, tpw == 4, tile=1, quant_tile_tpw=tpw)
+            assert np.array_equal(to_numpy(store[:, :, :, 1:T + 1]), q_ref) and np.array_equal(bits(scales[:, 1:T + 1]), bits(s32_ref)), (tpw, dist)
     if D == 64 and dtype != "f32":
         x_np = seeded_kv(case, dtype, seed=5, dist="heavy")
         q_ref, _, s32_ref = O.quantize_tokens(x_np, kind, dtype=odt(dtype))
