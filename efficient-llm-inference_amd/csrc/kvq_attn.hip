@@ -2088,6 +2088,9 @@ __device__ inline void quant_new_token_regs(const NewTokenArgs& a, const uint32_
 }
 
 // (has_new: without a new token the host points kn / vn at the query, so that the three loads need no branch)
+// PF: partial rows each thread requests up front (and holds): ceil(nsplit / (256 / (D/4))) rounded up to 2 / 4 / 16 by the
+// host — the 16 splits per head of the LDS-staged kernel need 2, not 16 (14 clamped re-reads of the last row per thread)
+template <int PF>
 __global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_fast_k(const AttnArgs a, const NewTokenArgs nt, const int fuse_quant,
                                                                        const int has_new_i) {
   __shared__ float s_red[3][kAttnBlock / kWave];
@@ -2135,9 +2138,9 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_fast_k(const Att
   const uint16_t qb_raw = reinterpret_cast<const uint16_t*>(a.q)[(int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + di];
   const uint16_t kb = reinterpret_cast<const uint16_t*>(a.kn)[(int64_t)b * a.kn_sb + (int64_t)hk * a.kn_sh + di];
   const uint16_t vb = reinterpret_cast<const uint16_t*>(a.vn)[(int64_t)b * a.vn_sb + (int64_t)hk * a.vn_sh + di];
-  f32x4 x[kMergePF];
+  f32x4 x[PF];
 #pragma unroll
-  for (int u = 0; u < kMergePF; ++u) {
+  for (int u = 0; u < PF; ++u) {
     const uint32_t s = g + (uint32_t)u * groups;
     x[u] = __builtin_nontemporal_load(src + (int64_t)(s < nb ? s : nb - 1u) * dv);
   }
@@ -2176,11 +2179,11 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_fast_k(const Att
   // ---- weighted sum: thread = (split group g, 4 elements at d4) ---------------------------------------------
   f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-  for (int u = 0; u < kMergePF; ++u) {
+  for (int u = 0; u < PF; ++u) {
     const uint32_t s = g + (uint32_t)u * groups;
     if (s < ns) o += x[u] * s_wt[s];
   }
-  for (uint32_t s = g + (uint32_t)kMergePF * groups; s < ns; s += groups) o += src[(int64_t)s * dv] * s_wt[s];
+  for (uint32_t s = g + (uint32_t)PF * groups; s < ns; s += groups) o += src[(int64_t)s * dv] * s_wt[s];
   *reinterpret_cast<f32x4*>(&s_out[tid * 4]) = o;  // [g][d]
   lds_barrier();
   if (tid < a.D) {
@@ -2574,8 +2577,11 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
       af.kn_sb = af.vn_sb = a.q_sb;
       af.kn_sh = af.vn_sh = 0;
     }
-    KVQ_LAUNCH(decode_attn_merge_fast_k, dim3(a.Hq + (nt ? 2u : 0u), a.B), dim3(kAttnBlock), 0, st, af, nt ? *nt : none,
-                       nt ? 1 : 0, a.kn ? 1 : 0);
+    const uint32_t groups = (uint32_t)kAttnBlock / (a.D / 4u), need = (a.nsplit + groups - 1u) / groups;
+    const dim3 mgrid(a.Hq + (nt ? 2u : 0u), a.B);
+    if (need <= 2u) KVQ_LAUNCH((decode_attn_merge_fast_k<2>), mgrid, dim3(kAttnBlock), 0, st, af, nt ? *nt : none, nt ? 1 : 0, a.kn ? 1 : 0);
+    else if (need <= 4u) KVQ_LAUNCH((decode_attn_merge_fast_k<4>), mgrid, dim3(kAttnBlock), 0, st, af, nt ? *nt : none, nt ? 1 : 0, a.kn ? 1 : 0);
+    else KVQ_LAUNCH((decode_attn_merge_fast_k<kMergePF>), mgrid, dim3(kAttnBlock), 0, st, af, nt ? *nt : none, nt ? 1 : 0, a.kn ? 1 : 0);
   } else
     KVQ_LAUNCH(decode_attn_merge_k, dim3(a.Hq + (nt ? 2u : 0u), a.B), dim3(kAttnBlock), 0, st, a, nt ? *nt : none,
                        nt ? 1 : 0);
