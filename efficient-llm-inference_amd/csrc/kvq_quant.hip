@@ -352,6 +352,9 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
 #ifndef KVQ_TILE_ST_AUX
 #define KVQ_TILE_ST_AUX 2
 #endif
+#ifndef KVQ_TILE_DIRECT
+#define KVQ_TILE_DIRECT 0
+#endif
 struct QuantTileArgs {
   PtrTable in;      // per-group input base pointers
   uint8_t* q;       // store base of this launch's first group
@@ -426,6 +429,21 @@ __global__ __launch_bounds__(kWave) void quant_tile_k(const QuantTileArgs a) {
   const float rcp = 1.0f / s32;
   if ((lane % DV) == 0u && sub == 0u && tok < nt && r0 == 0u) a.scales[(int64_t)g * a.ssg + t0 + tok] = Elem<IDT>::round_trip(s32);
 
+#if KVQ_TILE_DIRECT  // calibration build (`make calib_direct`): every row's run stored straight from registers, 8 / 4 B per lane
+  if constexpr (RPI == 1) {
+    uint8_t* ob = a.q + (int64_t)g * a.qs_g + (int64_t)r0 * a.qs_h + (int64_t)t0 * (D * BITS / 8);
+    const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((nr - 1u) * a.qs_h + nt * (D * BITS / 8)), 0x00020000);
+    const uint32_t doff = tok < nt ? wv * (uint32_t)QV : kOut;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      uint32_t qb[8];
+      quotient_bits8<BITS>(x[i], s32, rcp, qb);
+      if constexpr (BITS == 8) __builtin_amdgcn_raw_buffer_store_b64(pack_i8(qb), os, doff, (uint32_t)i * a.qs_h, KVQ_TILE_ST_AUX);
+      else __builtin_amdgcn_raw_buffer_store_b32(pack_i4(qb), os, doff, (uint32_t)i * a.qs_h, KVQ_TILE_ST_AUX);
+    }
+    return;
+  }
+#endif
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     uint32_t qb[8];
