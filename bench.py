@@ -857,14 +857,9 @@ def _mix_bound(n_elts, kind, measured_ms):
             "source": "profiles/r02ae_microbench_read_write_ceilings.txt (one-wave workgroups; reads and writes add)"}
 
 
-_WORLD = 1
-
-
 def _subrecord(fn, *a, **kw):
-    """a sub-record must never cost the headline: its failure is recorded in its place. (With several ranks a failure
-    on one of them cannot be swallowed — its peers sit in the sub-record's barriers — and takes the job down.)"""
-    if _WORLD > 1:
-        return fn(*a, **kw)
+    """a sub-record must never cost the headline: its failure is recorded in its place. At N > 1 the caller runs it under
+    sharding.local_mode() — no collective inside, so a rank that fails here fails alone and nobody waits for it."""
     try:
         return fn(*a, **kw)
     except Exception as exc:  # noqa: BLE001
@@ -880,8 +875,6 @@ def run_dequant(args, rank, world, dev, backend):
     from efficient_llm_inference_amd import _lib as _l
     from efficient_llm_inference_amd import kernels as _k
     from efficient_llm_inference_amd import sharding
-    global _WORLD
-    _WORLD = world
     L, B, H, T, D, mode = WORKLOADS[args.workload]
     kk, vk = MODE_KINDS[mode]
     t_run0 = time.perf_counter()
@@ -1052,13 +1045,26 @@ def run_dequant(args, rank, world, dev, backend):
     # ---- the rest of BASELINE.json's metric: sub-records (each guarded: a failure is recorded, never fatal) -----------
     if not args.no_subrecords and args.workload == "llama3_8b_mixed_seq16k":
         sub_t0 = time.perf_counter()
-        decode = _subrecord(measure_decode, *DECODE_DEFAULT, 1, 1, world)
-        cfgs = {}
-        for name in SHAPE_RECORDS:
-            cfgs[name] = _subrecord(measure_shape, name, dev, rank)
-        cfgs["llama3_8b_evict_seq32k"] = _subrecord(measure_evict, "llama3_8b_evict_seq32k", dev, rank, world, 6, 2)
-        shq = _subrecord(measure_sharded_quant, "llama3_8b_batch64_sharded_prefill512", dev, rank, world, 10, 3) if world > 1 else None
+        # decode / configs: every rank measures its own share with NO collective inside (sharding.local_mode: a failure
+        # is recorded and cannot hang the peers); at N > 1 the figures are rank 0's, taken while the other ranks run the same
+        with sharding.local_mode():
+            decode = _subrecord(measure_decode, *DECODE_DEFAULT, 1, 1, 1)
+            cfgs = {}
+            for name in SHAPE_RECORDS:
+                cfgs[name] = _subrecord(measure_shape, name, dev, rank)
+            cfgs["llama3_8b_evict_seq32k"] = _subrecord(measure_evict, "llama3_8b_evict_seq32k", dev, rank, 1, 6, 2)
+        shq = None
+        if world > 1:
+            # the one data-path collective, across the ranks for real: after a rendezvous every rank reaches whatever
+            # happened above; a failure in here takes the job down (rank abort), as a broken RCCL should
+            torch.cuda.synchronize()
+            sharding.barrier()
+            shq = measure_sharded_quant("llama3_8b_batch64_sharded_prefill512", dev, rank, world, 10, 3)
         if rank == 0:
+            if world > 1:
+                for rec in [decode] + list(cfgs.values()):
+                    if isinstance(rec, dict):
+                        rec["scope"] = f"rank 0 of {world}, measured while the other ranks run the same workload (no collective inside)"
             line["decode"] = decode
             line["configs"] = cfgs
             if shq is not None:

@@ -29,7 +29,7 @@ import torch
 import torch.distributed as dist
 
 # the group + device every reduction of this module uses; None = torch's default group
-_STATE = {"group": None, "device": None, "backend": None}
+_STATE = {"group": None, "device": None, "backend": None, "local": False}
 
 
 @contextlib.contextmanager
@@ -123,15 +123,30 @@ def shutdown() -> None:
 
 def backend() -> Optional[str]:
     """"nccl" | "gloo" | None (single process)"""
-    if not (dist.is_available() and dist.is_initialized()):
+    if _STATE["local"] or not (dist.is_available() and dist.is_initialized()):
         return None
     return _STATE["backend"] or dist.get_backend()
 
 
 def world() -> tuple:
+    if _STATE["local"]:
+        return 0, 1
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+@contextlib.contextmanager
+def local_mode():
+    """Inside the block this rank behaves as a single process: `world()` is (0, 1), `barrier()` / `max_over_ranks()` /
+    `aggregate_results()` touch no collective. For per-rank side measurements of an N-rank run that must not be able to
+    hang the job: a rank that fails inside the block fails alone (bench.py's sub-records at N > 1)."""
+    prev = _STATE["local"]
+    _STATE["local"] = True
+    try:
+        yield
+    finally:
+        _STATE["local"] = prev
 
 
 def shard_prompts(prompts: Sequence, rank: int = None, world_size: int = None) -> List:
@@ -167,7 +182,7 @@ def _all_reduce(t: torch.Tensor, op) -> None:
 def barrier() -> None:
     """Rendezvous of all ranks (no-op in a single process). bench.py brackets its timed region
     with barrier() + torch.cuda.synchronize() on both sides."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if not _STATE["local"] and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         if _STATE["group"] is not None:  # RCCL: a 1-element all_reduce on the device, then drained
             t = torch.zeros(1, device=_STATE["device"])
             _all_reduce(t, dist.ReduceOp.SUM)

@@ -150,6 +150,17 @@ def _worker(rank, world_size, port, q):
         sharding.barrier()
         slowest = sharding.max_over_ranks(1.0 + rank)  # bench.py's timing reduction
         rows = list(sharding.shard_batch_rows(5))
+        # local_mode: inside it this rank is a single process — no collective is touched (only rank 1 enters the block
+        # here: a barrier or reduction inside it would hang the pair), outside it the group is back
+        if rank == 1:
+            with sharding.local_mode():
+                assert sharding.world() == (0, 1) and sharding.backend() is None
+                sharding.barrier()
+                assert sharding.max_over_ranks(7.0) == 7.0
+                loc = sharding.benchmark_sharded(b, prompts, "full_cache", max_new_tokens=2)
+                assert loc["n_ranks"] == 1 and loc["total_new_tokens"] == 10
+        assert sharding.world() == (rank, world_size)
+        assert sharding.max_over_ranks(float(rank)) == 1.0
         q.put((rank, res["total_new_tokens"], res["n_prompts"], res["n_ranks"], res["elapsed_sec"], res["tokens_per_sec"],
                slowest, rows))
     finally:
