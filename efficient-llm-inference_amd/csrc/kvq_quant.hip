@@ -1011,6 +1011,28 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
   }
 }
 
+// Can the one-wave tile kernels over 8-row groups (quant_tile_k PHASE 1 / 2) serve this call? bits = 0: the abs-max phase
+// alone (no store side to check).
+static bool split_tile_ok(int bits, const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st, int in_dtype,
+                          const uint8_t* q, const kvq_strides_t* q_st, const kvq_dims_t* d) {
+  const int64_t Rt = d->B * d->H;
+  const int esz = in_dtype == KVQ_F32 ? 4 : 2;
+  bool tile = tunables().quant_tile && in_dtype != KVQ_F32 && (d->D == 128 || d->D == 64) && (d->T == 1 || in_st->t == d->D) &&
+              (d->B == 1 || in_st->b == d->H * in_st->h) && (in_st->h * 2) % 16 == 0 && in_st->h >= 0 &&
+              (Rt - 1) * in_st->h * 2 + 8 * d->D * 2 < (int64_t(1) << 31) && (Rt + 7) / 8 < 65536;
+  if (bits)
+    tile = tile && q && q_st && (d->T == 1 || q_st->t == d->D * bits / 8) && (d->B == 1 || q_st->b == d->H * q_st->h) && q_st->h % 16 == 0 &&
+           q_st->g % 16 == 0 && q_st->h >= 0 && (d->D * bits / 8) % 16 == 0 && aligned(q, 16) && (Rt - 1) * q_st->h + 8 * d->D < (int64_t(1) << 31);
+  for (int64_t i = 0; i < d->G && tile; ++i)
+    tile = aligned(in_ptrs ? in_ptrs[i] : static_cast<const char*>(in_base) + i * in_st->g * (int64_t)esz, 16) && (in_ptrs ? in_ptrs[i] : in_base) != nullptr;
+  return tile;
+}
+
+template <int PHASE>
+static int split_phase(const char* name, int bits, const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st,
+                       int in_dtype, uint8_t* q, const kvq_strides_t* q_st, float* scales, int64_t ssg, float* absmax,
+                       float eps, const kvq_dims_t* d, void* stream, bool accumulate = false);
+
 template <int BITS>
 static int quant_tokens(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st, int in_dtype,
                         uint8_t* q, const kvq_strides_t* q_st, float* scales, int64_t ssg, float* absmax_ws,
@@ -1135,6 +1157,14 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
   // D/8 not a power of two, or wider than one wave: swept tile with division-based indexing
   const bool anydv = d->D % 8 == 0 && (dvshift < 0 || d->D / 8 > kWave);
   const bool big = anydv || R * d->D > kTileElems;  // swept-tile kernel instead of the register tile
+  // Batched slices larger than the register tile (B*H*D > 16384, e.g. an un-sharded batch of 64): two passes of the
+  // one-wave tile kernels over 8-row groups — abs-max into the caller's [G,T] workspace, then quantise — run at 6.1-6.3
+  // TB/s of their own traffic each (3.6 TB/s of single-pass bytes) where the swept tile reaches 2.5
+  if (big && !anydv && absmax_ws && !tunables().quant_force_two_pass && split_tile_ok(BITS, in_base, in_ptrs, in_st, in_dtype, q, q_st, d)) {
+    int rc = split_phase<1>(name, BITS, in_base, in_ptrs, in_st, in_dtype, nullptr, nullptr, nullptr, 0, absmax_ws, eps, d, stream, false);
+    if (rc) return rc;
+    return split_phase<2>(name, BITS, in_base, in_ptrs, in_st, in_dtype, q, q_st, scales, ssg, absmax_ws, eps, d, stream, false);
+  }
   bool fused = !tunables().quant_force_two_pass && d->D % 8 == 0 && d->D <= kTileElems &&
                (d->T == 1 || (a.is.t == d->D && a.qs.t == Dq)) && (big ? (KVQ_AB || in_dtype != KVQ_F32) : bh_contig) &&
                (a.is.b * esz) % 16 == 0 && a.qs.b % qvec == 0 &&
@@ -1262,7 +1292,7 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
 template <int PHASE>
 static int split_phase(const char* name, int bits, const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st,
                        int in_dtype, uint8_t* q, const kvq_strides_t* q_st, float* scales, int64_t ssg, float* absmax,
-                       float eps, const kvq_dims_t* d, void* stream, bool accumulate = false) {
+                       float eps, const kvq_dims_t* d, void* stream, bool accumulate) {
   if (!in_st || !d || !absmax || (!in_base && !in_ptrs) || (PHASE == 2 && (!q || !q_st || !scales))) {
     set_error("%s: NULL argument", name);
     return KVQ_E_NULL;
@@ -1303,14 +1333,7 @@ static int split_phase(const char* name, int bits, const void* in_base, const vo
     vec = vec && a.qs.g % qvec == 0 && a.qs.b % qvec == 0 && a.qs.h % qvec == 0 && a.qs.t % qvec == 0 && aligned(q, qvec);
   // ---- one-wave tile kernels over 8-row groups (quant_tile_k PHASE 1 / 2): what a batch-sharded prefill chunk takes ----
   const int64_t Rt = d->B * d->H;
-  bool tile = tunables().quant_tile && in_dtype != KVQ_F32 && (d->D == 128 || d->D == 64) && (d->T == 1 || a.is.t == d->D) &&
-              (d->B == 1 || a.is.b == d->H * a.is.h) && (a.is.h * 2) % 16 == 0 && a.is.h >= 0 &&
-              (Rt - 1) * a.is.h * 2 + 8 * d->D * 2 < (int64_t(1) << 31) && (Rt + 7) / 8 < 65536;
-  if (PHASE == 2)
-    tile = tile && (d->T == 1 || a.qs.t == d->D * bits / 8) && (d->B == 1 || a.qs.b == d->H * a.qs.h) && a.qs.h % 16 == 0 && a.qs.g % 16 == 0 &&
-           a.qs.h >= 0 && (d->D * bits / 8) % 16 == 0 && aligned(q, 16) && (Rt - 1) * a.qs.h + 8 * d->D < (int64_t(1) << 31);
-  for (int64_t i = 0; i < d->G && tile; ++i)
-    tile = aligned(in_ptrs ? in_ptrs[i] : static_cast<const char*>(in_base) + i * a.is.g * (int64_t)esz, 16) && (in_ptrs ? in_ptrs[i] : in_base) != nullptr;
+  const bool tile = split_tile_ok(PHASE == 2 ? bits : 0, in_base, in_ptrs, in_st, in_dtype, q, q_st, d);
   if (tile) {
     const int tt = d->D == 128 ? 4 : 8;
     QuantTileArgs ta;
