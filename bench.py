@@ -38,6 +38,8 @@ import os
 import sys
 import time
 
+_T_PROCESS0 = time.perf_counter()  # before `import torch`: the start-up share of `phases_s`
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -99,6 +101,7 @@ def parse():
                          "step re-reads lines the 256 MiB Infinity Cache may still hold (1 = the decode loop's "
                          "behaviour: the same cache every step; its 256 MiB INT4 store then stays cache-resident)")
     ap.add_argument("--cpu-sample-layers", type=int, default=8)
+    ap.add_argument("--cpu-reps", type=int, default=5, help="timed repetitions per cpu_baseline entry (median reported)")
     ap.add_argument("--tunable", action="append", default=[], metavar="KEY=VALUE",
                     help="kvq_set_tunable(KEY, VALUE) before the run (include/kvq_hip.h lists the keys; A-B keys need "
                          "KVQ_HIP_LIB=<pkg>/lib/ab/libkvq_hip.so)")
@@ -497,36 +500,51 @@ def measure_sharded_quant(name, dev, rank, world, steps, warmup):
     step_bytes = L * Bg * H * T * D * (BYTES_PER_ELT["int8"] + BYTES_PER_ELT["int4"])  # whole job, single-pass bytes
     outs = [sharding.ShardedQuantBuffers(k, "int8"), sharding.ShardedQuantBuffers(v, "int4")]
 
-    def step():
-        sharding.quantize_tokens_batch_sharded(k, "int8", out=outs[0])
-        sharding.quantize_tokens_batch_sharded(v, "int4", out=outs[1])
+    def run(two_phase):
+        def step():
+            sharding.quantize_tokens_batch_sharded(k, "int8", out=outs[0], two_phase=two_phase)
+            sharding.quantize_tokens_batch_sharded(v, "int4", out=outs[1], two_phase=two_phase)
 
-    kernels = _kernels_of(step)
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    sharding.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    sharding.barrier()
-    torch.cuda.synchronize()
-    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+        kernels = _kernels_of(step)
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        sharding.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        sharding.barrier()
+        torch.cuda.synchronize()
+        return sharding.max_over_ranks(time.perf_counter() - t0, dev), kernels
+
+    # what the call does at THIS world size: the phases + all_reduce at N > 1; at N = 1 there is nothing to exchange and
+    # the slice takes the un-sharded single-pass call — the phases a rank of a larger job runs are timed beside it
+    elapsed, kernels = run(None)
+    phases = None
+    if world == 1:
+        el2, k2 = run(True)
+        phases = {"value": round(step_bytes / (el2 / steps) / 1e9, 2), "unit": "GB/s", "ms_per_step": round(el2 / steps * 1e3, 4),
+                  "frac_of_hbm_peak_per_gpu": round(step_bytes / (el2 / steps) / 1e9 / HBM_PEAK_GBPS, 4), "kernels": k2,
+                  "what": "two_phase=True on one rank: abs-max pass, (no exchange), quantise pass — the input is read twice, "
+                          "as on every rank of an N > 1 job; bytes counted once"}
     rec = {
         "value": round(step_bytes / (elapsed / steps) / 1e9, 2), "unit": "GB/s", "steps": steps,
         "ms_per_step": round(elapsed / steps * 1e3, 4), "scaling": "strong",
         "frac_of_hbm_peak_per_gpu": round(step_bytes / world / (elapsed / steps) / 1e9 / HBM_PEAK_GBPS, 4),
         "kernels": kernels,
         "config": {"workload": name, "shape_L_Bglobal_H_T_D": [L, Bg, H, T, D], "batch_rows_per_rank": Bl,
-                   "step": "per layer chunk: kvq_absmax_tokens -> all_reduce(MAX) [Lc,T] fp32 (side stream) -> "
-                           "kvq_quant_tokens_from_absmax; K (INT8) then V (INT4)",
+                   "step": ("per layer chunk: kvq_absmax_tokens -> all_reduce(MAX) [Lc,T] fp32 (side stream) -> "
+                            "kvq_quant_tokens_from_absmax; K (INT8) then V (INT4)") if world > 1 else
+                           "one rank, nothing to exchange: kvq_quant_i8_tokens / kvq_quant_i4_tokens, ONE pass (see two_phase)",
                    "layer_chunks": outs[0].n_chunks, "collective": "all_reduce(MAX)", "collective_backend": sharding.backend() or "none (1 rank)",
                    "collective_bytes_per_step": 2 * L * T * 4, "bytes_per_step_single_pass": int(step_bytes),
                    "parallelism": f"batch rows sharded x{world}; one all_reduce(MAX) per layer chunk, set and step",
                    "timing_reduction_backend": sharding.backend()},
     }
+    if phases is not None:
+        rec["two_phase"] = phases
     del k, v, outs
     _free()
     return rec
@@ -540,7 +558,7 @@ def run_sharded_quant(args, rank, world, dev):
             "value": rec["value"], "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic", "config": rec["config"], "kernels": rec["kernels"],
-            "frac_of_hbm_peak_per_gpu": rec["frac_of_hbm_peak_per_gpu"],
+            "frac_of_hbm_peak_per_gpu": rec["frac_of_hbm_peak_per_gpu"], "two_phase": rec.get("two_phase"),
         }), flush=True)
 
 
@@ -878,6 +896,12 @@ def run_dequant(args, rank, world, dev, backend):
     L, B, H, T, D, mode = WORKLOADS[args.workload]
     kk, vk = MODE_KINDS[mode]
     t_run0 = time.perf_counter()
+    phases = {}  # seconds of wall clock per phase of this run (rank 0's), reported as `phases_s`
+
+    def mark(name, _t=[t_run0]):
+        now = time.perf_counter()
+        phases[name] = round(phases.get(name, 0.0) + now - _t[0], 2)
+        _t[0] = now
 
     # ---- build the quantised cache once (each rank its own prompt: seed 42 + rank) ------------
     torch.manual_seed(42 + rank)
@@ -904,6 +928,8 @@ def run_dequant(args, rank, world, dev, backend):
     for ko, vo in outs:  # first touch of the fresh pages happens here, not in a timed step
         ko.zero_()
         vo.zero_()
+    torch.cuda.synchronize()
+    mark("build_caches")
     n_elts = L * B * H * T * D  # per K or V set
     bytes_k = n_elts * BYTES_PER_ELT[kk]
     bytes_v = n_elts * BYTES_PER_ELT[vk]
@@ -938,6 +964,7 @@ def run_dequant(args, rank, world, dev, backend):
         else:
             c._v.dequant(torch.float16, out=vo)  # all layers of V: one launch (the roofline kernel)
 
+    mark("quantise_side_measurement")
     for i in range(args.warmup):
         step(i)
     # Two HIP events per step, bound to the INT4 launch itself (kvq_time_next_launch -> hipExtLaunchKernelGGL): they
@@ -959,6 +986,7 @@ def run_dequant(args, rank, world, dev, backend):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
+    mark("warmup_and_timed_steps")
     v_each = sorted(e[0].elapsed_time(e[1]) for e in events)
     elapsed = sharding.max_over_ranks(elapsed, dev)  # the step takes as long as the slowest rank
 
@@ -978,6 +1006,7 @@ def run_dequant(args, rank, world, dev, backend):
     torch.cuda.synchronize()
     pub_ms = (time.perf_counter() - tp0) / n_pub * 1e3
     del pkv
+    mark("extended_samples_and_public_api")
 
     gpu_check = None
     if rank == 0 and not args.no_cpu_baseline and world == 1:  # layer 0 of what the GPU just produced, for the port to check
@@ -997,6 +1026,7 @@ def run_dequant(args, rank, world, dev, backend):
             gpu_check[f"s_{name}"] = host(st_.scales[:1, :T])
             gpu_check[f"out_{name}"] = host(o[:1])
 
+    mark("gpu_outputs_to_host_for_parity")
     line = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -1054,6 +1084,9 @@ def run_dequant(args, rank, world, dev, backend):
                 cfgs[name] = _subrecord(measure_shape, name, dev, rank)
             cfgs["llama3_8b_evict_seq32k"] = _subrecord(measure_evict, "llama3_8b_evict_seq32k", dev, rank, 1, 6, 2)
         shq = None
+        if world == 1:
+            # one rank: the batch-64 prefill slice of the sharded workload, single pass beside the two phases (no collective)
+            shq = _subrecord(measure_sharded_quant, "llama3_8b_batch64_sharded_prefill512", dev, rank, world, 10, 3)
         if world > 1:
             # the one data-path collective, across the ranks for real: after a rendezvous every rank reaches whatever
             # happened above; a failure in here takes the job down (rank abort), as a broken RCCL should
@@ -1070,10 +1103,14 @@ def run_dequant(args, rank, world, dev, backend):
             if shq is not None:
                 line["sharded_quant"] = shq
             line["subrecords_s"] = round(time.perf_counter() - sub_t0, 2)
+    mark("subrecords")
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            line["cpu_baseline"] = cpu_baseline(L, B, H, T, D, args.cpu_sample_layers, gpu_check=gpu_check)
+            line["cpu_baseline"] = cpu_baseline(L, B, H, T, D, args.cpu_sample_layers, reps=max(1, args.cpu_reps), gpu_check=gpu_check)
+            mark("cpu_baseline")
         line["run_s"] = round(time.perf_counter() - t_run0, 2)
+        phases["startup_before_workload"] = round(t_run0 - _T_PROCESS0, 2)
+        line["phases_s"] = phases
         print(json.dumps(line), flush=True)
 
 

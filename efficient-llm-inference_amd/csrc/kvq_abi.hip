@@ -58,6 +58,7 @@ Tunables& tunables() {
     d.nt_loads = 1;
     d.quant_nt_stores = -1;
     d.quant_tile = 1;
+    d.quant_wide = 1;
     d.attn_lds = -1;
     d.attn_k_i8 = -1;
     d.attn_merge_fast = 1;
@@ -79,6 +80,7 @@ static const TunableKey kTunableKeys[] = {
     {"quant_force_two_pass", &Tunables::quant_force_two_pass, false},
     {"quant_direct_stores", &Tunables::quant_direct_stores, false},
     {"quant_tile", &Tunables::quant_tile, false},
+    {"quant_wide", &Tunables::quant_wide, false},
     {"quant_block", &Tunables::quant_block, false},
     {"pool_wave", &Tunables::pool_wave, false},
     {"attn_force_valu", &Tunables::attn_force_valu, false},

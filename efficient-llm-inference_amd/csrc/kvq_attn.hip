@@ -2580,7 +2580,9 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
     const uint32_t groups = (uint32_t)kAttnBlock / (a.D / 4u), need = (a.nsplit + groups - 1u) / groups;
     const dim3 mgrid(a.Hq + (nt ? 2u : 0u), a.B);
     if (need <= 2u) KVQ_LAUNCH((decode_attn_merge_fast_k<2>), mgrid, dim3(kAttnBlock), 0, st, af, nt ? *nt : none, nt ? 1 : 0, a.kn ? 1 : 0);
+#if KVQ_AB  // (17-32 splits: depth 4 measured within 0.1 us of depth 16; one instantiation less in the default library)
     else if (need <= 4u) KVQ_LAUNCH((decode_attn_merge_fast_k<4>), mgrid, dim3(kAttnBlock), 0, st, af, nt ? *nt : none, nt ? 1 : 0, a.kn ? 1 : 0);
+#endif
     else KVQ_LAUNCH((decode_attn_merge_fast_k<kMergePF>), mgrid, dim3(kAttnBlock), 0, st, af, nt ? *nt : none, nt ? 1 : 0, a.kn ? 1 : 0);
   } else
     KVQ_LAUNCH(decode_attn_merge_k, dim3(a.Hq + (nt ? 2u : 0u), a.B), dim3(kAttnBlock), 0, st, a, nt ? *nt : none,

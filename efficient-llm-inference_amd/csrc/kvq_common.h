@@ -70,6 +70,7 @@ struct Tunables {
   int64_t quant_force_two_pass;  // 1 = generic two-pass quantise for every shape
   int64_t quant_direct_stores;   // 1 = skip the LDS-staged 16 B stores of the 256-thread fused kernel
   int64_t quant_block;           // general fused quantise kernel: 64 (default, one wave per tile) or 256 threads; 128 in A-B builds (measured: 241 / 261 / 270 us)
+  int64_t quant_wide;            // 1 (default) = single-pass 1024-thread register tile for batched slices of 16384 < B*H*D <= 131072 elements; 0 = split phases / swept tile
   int64_t quant_tile;            // 1 (default) = compile-time-geometry one-wave tile kernel where the shape has one; 0 = general kernels
   int64_t pool_wave;             // chunk mean-pool: one wave per output row when the shape allows (1, default) or the per-lane-group walk (0)
   int64_t attn_force_valu;       // 1 = decode attention never takes an MFMA kernel

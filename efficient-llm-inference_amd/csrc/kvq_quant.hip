@@ -474,6 +474,80 @@ __global__ __launch_bounds__(kWave) void quant_tile_k(const QuantTileArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------- wide tile (single pass, 16384 < B*H*D <= 131072)
+// A batched slice too large for the one-wave tile — an un-sharded batch of 32 / 64 rows of Llama-3-8B: R = B*H = 256 / 512
+// head rows of 128 — still read ONCE: a 1024-thread workgroup owns TT tokens x ALL R rows (TT * R * D = up to 131072
+// elements = 256 KiB of fp16) and keeps them in REGISTERS (NV = 16 vectors of 8 elements per lane, 64 of the 128 VGPRs a
+// lane of such a workgroup has), one workgroup per CU. Lane = (row-in-round, token, d-vector): in round i it holds row
+// i * RPR + lane_row, so its (token, d-vector) never changes and the abs-max across rows is a register max, then DPP across
+// the token's D/8 lanes, a lane exchange across the rows that share a wave, ONE LDS atomic per token per wave. Every load is
+// issued before the first is used; the row of a round is the lane's first row plus a uniform stride per round (the host
+// admits only layouts where that holds: B*H rows evenly spaced, or rows-per-round a multiple of H).
+// Same arithmetic per element as every other quantise kernel (quotient_bits8 / pack_*): bit-identical.
+// Against the alternatives for these shapes (Llama-3-8B batch 64 x 512 tokens, profiles/r03w_*): two passes of the one-wave
+// tile kernels 3.6 TB/s of single-pass bytes, the swept tile 2.5.
+struct QuantWideArgs {
+  PtrTable in;
+  uint8_t* q;
+  float* scales;
+  int64_t qs_g, ssg;
+  int64_t is_b, is_h, qs_b, qs_h;  // BYTES
+  int64_t is_round, qs_round;      // bytes between a lane's rows of consecutive rounds
+  uint32_t H, R, T, D;
+  uint32_t vshift, dvshift;        // log2(vectors per row run = TT * D/8), log2(D/8)
+  float eps;
+};
+
+template <int IDT, int BITS, int BLK, int NV>
+__global__ __launch_bounds__(BLK) void quant_wide_k(const QuantWideArgs a) {
+  static_assert(IDT != KVQ_F32, "two-byte inputs (an fp32 tile of this size does not fit the register file)");
+  __shared__ uint32_t s_amax[kMaxTT];
+  __shared__ float s_scale[kMaxTT], s_rcp[kMaxTT];
+  const uint32_t tid = threadIdx.x, g = blockIdx.y;
+  const uint32_t TT = 1u << (a.vshift - a.dvshift), DV = 1u << a.dvshift;
+  const uint32_t t0 = blockIdx.x * TT;
+  const uint32_t wv = tid & ((1u << a.vshift) - 1u), lr = tid >> a.vshift, tl = wv >> a.dvshift;
+  const uint32_t RPR = (uint32_t)BLK >> a.vshift;  // rows per round
+  const bool tok_ok = t0 + tl < a.T;
+  const uint32_t lb = lr / a.H, lh = lr - lb * a.H;
+  const char* in = reinterpret_cast<const char*>(a.in.p[g]) + (int64_t)lb * a.is_b + (int64_t)lh * a.is_h + ((int64_t)t0 * a.D + (int64_t)wv * 8) * 2;
+  uint8_t* qp = a.q + (int64_t)g * a.qs_g + (int64_t)lb * a.qs_b + (int64_t)lh * a.qs_h + (int64_t)t0 * (a.D * BITS / 8) + (int64_t)wv * BITS;
+  if (tid < (uint32_t)kMaxTT) s_amax[tid] = 0u;
+  __syncthreads();
+
+  Vec8<IDT> x[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    x[i].w = u32x4{0u, 0u, 0u, 0u};  // rows past R, tokens past T: cannot raise an abs-max, never stored
+    if (tok_ok && (uint32_t)i * RPR + lr < a.R) x[i].load_nt(in + (int64_t)i * a.is_round);
+  }
+  uint32_t m = 0u;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) m = max(m, x[i].absmax_bits());
+  m = group_umax(m, (int)a.dvshift);                                                            // the token's D/8 lanes
+  for (uint32_t sh = a.vshift; sh < 6u; ++sh) m = max(m, (uint32_t)__shfl_xor((int)m, 1 << sh));  // rows sharing the wave
+  if ((wv & (DV - 1u)) == 0u && ((tid & 63u) >> a.vshift) == 0u && tok_ok) atomicMax(&s_amax[tl], m);
+  __syncthreads();
+  if (tid < TT && t0 + tid < a.T) {
+    const float s32 = fmaxf(Vec8<IDT>::bits_to_f32(s_amax[tid]) / QRange<BITS>::qmax, a.eps);
+    s_scale[tid] = s32;
+    s_rcp[tid] = 1.0f / s32;
+    a.scales[(int64_t)g * a.ssg + t0 + tid] = Elem<IDT>::round_trip(s32);
+  }
+  __syncthreads();
+  const float s32 = s_scale[tl], rcp = s_rcp[tl];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (tok_ok && (uint32_t)i * RPR + lr < a.R) {
+      uint32_t qb[8];
+      quotient_bits8<BITS>(x[i], s32, rcp, qb);
+      uint8_t* dst = qp + (int64_t)i * a.qs_round;
+      if constexpr (BITS == 8) __builtin_nontemporal_store(pack_i8(qb), reinterpret_cast<u32x2*>(dst));
+      else __builtin_nontemporal_store(pack_i4(qb), reinterpret_cast<uint32_t*>(dst));
+    }
+  }
+}
+
 #if KVQ_AB
 // ---------------------------------------------------------------------------- tile kernel, merged stores
 // quant_tile_k's INT4 output leaves a wave as 256-byte pieces per head row (4 tokens x 64 B); the calibration builds of
@@ -865,10 +939,13 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
   if (fused && a.rpc) {  // swept tile: B*H*D larger than the register tile
     if constexpr (KVQ_AB || IDT != KVQ_F32) {  // (fp32 batched slices take the generic pair in the default library: host)
       const unsigned tiles = (a.T + a.TT - 1) / a.TT;
-      if (a.vpr)
-        KVQ_LAUNCH((quant_tokens_sweep_k<IDT, BITS, false>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
-      else
+#if KVQ_AB
+      if (!a.vpr) {
         KVQ_LAUNCH((quant_tokens_sweep_k<IDT, BITS, true>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
+        return;
+      }
+#endif
+      KVQ_LAUNCH((quant_tokens_sweep_k<IDT, BITS, false>), dim3(tiles, a.G), dim3(kBlock), 0, st, a);
     }
   } else if (fused) {
     const unsigned tiles = (a.T + a.TT - 1) / a.TT;
@@ -1017,7 +1094,8 @@ static bool split_tile_ok(int bits, const void* in_base, const void* const* in_p
                           const uint8_t* q, const kvq_strides_t* q_st, const kvq_dims_t* d) {
   const int64_t Rt = d->B * d->H;
   const int esz = in_dtype == KVQ_F32 ? 4 : 2;
-  bool tile = tunables().quant_tile && in_dtype != KVQ_F32 && (d->D == 128 || d->D == 64) && (d->T == 1 || in_st->t == d->D) &&
+  bool tile = tunables().quant_tile && in_dtype != KVQ_F32 && (d->D == 128 || (KVQ_AB && d->D == 64)) &&  // (head_dim 64: A-B builds; the default library takes the 256-thread pair)
+              (d->T == 1 || in_st->t == d->D) &&
               (d->B == 1 || in_st->b == d->H * in_st->h) && (in_st->h * 2) % 16 == 0 && in_st->h >= 0 &&
               (Rt - 1) * in_st->h * 2 + 8 * d->D * 2 < (int64_t(1) << 31) && (Rt + 7) / 8 < 65536;
   if (bits)
@@ -1160,6 +1238,56 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
   // Batched slices larger than the register tile (B*H*D > 16384, e.g. an un-sharded batch of 64): two passes of the
   // one-wave tile kernels over 8-row groups — abs-max into the caller's [G,T] workspace, then quantise — run at 6.1-6.3
   // TB/s of their own traffic each (3.6 TB/s of single-pass bytes) where the swept tile reaches 2.5
+  // ---- wide tile: one pass with the slice's TT tokens x all rows in the registers of a 1024-thread workgroup ------
+  if (big && !anydv && in_dtype != KVQ_F32 && tunables().quant_wide != 0 && !tunables().quant_force_two_pass &&
+      (d->T == 1 || (a.is.t == d->D && a.qs.t == Dq)) && (a.is.b * esz) % 16 == 0 && (a.is.h * esz) % 16 == 0 &&
+      a.qs.b % qvec == 0 && a.qs.h % qvec == 0 && a.qs.g % qvec == 0 && aligned(q, qvec)) {
+    constexpr int kWideBlk = 1024, kWideNV = 16;
+    const int64_t cap = (int64_t)kWideBlk * kWideNV * 8;  // elements a workgroup holds
+    if (R * d->D <= cap) {
+      uint32_t tt = pow2_floor((uint64_t)(cap / (R * d->D)));
+      if (tt > (uint32_t)kMaxTT) tt = kMaxTT;
+      while (tt > 1 && tt / 2 >= (uint64_t)d->T) tt /= 2;
+      QuantWideArgs wa;
+      wa.dvshift = (uint32_t)dvshift;
+      wa.vshift = (uint32_t)(dvshift + ilog2_exact((int64_t)tt));
+      const int64_t rpr = kWideBlk >> wa.vshift;  // >= 2: tt * D/8 <= cap / (8 R) < 512 since R * D > 16384, D/8 <= 64
+      const bool in_contig = d->B == 1 || a.is.b == d->H * a.is.h, q_contig = d->B == 1 || a.qs.b == d->H * a.qs.h;
+      bool ok = rpr >= 1 && (in_contig || rpr % d->H == 0) && (q_contig || rpr % d->H == 0);
+      for (int64_t i = 0; ok && i < d->G; ++i) {
+        const void* p = in_ptrs ? in_ptrs[i] : static_cast<const char*>(in_base) + i * a.is.g * (int64_t)esz;
+        ok = p != nullptr && aligned(p, 16);
+      }
+      if (ok) {
+        wa.qs_g = a.qs.g;
+        wa.ssg = ssg;
+        wa.is_h = a.is.h * esz;
+        wa.is_b = in_contig ? d->H * wa.is_h : a.is.b * esz;
+        wa.qs_h = a.qs.h;
+        wa.qs_b = q_contig ? d->H * wa.qs_h : a.qs.b;
+        wa.is_round = in_contig ? rpr * wa.is_h : rpr / d->H * wa.is_b;
+        wa.qs_round = q_contig ? rpr * wa.qs_h : rpr / d->H * wa.qs_b;
+        wa.H = (uint32_t)d->H;
+        wa.R = (uint32_t)R;
+        wa.T = (uint32_t)d->T;
+        wa.D = (uint32_t)d->D;
+        wa.eps = eps;
+        for (int64_t g0 = 0; g0 < d->G; g0 += kPtrsPerLaunch) {
+          const int64_t gn = d->G - g0 < kPtrsPerLaunch ? d->G - g0 : kPtrsPerLaunch;
+          for (int64_t i = 0; i < gn; ++i)
+            wa.in.p[i] = in_ptrs ? in_ptrs[g0 + i] : static_cast<const char*>(in_base) + (g0 + i) * a.is.g * (int64_t)esz;
+          wa.q = q + g0 * a.qs.g;
+          wa.scales = scales + g0 * ssg;
+          const dim3 grid((unsigned)((d->T + tt - 1) / tt), (unsigned)gn);
+          if (in_dtype == KVQ_F16) KVQ_LAUNCH((quant_wide_k<KVQ_F16, BITS, kWideBlk, kWideNV>), grid, dim3(kWideBlk), 0, st, wa);
+          else KVQ_LAUNCH((quant_wide_k<KVQ_BF16, BITS, kWideBlk, kWideNV>), grid, dim3(kWideBlk), 0, st, wa);
+          const int rc = check_launch(name);
+          if (rc) return rc;
+        }
+        return 0;
+      }
+    }
+  }
   if (big && !anydv && absmax_ws && !tunables().quant_force_two_pass && split_tile_ok(BITS, in_base, in_ptrs, in_st, in_dtype, q, q_st, d)) {
     int rc = split_phase<1>(name, BITS, in_base, in_ptrs, in_st, in_dtype, nullptr, nullptr, nullptr, 0, absmax_ws, eps, d, stream, false);
     if (rc) return rc;
@@ -1182,7 +1310,9 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
   a.nt_stores = tunables().quant_nt_stores < 0 ? a.nt_loads : (int32_t)(tunables().quant_nt_stores != 0);
   a.bh_contig = bh_contig ? 1 : 0;
   a.xcd_group = (uint32_t)(tunables().quant_xcd_group > 1 ? tunables().quant_xcd_group : 0);
-  if (fused && anydv) {
+  // (default library: ONE swept-tile kernel, the division-indexed one; the shift-indexed instantiation is an A-B variant —
+  // power-of-two shapes this large take the split-phase tile kernels above when the caller passed a workspace)
+  if (fused && big && (anydv || !KVQ_AB)) {
     const int64_t dv = d->D / 8;
     int64_t tt = (256 * 1024) / (R * d->D * esz);
     if (tt < 1) tt = 1;
@@ -1354,7 +1484,11 @@ static int split_phase(const char* name, int bits, const void* in_base, const vo
       ta.scales = PHASE == 2 ? scales + g0 * ssg : nullptr;
       const dim3 grid((unsigned)((d->T + tt - 1) / tt), (unsigned)gn, (unsigned)((Rt + 7) / 8));
 #define KVQ_PH(IDT_, BITS_, DV_, TT_) KVQ_LAUNCH((quant_tile_k<IDT_, BITS_, 8, DV_, TT_, PHASE>), grid, dim3(kWave), 0, st, ta)
+#if KVQ_AB
 #define KVQ_PH_SHAPE(IDT_, BITS_) do { if (d->D == 128) KVQ_PH(IDT_, BITS_, 16, 4); else KVQ_PH(IDT_, BITS_, 8, 8); } while (0)
+#else
+#define KVQ_PH_SHAPE(IDT_, BITS_) KVQ_PH(IDT_, BITS_, 16, 4)
+#endif
       if (PHASE == 1 || bits == 8) {  // the abs-max phase never looks at BITS: one instantiation (8)
         if (in_dtype == KVQ_F16) KVQ_PH_SHAPE(KVQ_F16, 8);
         else KVQ_PH_SHAPE(KVQ_BF16, 8);

@@ -313,7 +313,7 @@ class ShardedQuantBuffers:
             self.ev_reduced = [torch.cuda.Event() for _ in self.chunks]
 
 
-def quantize_tokens_batch_sharded(x_local, kind: str, eps: float = 1e-8, out: "ShardedQuantBuffers" = None):
+def quantize_tokens_batch_sharded(x_local, kind: str, eps: float = 1e-8, out: "ShardedQuantBuffers" = None, two_phase: bool = None):
     """Quantise this rank's batch rows ``x_local`` (``[G,B_local,H,T,D]`` on the GPU, or a list of G
     ``[B_local,H,T,D]`` tensors) of a slice whose batch is split over the ranks, with the scale of
     the WHOLE batch (reference ops.py:27,48: one ``abs().max()`` per ``[B,H,1,D]`` slice), layer chunk by layer chunk:
@@ -325,7 +325,11 @@ def quantize_tokens_batch_sharded(x_local, kind: str, eps: float = 1e-8, out: "S
     Returns ``(q, scales)`` as `kernels.quant_tokens` does for the un-sharded batch: ``q`` holds
     this rank's rows, ``scales`` ``[G,T]`` (stored scales widened to fp32) is identical on every
     rank and bit-identical to the un-sharded result. ``out``: reuse these buffers (a decode / prefill loop builds them
-    once); the returned tensors are then ``out.q`` / ``out.scales``."""
+    once); the returned tensors are then ``out.q`` / ``out.scales``.
+
+    On a single rank there is nothing to exchange and the slice takes the un-sharded call (`kernels.quant_tokens`: ONE pass
+    over the input — the 1024-thread register tile for batches of up to 131072 elements per token); ``two_phase=True``
+    runs the phases a rank of a larger job runs anyway (bench.py reports both at N = 1)."""
     from . import kernels as K
     if out is None:
         out = ShardedQuantBuffers(x_local, kind)
@@ -333,6 +337,13 @@ def quantize_tokens_batch_sharded(x_local, kind: str, eps: float = 1e-8, out: "S
     if len(x_local) != G or tuple(x_local[0].shape) != (B, H, T, D) or out.kind != kind:
         raise ValueError(f"kvq: ShardedQuantBuffers were built for {out.shape} {out.kind}, got {len(x_local)} x {tuple(x_local[0].shape)} {kind}")
     _, ws = world()
+    if two_phase is None:
+        two_phase = ws > 1 or out.overlap
+    if not two_phase:
+        if ws > 1:
+            raise ValueError("kvq: a batch split over ranks needs the abs-max exchange (two_phase=False is for one rank)")
+        K.quant_tokens(x_local, out.q, out.scales, out.absmax, kind, eps)
+        return out.q, out.scales
 
     def quant(c):
         g0, g1 = out.chunks[c]

@@ -283,7 +283,8 @@ int64_t kvq_kernel_log(char* buf, int64_t n);
  * Test knobs (every build) route a call to SHIPPED code it would not take by size or shape; results never change:
  *   "quant_force_two_pass" (0/1: generic two-pass quantise), "quant_direct_stores" (0/1: no LDS-staged stores in the
  *   256-thread quantise kernel), "quant_tile" (1 = compile-time one-wave tile kernel where the shape has one, default;
- *   0 = general kernels), "quant_block" (general quantise kernel: 64-thread one-wave tiles, default, or 256; 128 in A-B builds), "pool_wave" (1 = one wave per output row where the shape allows, default; 0 = per-lane-group
+ *   0 = general kernels), "quant_wide" (1 = single-pass 1024-thread register tile for batched slices of 16384 < B*H*D <=
+ *   131072 two-byte elements, default; 0 = split phases / swept tile), "quant_block" (general quantise kernel: 64-thread one-wave tiles, default, or 256; 128 in A-B builds), "pool_wave" (1 = one wave per output row where the shape allows, default; 0 = per-lane-group
  *   walk), "attn_force_valu" (0/1), "attn_stream_tpw" (tiles per wave of the streaming attention kernel: -1 never,
  *   0 by size, > 0 that many), "attn_lds" (LDS-staged MFMA attention: -1 by shape, 0 never, 1 wherever it applies).
  * A-B keys select variants that lost a measurement and exist only in the A-B library (`make -C csrc ab` ->

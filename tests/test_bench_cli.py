@@ -99,11 +99,12 @@ def test_bench_line_carries_the_contract_fields(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
-                           "--cpu-sample-layers", "1"], capture_output=True, text=True, timeout=900, cwd=root)
+                           "--cpu-sample-layers", "1", "--cpu-reps", "1"], capture_output=True, text=True, timeout=900, cwd=root)
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     j = json.loads(lines[0])
+    print("bench phases_s:", j.get("phases_s"), "run_s:", j.get("run_s"))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline", "decode", "configs", "public_api"):
         assert key in j, key
@@ -139,6 +140,11 @@ def test_bench_line_carries_the_contract_fields(tmp_path):
     assert "error" not in ev, ev
     assert ev["roofline"]["kernel"].startswith("chunk_pool_wave_k<0, 4, 16>") and ev["roofline_window"]["kernel"].startswith("copy_rows_k<")
     assert 0.5 < ev["roofline"]["frac"] < 1.0 and 0.3 < ev["roofline_window"]["frac"] < 1.0
+    sq = j["sharded_quant"]  # one rank: the batch-64 slice in ONE pass, the two phases of an N > 1 rank beside it
+    assert "error" not in sq, sq
+    assert sq["kernels"] == "quant_wide_k<0, 8, 1024, 16> + quant_wide_k<0, 4, 1024, 16>", sq["kernels"]
+    assert sq["two_phase"]["kernels"].startswith("quant_tile_k<0, 8, 8, 16, 4, 1> + quant_tile_k<0, 8, 8, 16, 4, 2>"), sq["two_phase"]
+    assert sq["value"] > sq["two_phase"]["value"] > 0 and sq["config"]["collective_backend"] == "none (1 rank)"
     c = j["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key

@@ -391,7 +391,7 @@ def test_decode_attn_fused_workspace_reuse(K, tunable, shape):
 
 @pytest.mark.parametrize("lds", [-1, pytest.param(0, marks=pytest.mark.ab)])  # 0 (A-B library): the register-staged kernel
 @pytest.mark.parametrize("tc", [64, pytest.param(32, marks=pytest.mark.ab)])
-@pytest.mark.parametrize("tpw", [1, 2, 3, 5])
+@pytest.mark.parametrize("tpw", [pytest.param(1, marks=pytest.mark.ab), 2, pytest.param(3, marks=pytest.mark.ab), 5])  # shipped library: 1 / 3 tiles per wave are test_decode_attn_lds_staged_kernel's
 def test_decode_attn_streaming_kernel_matches_oracle(K, tunable, tc, tpw, lds):
     """decode_attn_stream_mfma_k (one wave walks `tpw` tiles with the next tile's rows in flight, online
     softmax across tiles): forced on small shapes through the tunables — odd / even tile counts per wave, a
@@ -444,13 +444,15 @@ def test_decode_attn_lds_staged_kernel(K, tunable, tpw, which):
     from efficient_llm_inference_amd import _lib
     tunable("attn_stream_tpw", tpw)
     tunable("attn_lds", which)
+    every = tpw == 3 or which != 1  # the shipped kernel: every kind pair at 3 tiles per wave, the headline pair (+ bf16) at the other splits
     for case in LDS_CASES:
         big = case[0] * case[3] > 20000  # the batch-8 case: the float64 oracle on the host is what takes the time
-        for kinds in (("int8", "int4"),) if big else (("int8", "int4"), ("int4", "int8"), ("int8", "int8"), ("int4", "int4")):
+        for kinds in (("int8", "int4"),) if big or not every else (("int8", "int4"), ("int4", "int8"), ("int8", "int8"), ("int4", "int4")):
             _run_case(K, *case, kinds[0], kinds[1], "f16", True)
         if not big:
             _run_case(K, *case, "int8", "int4", "bf16", True)
-            _run_case(K, *case, "int8", "int4", "f16", False)
+            if every:
+                _run_case(K, *case, "int8", "int4", "f16", False)
     if tpw:
         _lib.kernel_log_clear()
         _run_case(K, 2, 32, 8, 1500, 128, "int8", "int4", "f16", True)

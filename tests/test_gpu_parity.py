@@ -136,10 +136,11 @@ CASES = [  # (G, B, H, T, D)
 ]
 
 
-def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3, direct_stores=False, block=64, tile=1, **ab):
+def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3, direct_stores=False, block=64, tile=1, wide=1, **ab):
     """quantise through the C ABI into a window of a larger store. Test knobs (every build): force_two_pass,
     direct_stores, block (64 | 256: the one-wave or the 256-thread general kernel), tile (1 = the compile-time tile
-    kernel where the shape has one). **ab: A-B keys (quant_nv, quant_tpw, ...; `pytest -m ab` only)."""
+    kernel where the shape has one), wide (1 = the single-pass 1024-thread tile for 16384 < B*H*D <= 131072).
+    **ab: A-B keys (quant_nv, quant_tpw, ...; `pytest -m ab` only)."""
     from efficient_llm_inference_amd import kernels
     G, B, H, T, D = x_np.shape
     x = to_torch(x_np, dtype)
@@ -148,7 +149,7 @@ def _quant_via_kernels(E, x_np, dtype, kind, force_two_pass, as_list, tcap_pad=3
     scales = torch.zeros(G, T + tcap_pad, dtype=torch.float32, device="cuda")
     ws = torch.empty(G * T + 8, dtype=torch.float32, device="cuda")
     with tunables(quant_force_two_pass=int(force_two_pass), quant_direct_stores=int(direct_stores), quant_block=int(block),
-                  quant_tile=int(tile), **ab):
+                  quant_tile=int(tile), quant_wide=int(wide), **ab):
         src = [x[g] for g in range(G)] if as_list else x
         kernels.quant_tokens(src, store[:, :, :, 1:T + 1], scales[:, 1:T + 1], ws, kind)
     torch.cuda.synchronize()
@@ -199,6 +200,64 @@ def test_oracle_quant_dequant_tokens(E, case, dtype, kind):
             ref = O.dequantize_tokens(q_ref, s32_ref, kind, D, od)
             assert np.array_equal(bits(out[:, :, :, :T]), bits(ref)), (dist, od)
             assert float(out[:, :, :, T:].float().abs().sum()) == 0.0
+
+
+WIDE_CASES = [  # (G, B, H, T, D): 16384 < B*H*D <= 131072 -> quant_wide_k (two-byte inputs)
+    (1, 32, 8, 70, 128),   # 4 tokens per workgroup, ragged last tile
+    (2, 64, 8, 33, 128),   # Llama-3-8B batch 64: 2 tokens per workgroup, odd token count
+    (1, 128, 8, 5, 128),   # the largest slice the register tile holds: 1 token per workgroup
+    (2, 40, 8, 21, 64),    # 320 rows of 64: rounds partly filled
+    (1, 10, 5, 9, 512),    # D/8 = 64: a row run of 256 vectors, 4 rows per round
+    (3, 64, 8, 1, 128),    # batch-64 decode append
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES)
+@pytest.mark.parametrize("kind", ["int8", "int4"])
+def test_quant_wide_tile(E, case, kind):
+    """Batched slices larger than the one-wave tile: the single-pass 1024-thread kernel (default), the split-phase tile
+    kernels (quant_wide = 0, head_dim 128) and the swept tile (quant_wide = 0, quant_tile = 0) all give the oracle's bytes
+    and stored scales; the kernel log shows which one ran."""
+    from efficient_llm_inference_amd import _lib
+    G, B, H, T, D = case
+    for dtype, dist, as_list in (("f16", "heavy", False), ("bf16", "tiny", True)):
+        x_np = seeded_kv(case, dtype, seed=zlib.crc32(repr((case, dtype, kind, dist, "wide")).encode()), dist=dist)
+        q_ref, _, s32_ref = O.quantize_tokens(x_np, kind, dtype=odt(dtype))
+        for wide, tile in ((1, 1), (0, 1), (0, 0)):
+            _lib.kernel_log_clear()
+            store, scales = _quant_via_kernels(E, x_np, dtype, kind, False, as_list, wide=wide, tile=tile)
+            log = _lib.kernel_log()
+            assert np.array_equal(to_numpy(store[:, :, :, 1:T + 1]), q_ref), (dist, wide, tile, log)
+            assert np.array_equal(bits(scales[:, 1:T + 1]), bits(s32_ref)), (dist, wide, tile, log)
+            if wide:
+                assert log and all(k.startswith("quant_wide_k<") for k in log), log
+            else:
+                assert not any(k.startswith("quant_wide_k<") for k in log), log
+                if tile and D == 128:
+                    assert any(k.startswith("quant_tile_k<") and k.endswith(", 2>") for k in log), log
+
+
+@pytest.mark.parametrize("kind", ["int8", "int4"])
+def test_quant_wide_tile_strided_batch_rows(E, kind):
+    """Every second batch row of a larger tensor (input batch stride != H * head stride) into every second batch row of a
+    larger store: the wide kernel serves it when its rows-per-round is a multiple of H (H = 8), other layouts fall through
+    to the general kernels (H = 5: 4 rows per round) — same bytes either way."""
+    from efficient_llm_inference_amd import _lib, kernels
+    for (G, B, H, T, D), served in (((2, 64, 8, 19, 128), True), ((1, 10, 5, 9, 512), False)):
+        x_np = seeded_kv((G, 2 * B, H, T, D), "f16", seed=B + H, dist="heavy")
+        q_ref, _, s32_ref = O.quantize_tokens(np.ascontiguousarray(x_np[:, ::2]), kind, dtype=odt("f16"))
+        x = to_torch(x_np, "f16")
+        Dq = kernels.packed_dim(kind, D)
+        store = torch.zeros(G, 2 * B, H, T, Dq, dtype=kernels.QDTYPE[kind], device="cuda")
+        scales = torch.zeros(G, T, dtype=torch.float32, device="cuda")
+        ws = torch.empty(G * T, dtype=torch.float32, device="cuda")
+        _lib.kernel_log_clear()
+        kernels.quant_tokens(x[:, ::2], store[:, 1::2], scales, ws, kind)
+        torch.cuda.synchronize()
+        log = _lib.kernel_log()
+        assert any(k.startswith("quant_wide_k<") for k in log) == served, log
+        assert np.array_equal(to_numpy(store[:, 1::2]), q_ref) and np.array_equal(bits(scales), bits(s32_ref)), log
+        assert int(store[:, 0::2].to(torch.int32).abs().sum()) == 0
 
 
 @pytest.mark.ab

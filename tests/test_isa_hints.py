@@ -67,6 +67,22 @@ def test_split_phase_tiles_keep_phase_one_rows_cacheable(quant_asm):
     assert not re.findall(r"buffer_store", p1) and re.findall(r"global_atomic_umax", p1)
 
 
+@pytest.mark.parametrize("bits", [4, 8])
+def test_wide_quantise_tile_holds_its_slice_in_registers(quant_asm, bits):
+    # quant_wide_k<f16, BITS, 1024, 16>: sixteen 16-byte non-temporal loads per lane, sixteen non-temporal stores of the
+    # packed vector (4 / 8 bytes), no scratch: the 64 data VGPRs + arithmetic fit the 128 a 1024-thread workgroup's lanes have
+    sym = r"_ZN3kvq12quant_wide_kILi0ELi%dELi1024ELi16EEEvNS_13QuantWideArgsE" % bits
+    body = _kernel_body(quant_asm, sym)
+    loads = re.findall(r"global_load_dwordx4[^\n]*", body)
+    assert len(loads) == 16 and all(l.rstrip().endswith(" nt") for l in loads), loads
+    stores = re.findall(r"global_store_dword%s [^\n]*" % ("x2" if bits == 8 else ""), body)
+    nt = [s for s in stores if s.rstrip().endswith(" nt")]  # (INT4: the one plain dword store is the per-token scale)
+    assert len(nt) == 16 and len(stores) - len(nt) <= 1, stores
+    assert "scratch_" not in body
+    m = re.search(r"\.amdhsa_kernel %s\b.*?\.amdhsa_next_free_vgpr (\d+)" % sym, quant_asm, flags=re.S)
+    assert m and int(m.group(1)) <= 128, m and m.group(1)
+
+
 def test_pool_kernels_issue_non_temporal_loads(evict_asm):
     wave = _kernel_body(evict_asm, r"_ZN3kvq17chunk_pool_wave_kILi0ELi4ELi16EEEvNS_8PoolArgsE")
     loads = re.findall(r"buffer_load_dwordx4[^\n]*", wave)

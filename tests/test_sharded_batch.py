@@ -213,3 +213,28 @@ def test_rccl_group_comes_up_on_one_rank():
     p.join(timeout=120)
     assert p.exitcode == 0 and backend == reported == "nccl" and vals == [3.0] * 4
     assert chunked == {"int8": True, "int4": True}, chunked
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["int8", "int4"])
+def test_single_rank_takes_one_pass_and_equals_the_two_phases(kind):
+    """One rank, nothing to exchange: `quantize_tokens_batch_sharded` takes the un-sharded single-pass call (the 1024-thread
+    register tile for a batch-64 slice); `two_phase=True` runs the abs-max and quantise phases a rank of a larger job runs.
+    Same bytes, same stored scales, both equal to the oracle; the kernel log tells the two apart."""
+    from efficient_llm_inference_amd import _lib, sharding
+    shape = (2, 64, 8, 17, 128)
+    x = _batch("f16", shape)
+    xt = to_torch(x, "f16")
+    q_ref, _, s32_ref = O.quantize_tokens(x, kind, dtype=odt("f16"))
+    bufs = sharding.ShardedQuantBuffers(xt, kind)
+    logs = {}
+    for two_phase in (None, True):
+        bufs.q.zero_()
+        bufs.scales.zero_()
+        _lib.kernel_log_clear()
+        qq, sc = sharding.quantize_tokens_batch_sharded(xt, kind, out=bufs, two_phase=two_phase)
+        torch.cuda.synchronize()
+        logs[two_phase] = _lib.kernel_log()
+        assert np.array_equal(to_numpy(qq), q_ref) and np.array_equal(to_numpy(sc).view(np.uint32), s32_ref.view(np.uint32)), (two_phase, logs)
+    assert len(logs[None]) == 1 and logs[None][0].startswith("quant_wide_k<"), logs
+    assert [k.rsplit(", ", 1)[-1] for k in logs[True]] == ["1>", "2>"] and all(k.startswith("quant_tile_k<") for k in logs[True]), logs
