@@ -99,6 +99,7 @@ static const TunableKey kTunableKeys[] = {
     {"quant_lds_pad", &Tunables::quant_lds_pad, true},
     {"quant_tpw", &Tunables::quant_tpw, true},
     {"quant_nt_stores", &Tunables::quant_nt_stores, true},
+    {"quant_wide_blk", &Tunables::quant_wide_blk, true},
     {"quant_geo128", &Tunables::quant_geo128, true},
     {"quant_tile_tt", &Tunables::quant_tile_tt, true},
     {"quant_tile_tpw", &Tunables::quant_tile_tpw, true},

@@ -85,6 +85,7 @@ struct Tunables {
   int64_t pool_block;            // chunk mean-pool workgroup size: 64 (default, +7 %), 128 or 256
   int64_t quant_nv;              // 4 = 2048-element one-wave tiles, 16 = 8192, else 8
   int64_t quant_no_regmax;       // 1 = keep the LDS abs-max in one-wave tiles
+  int64_t quant_wide_blk;        // wide quantise tile: 1024 threads (default) | 512 (two workgroups per CU, half the tile)
   int64_t quant_geo128;          // round 2's GEO128 instantiation of the general kernel instead of the tile kernel (needs quant_tile = 0)
   int64_t quant_nt_stores;       // GEO128 kernel: non-temporal output stores (1), write-back stores (0), -1 (default) = as nt_loads
   int64_t quant_tpw;             // tiles per wave of the pipelined one-wave quantise kernel (2 | 4 | 8); 0 = one tile per wave

@@ -1242,7 +1242,8 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
   if (big && !anydv && in_dtype != KVQ_F32 && tunables().quant_wide != 0 && !tunables().quant_force_two_pass &&
       (d->T == 1 || (a.is.t == d->D && a.qs.t == Dq)) && (a.is.b * esz) % 16 == 0 && (a.is.h * esz) % 16 == 0 &&
       a.qs.b % qvec == 0 && a.qs.h % qvec == 0 && a.qs.g % qvec == 0 && aligned(q, qvec)) {
-    constexpr int kWideBlk = 1024, kWideNV = 16;
+    constexpr int kWideNV = 16;
+    const int kWideBlk = KVQ_AB && tunables().quant_wide_blk == 512 ? 512 : 1024;  // (A-B: two 512-thread workgroups per CU)
     const int64_t cap = (int64_t)kWideBlk * kWideNV * 8;  // elements a workgroup holds
     if (R * d->D <= cap) {
       uint32_t tt = pow2_floor((uint64_t)(cap / (R * d->D)));
@@ -1279,8 +1280,14 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
           wa.q = q + g0 * a.qs.g;
           wa.scales = scales + g0 * ssg;
           const dim3 grid((unsigned)((d->T + tt - 1) / tt), (unsigned)gn);
-          if (in_dtype == KVQ_F16) KVQ_LAUNCH((quant_wide_k<KVQ_F16, BITS, kWideBlk, kWideNV>), grid, dim3(kWideBlk), 0, st, wa);
-          else KVQ_LAUNCH((quant_wide_k<KVQ_BF16, BITS, kWideBlk, kWideNV>), grid, dim3(kWideBlk), 0, st, wa);
+#if KVQ_AB
+          if (kWideBlk == 512) {
+            if (in_dtype == KVQ_F16) KVQ_LAUNCH((quant_wide_k<KVQ_F16, BITS, 512, kWideNV>), grid, dim3(512), 0, st, wa);
+            else KVQ_LAUNCH((quant_wide_k<KVQ_BF16, BITS, 512, kWideNV>), grid, dim3(512), 0, st, wa);
+          } else
+#endif
+          if (in_dtype == KVQ_F16) KVQ_LAUNCH((quant_wide_k<KVQ_F16, BITS, 1024, kWideNV>), grid, dim3(1024), 0, st, wa);
+          else KVQ_LAUNCH((quant_wide_k<KVQ_BF16, BITS, 1024, kWideNV>), grid, dim3(1024), 0, st, wa);
           const int rc = check_launch(name);
           if (rc) return rc;
         }

@@ -237,6 +237,20 @@ def test_quant_wide_tile(E, case, kind):
                     assert any(k.startswith("quant_tile_k<") and k.endswith(", 2>") for k in log), log
 
 
+@pytest.mark.ab
+@pytest.mark.parametrize("case", WIDE_CASES[:5])
+@pytest.mark.parametrize("kind", ["int8", "int4"])
+def test_quant_wide_tile_512_thread_variant(E, case, kind):
+    """A-B library: the wide tile as 512-thread workgroups (two per CU, half the elements each) — same bytes; slices
+    above its 65536 elements fall through to the other kernels."""
+    G, B, H, T, D = case
+    for dtype, dist in (("f16", "heavy"), ("bf16", "tiny")):
+        x_np = seeded_kv(case, dtype, seed=zlib.crc32(repr((case, dtype, kind, dist, "wide512")).encode()), dist=dist)
+        q_ref, _, s32_ref = O.quantize_tokens(x_np, kind, dtype=odt(dtype))
+        store, scales = _quant_via_kernels(E, x_np, dtype, kind, False, False, quant_wide_blk=512)
+        assert np.array_equal(to_numpy(store[:, :, :, 1:T + 1]), q_ref) and np.array_equal(bits(scales[:, 1:T + 1]), bits(s32_ref)), (dtype, dist)
+
+
 @pytest.mark.parametrize("kind", ["int8", "int4"])
 def test_quant_wide_tile_strided_batch_rows(E, kind):
     """Every second batch row of a larger tensor (input batch stride != H * head stride) into every second batch row of a
