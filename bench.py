@@ -101,7 +101,7 @@ def parse():
                          "step re-reads lines the 256 MiB Infinity Cache may still hold (1 = the decode loop's "
                          "behaviour: the same cache every step; its 256 MiB INT4 store then stays cache-resident)")
     ap.add_argument("--cpu-sample-layers", type=int, default=8)
-    ap.add_argument("--cpu-reps", type=int, default=5, help="timed repetitions per cpu_baseline entry (median reported)")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="timed repetitions per cpu_baseline entry (median reported)")
     ap.add_argument("--tunable", action="append", default=[], metavar="KEY=VALUE",
                     help="kvq_set_tunable(KEY, VALUE) before the run (include/kvq_hip.h lists the keys; A-B keys need "
                          "KVQ_HIP_LIB=<pkg>/lib/ab/libkvq_hip.so)")
