@@ -110,6 +110,7 @@ static const TunableKey kTunableKeys[] = {
     {"attn_merge_fast", &Tunables::attn_merge_fast, true},
     {"attn_stream_roll", &Tunables::attn_stream_roll, true},
     {"attn_lds_nb", &Tunables::attn_lds_nb, true},
+    {"attn_tg", &Tunables::attn_tg, true},
     {"attn_lds_tc", &Tunables::attn_lds_tc, true},
     {"attn_stream_slots", &Tunables::attn_stream_slots, true},
     {"attn_stream_tc", &Tunables::attn_stream_tc, true},

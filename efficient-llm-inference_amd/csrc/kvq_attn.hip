@@ -915,8 +915,16 @@ __global__ __launch_bounds__(kWave) void decode_attn_partial_mfma_k(const AttnAr
 // 12 KB tile per wave x 2048 waves is 24 MB). Batch 8, 16 K tokens: 49.4 -> 44.8 us per call.
 // (Also measured: the INT4 V tile as 16-byte loads redistributed through an LDS image — 4 load instructions instead
 // of 16: 2 us faster with the arithmetic removed, nothing with it, slower together with ROLL; not kept.)
-template <int KBITS, int VBITS, int TC, int HD, bool KI8 = false, bool ROLL = false>
+// TG = 4 (int8 keys, at most 4 query heads per kv head — Llama-3 / Mistral grouping, 64-token tiles): the score product
+// as ONE 16 x 16 output per int8 plane for the whole tile instead of four with 12 of 16 columns padding. Column j = (token
+// group j >> 2, head j & 3): the MFMA of token group tg and d-half c multiplies that group's K rows by a query operand that
+// is zero outside the four columns of tg, and all eight accumulate into the same registers (block-diagonal over the
+// contraction: the same sixteen MFMAs per tile). Every lane then holds 4 real scores (head x & 3, tokens 16 (x >> 2) + 4 g
+// + q) instead of 16 of which 12 are padding: a quarter of the softmax arithmetic (scale, max, exp2, sum, V-scale, f16
+// pack); P reaches the P·V operand layout (row = head, 8 tokens per lane) by three DPP row rotations of two registers.
+template <int KBITS, int VBITS, int TC, int HD, bool KI8 = false, bool ROLL = false, int TG = 1>
 struct AttnStream {
+  static_assert(TG == 1 || (TG == 4 && KI8 && TC == 64), "TG = 4: int8 keys, 64-token tiles");
   typedef AttnTile<KBITS, VBITS, TC, HD> TL;
   static constexpr int NT = TL::NT, NS = TL::NS, KS = TL::KS, DVN = TL::DVN, CBK = TL::CBK, NL = TL::NL, SPL = TL::SPL, VB = TL::VB;
   static constexpr int SR = (TC + kWave - 1) / kWave;
@@ -927,6 +935,7 @@ struct AttnStream {
   };
   f16x8 qb[KS];
   QPlanes qi[KI8 ? NL : 1];  // INT8 K through the int8 MFMA: the query as two int8 planes, aq their scale
+  QPlanes qt[TG == 4 ? 4 : 1][TG == 4 ? NL : 1];  // TG = 4: qi masked to the columns of token group tg
   float aq;
   float m, l, svref;
   f32x4 acc[DVN];
@@ -934,7 +943,8 @@ struct AttnStream {
   __device__ __forceinline__ void init(const AttnArgs& a, const uint32_t b, const uint32_t hk) {
     const uint32_t lane = threadIdx.x & 63u, x = lane & 15u, g = lane >> 4;
     uint32_t w[4 * KS];
-    const uint32_t hx = x < a.nq ? x : 0u;  // padded heads read head 0 and are zeroed below
+    const uint32_t xh = TG == 4 ? (x & 3u) : x;  // the head this lane's column stands for
+    const uint32_t hx = xh < a.nq ? xh : 0u;     // padded heads read head 0 and are zeroed below
     const char* qp = reinterpret_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)(hk * a.nq + hx) * a.q_sh) * 2;
 #pragma unroll
     for (int c = 0; c < NL; ++c)
@@ -961,7 +971,7 @@ struct AttnStream {
         w[4 * c + 3] = __builtin_amdgcn_perm(w3, w2, 0x07060302u);  // (q5, q7)
       }
     }
-    if (x >= a.nq) {
+    if (xh >= a.nq) {
 #pragma unroll
       for (int j = 0; j < 4 * KS; ++j) w[j] = 0u;
     }
@@ -981,6 +991,16 @@ struct AttnStream {
 #pragma unroll
         for (int j = 0; j < 8; ++j) wc[j] = w[8 * c + j];
         qi[c] = quantize_q16(wc, inv);
+      }
+      if constexpr (TG == 4) {
+        const i32x4 zero = {0, 0, 0, 0};
+#pragma unroll
+        for (int tg = 0; tg < 4; ++tg)
+#pragma unroll
+          for (int c = 0; c < NL; ++c) {
+            qt[tg][c].p1 = (x >> 2) == (uint32_t)tg ? qi[c].p1 : zero;
+            qt[tg][c].p2 = (x >> 2) == (uint32_t)tg ? qi[c].p2 : zero;
+          }
       }
     }
     m = -INFINITY;
@@ -1108,6 +1128,67 @@ struct AttnStream {
       }
     }
     if constexpr (ROLL) issue_scales(a, nx, r);
+    uint32_t pp[NS][4];  // P of this tile as the P·V operand: 8 tokens of head x per lane and 32-token step, f16 pairs
+    float alpha;
+    if constexpr (TG == 4) {
+      // ---- S = K Q^T, one output for the tile: column x = (token group x >> 2, head x & 3) ---------------------------
+      i32x4 c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
+#pragma unroll
+      for (int tg = 0; tg < 4; ++tg) {
+#pragma unroll
+        for (int c = 0; c < NL; ++c) {
+          const i32x4 ka = {(int)r.k[tg][c][0], (int)r.k[tg][c][1], (int)r.k[tg][c][2], (int)r.k[tg][c][3]};
+          c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ka, qt[tg][c].p1, c1, 0, 0, 0);
+          c2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ka, qt[tg][c].p2, c2, 0, 0, 0);
+        }
+        if constexpr (ROLL) issue_k(a, nx, tg, r);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // s_ks / s_vs written above by this wave's lanes
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // ---- online softmax (log2 domain): 4 scores per lane, tokens tb .. tb + 3 of head x & 3 -------------------------
+      const uint32_t tb = 16u * (x >> 2) + 4u * g;
+      const f32x4 ks = *reinterpret_cast<const f32x4*>(&s_ks[tb]);
+      float s4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s4[q] = fmaf((float)c2[q], 1.0f / 254.0f, (float)c1[q]) * aq * ks[q];
+      if (!full) {  // uniform: only a ragged last tile pays for the masks
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (tb + (uint32_t)q >= nt) s4[q] = -INFINITY;
+      }
+      float mt = fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3]));
+      // across the head's 16 lanes: the four token groups of the row (rotations by 8 and 4 lanes), the four rows
+      mt = fmaxf(mt, __uint_as_float(dpp_u32_attn<0x128>(__float_as_uint(mt))));
+      mt = fmaxf(mt, __uint_as_float(dpp_u32_attn<0x124>(__float_as_uint(mt))));
+      mt = xor32_max(xor16_max(mt));
+      const float mnew = fmaxf(m, mt);                 // finite: every tile holds >= 1 token
+      alpha = __builtin_amdgcn_exp2f(m - mnew);        // first tile: 2^(-inf) = 0
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(&s_vs[tb]);
+      float lt = 0.0f, pv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float p = __builtin_amdgcn_exp2f(s4[q] - mnew);  // tokens past nt: 2^(-inf) = 0
+        lt += p;
+        pv[q] = p * sv[q];
+      }
+      lt += __uint_as_float(dpp_u32_attn<0x128>(__float_as_uint(lt)));
+      lt += __uint_as_float(dpp_u32_attn<0x124>(__float_as_uint(lt)));
+      lt = xor32_add(xor16_add(lt));
+      l = l * alpha + lt;
+      m = mnew;
+      // P·V operand of lane x (row = head x for x < 4; the other rows are padding): token group i comes from lane x + 4 i
+      // of the row (row_ror:n hands lane i the value of lane i - n)
+      const uint32_t p01 = Elem<KVQ_F16>::pack2(pv[0], pv[1]), p23 = Elem<KVQ_F16>::pack2(pv[2], pv[3]);
+      pp[0][0] = p01;
+      pp[0][1] = p23;
+      pp[0][2] = dpp_u32_attn<0x12C>(p01);
+      pp[0][3] = dpp_u32_attn<0x12C>(p23);
+      pp[1][0] = dpp_u32_attn<0x128>(p01);
+      pp[1][1] = dpp_u32_attn<0x128>(p23);
+      pp[1][2] = dpp_u32_attn<0x124>(p01);
+      pp[1][3] = dpp_u32_attn<0x124>(p23);
+    } else {
     // ---- S = K Q^T ------------------------------------------------------------------------------------------
     f32x4 sc[NT];
 #pragma unroll
@@ -1170,7 +1251,7 @@ struct AttnStream {
     }
     mt = xor32_max(xor16_max(mt));
     const float mnew = fmaxf(m, mt);                          // finite: every tile holds >= 1 token
-    const float alpha = __builtin_amdgcn_exp2f(m - mnew);     // first tile: 2^(-inf) = 0
+    alpha = __builtin_amdgcn_exp2f(m - mnew);     // first tile: 2^(-inf) = 0
     float lt = 0.0f;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -1185,6 +1266,14 @@ struct AttnStream {
     lt = xor32_add(xor16_add(lt));
     l = l * alpha + lt;
     m = mnew;
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      pp[sidx][0] = Elem<KVQ_F16>::pack2(sc[2 * sidx][0], sc[2 * sidx][1]);
+      pp[sidx][1] = Elem<KVQ_F16>::pack2(sc[2 * sidx][2], sc[2 * sidx][3]);
+      pp[sidx][2] = Elem<KVQ_F16>::pack2(sc[2 * sidx + 1][0], sc[2 * sidx + 1][1]);
+      pp[sidx][3] = Elem<KVQ_F16>::pack2(sc[2 * sidx + 1][2], sc[2 * sidx + 1][3]);
+    }
+    }
     // the accumulator rows of this lane are heads 4 g + q: their alpha lives in lanes x = 4 g + q
     if (g == 0u) s_al[x] = alpha * ratio;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1213,9 +1302,7 @@ struct AttnStream {
         }
       }
       if constexpr (ROLL) issue_v(a, nx, sidx, r);
-      const f16x8 pa = pack_h8(Elem<KVQ_F16>::pack2(sc[2 * sidx][0], sc[2 * sidx][1]), Elem<KVQ_F16>::pack2(sc[2 * sidx][2], sc[2 * sidx][3]),
-                               Elem<KVQ_F16>::pack2(sc[2 * sidx + 1][0], sc[2 * sidx + 1][1]),
-                               Elem<KVQ_F16>::pack2(sc[2 * sidx + 1][2], sc[2 * sidx + 1][3]));
+      const f16x8 pa = pack_h8(pp[sidx][0], pp[sidx][1], pp[sidx][2], pp[sidx][3]);
       constexpr int BIAS = VBITS == 8 ? 128 : 8;
 #pragma unroll
       for (int half = 0; half < DVN / 4; ++half) {
@@ -1341,8 +1428,8 @@ __device__ __forceinline__ void wait_vmcnt() {  // s_waitcnt vmcnt(N) only (expc
 // MFMA operand fragments of one tile out of its LDS image (K rows swizzled as k_swizzle says, V rows plain), in
 // AttnStream::Raw's register layout: lane (x, g) takes the 16 K bytes of row 16 i + x at chunk 4 c + g, and the V bytes
 // of its eight token rows per 32-token step.
-template <int KBITS, int VBITS, int TC, bool KI8>
-__device__ __forceinline__ void read_fragments(const uint8_t* img, typename AttnStream<KBITS, VBITS, TC, 128, KI8, false>::Raw& r) {
+template <int KBITS, int VBITS, int TC, bool KI8, class RAW>
+__device__ __forceinline__ void read_fragments(const uint8_t* img, RAW& r) {  // RAW: AttnStream<...>::Raw of any TG
   typedef AttnStream<KBITS, VBITS, TC, 128, KI8, false> ST;
   constexpr int NT = ST::NT, NS = ST::NS, NL = ST::NL, VB = ST::VB;
   constexpr int KROW = 128 * KBITS / 8, VROW = 128 * VBITS / 8;
@@ -1374,10 +1461,10 @@ __device__ __forceinline__ void read_fragments(const uint8_t* img, typename Attn
   }
 }
 
-template <int KBITS, int VBITS, int TC, bool KI8, int NB>
+template <int KBITS, int VBITS, int TC, bool KI8, int NB, int TG = 1>
 __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_lds_mfma_k(const AttnArgs a, const uint32_t tpw) {
   constexpr int HD = 128;
-  typedef AttnStream<KBITS, VBITS, TC, HD, KI8, false> ST;
+  typedef AttnStream<KBITS, VBITS, TC, HD, KI8, false, TG> ST;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   constexpr int DVN = ST::DVN;
   static_assert(ST::CBK == 16, "head_dim 128 rows: 16-byte K fragments");
@@ -2381,6 +2468,12 @@ static void launch_partial(const AttnArgs& a, hipStream_t st) {
     if (nb == 3) { KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 64, kI8, 3>), grid, dim3(kWave), (size_t)(3 * kSlot), st, a, a.stream_tpw); return; }
 #endif
     (void)nb;
+    if constexpr (kI8) {  // at most 4 query heads per kv head: one score output per tile (AttnStream TG = 4)
+      if (a.nq <= 4u && !(KVQ_AB && tunables().attn_tg == 1)) {
+        KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 64, kI8, 2, 4>), grid, dim3(kWave), (size_t)(2 * kSlot), st, a, a.stream_tpw);
+        return;
+      }
+    }
     KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 64, kI8, 2>), grid, dim3(kWave), (size_t)(2 * kSlot), st, a, a.stream_tpw);
     return;
   }

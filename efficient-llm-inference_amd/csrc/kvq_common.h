@@ -96,6 +96,7 @@ struct Tunables {
   int64_t attn_mfma_tc;          // tokens per one-wave split of the MFMA kernel: 128 (default) or 64
   int64_t attn_stream_tc;        // tokens per tile of the streaming kernel: 64 (default) or 32
   int64_t attn_stream_slots;     // wave slots the streaming plan fills in one round (default 2048 = 2 per SIMD)
+  int64_t attn_tg;               // LDS-staged kernel, <= 4 query heads per kv head: 0 = one score output per tile (default), 1 = one per 16-token group
   int64_t attn_lds_tc;           // LDS-staged streaming kernel: tokens per tile 64 (default) | 32
   int64_t attn_lds_nb;           // LDS-staged streaming kernel: ring depth 2 | 3 | 4; 0 = by kinds (3 where four workgroups fit a CU)
   int64_t attn_stream_roll;      // streaming kernel, 64-token tiles: re-request a tile's registers piece by piece for the tile after next (1) or whole tiles between reductions (0)

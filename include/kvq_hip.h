@@ -291,10 +291,12 @@ int64_t kvq_kernel_log(char* buf, int64_t n);
  *   lib/ab/libkvq_hip.so, kvq_is_ab_build() == 1); the default library returns KVQ_E_DIMS for them:
  *   dequantise  "dequant_variant" (0..35), "dequant_grid", "dequant_xcd_group"
  *   quantise    "quant_nv" (8|4|16), "quant_lds_pad", "quant_tpw" (0|2|4|8),
- *               "quant_no_regmax", "quant_xcd_group", "quant_geo128", "quant_nt_stores", "quant_tile_tt" (8|4), "nt_loads"
+ *               "quant_no_regmax", "quant_xcd_group", "quant_geo128", "quant_nt_stores", "quant_tile_tt" (8|4), "nt_loads",
+ *               "quant_wide_blk" (1024|512), "quant_tile_tpw" (0|2|4)
  *   eviction    "pool_grid", "pool_block" (64|128|256)
  *   attention   "attn_mfma_min_nq", "attn_mfma_tc" (128|64), "attn_merge_fast" (0 = chained merge by choice),
- *               "attn_stream_tc" (64|32), "attn_stream_slots", "attn_stream_roll", "attn_k_i8" (-1|0|1; tolerance-level
+ *               "attn_stream_tc" (64|32), "attn_stream_slots", "attn_stream_roll", "attn_tg" (1 = one score output per
+ *               16-token group in the LDS-staged kernel at <= 4 query heads per kv head too), "attn_k_i8" (-1|0|1; tolerance-level
  *               difference), "attn_fused" (one launch per call; refused while the stream is being captured into a
  *               HIP graph: its arrival epoch is a launch argument), "attn_fused_tc" / "attn_fused_nw".
  * Returns 0, or KVQ_E_DIMS for an unknown key / an A-B key in the default library. Process-global. */

@@ -456,7 +456,29 @@ def test_decode_attn_lds_staged_kernel(K, tunable, tpw, which):
     if tpw:
         _lib.kernel_log_clear()
         _run_case(K, 2, 32, 8, 1500, 128, "int8", "int4", "f16", True)
-        assert _lib.kernel_log()[0].startswith(("decode_attn_lds_mfma_k<8, 4, 64, true, 2>", "decode_attn_coal_mfma_k<", "decode_attn_lds_mfma_k<8, 4, 64, true, 2>")[which - 1]), _lib.kernel_log()
+        # (4 query heads per kv head: the shipped kernel's one-score-output-per-tile instantiation, TG = 4)
+        assert _lib.kernel_log()[0].startswith(("decode_attn_lds_mfma_k<8, 4, 64, true, 2, 4>", "decode_attn_coal_mfma_k<", "decode_attn_lds_mfma_k<8, 4, 64, true, 2, 4>")[which - 1]), _lib.kernel_log()
+        _lib.kernel_log_clear()
+        _run_case(K, 1, 16, 2, 700, 128, "int8", "int4", "f16", True)  # 8 query heads per kv head: one output per 16-token group
+        if which != 2:
+            assert _lib.kernel_log()[0].startswith("decode_attn_lds_mfma_k<8, 4, 64, true, 2, 1>"), _lib.kernel_log()
+
+
+@pytest.mark.ab
+@pytest.mark.parametrize("tpw", [1, 3])
+def test_decode_attn_lds_kernel_one_output_per_token_group(K, tunable, tpw):
+    """A-B library, attn_tg = 1: the LDS-staged kernel with one score output per 16-token group at <= 4 query heads per
+    kv head too (what shipped before the block-diagonal score product) — against the oracle, like the shipped path."""
+    from efficient_llm_inference_amd import _lib
+    tunable("attn_stream_tpw", tpw)
+    tunable("attn_tg", 1)
+    for case in LDS_CASES:
+        _run_case(K, *case, "int8", "int4", "f16", True)
+        if case[0] * case[3] <= 20000:
+            _run_case(K, *case, "int8", "int8", "bf16", True)
+    _lib.kernel_log_clear()
+    _run_case(K, 2, 32, 8, 1500, 128, "int8", "int4", "f16", True)
+    assert _lib.kernel_log()[0].startswith("decode_attn_lds_mfma_k<8, 4, 64, true, 2, 1>"), _lib.kernel_log()
 
 
 def test_streaming_plan_rejected_falls_back_to_one_tile_splits(K, tunable):
@@ -496,6 +518,7 @@ def test_lds_staged_kernels_equal_the_register_staged_streaming_kernel(K, tunabl
     code (AttnStream::consume)."""
     from efficient_llm_inference_amd import _lib
     tunable("attn_stream_tpw", tpw)
+    tunable("attn_tg", 1)  # one score output per 16-token group on both sides (the shipped TG = 4 path sums l in another order)
     if which > 10:
         tunable("attn_lds_nb", which - 10)
         which = 1
