@@ -355,6 +355,9 @@ __global__ __launch_bounds__(BLK) void quant_tokens_fused_k(const QuantArgs a) {
 #ifndef KVQ_TILE_DIRECT
 #define KVQ_TILE_DIRECT 0
 #endif
+#ifndef KVQ_TILE_PRIO  // calibration (`make calib_prio`): 1 = raise the wave's priority once its loads are issued, 2 = high while issuing the loads, low after
+#define KVQ_TILE_PRIO 0
+#endif
 struct QuantTileArgs {
   PtrTable in;      // per-group input base pointers
   uint8_t* q;       // store base of this launch's first group
@@ -405,9 +408,17 @@ __global__ __launch_bounds__(kWave) void quant_tile_k(const QuantTileArgs a) {
                                                                         (int)((nr - 1u) * a.is_h + nt * (D * 2)), 0x00020000);
   const uint32_t ioff = tok < nt ? sub * a.is_h + wv * 16u : kOut;
   Vec8<IDT> x[NV];
+#if KVQ_TILE_PRIO == 2
+  __builtin_amdgcn_s_setprio(3);
+#endif
 #pragma unroll
   for (int i = 0; i < NV; ++i)
     x[i].w = __builtin_amdgcn_raw_buffer_load_b128(irs, ioff, (uint32_t)(i * RPI) * a.is_h, PHASE == 1 ? 0 : KVQ_TILE_LD_AUX /* non-temporal */);
+#if KVQ_TILE_PRIO == 1
+  __builtin_amdgcn_s_setprio(3);
+#elif KVQ_TILE_PRIO == 2
+  __builtin_amdgcn_s_setprio(0);
+#endif
 
   constexpr int DVSH = DV == 16 ? 4 : 3;
   float s32;
