@@ -60,6 +60,7 @@ Tunables& tunables() {
     d.quant_tile = 1;
     d.quant_wide = 1;
     d.attn_lds = -1;
+    d.attn_merge_wave = 1;
     d.attn_k_i8 = -1;
     d.attn_merge_fast = 1;
     d.attn_stream_roll = 1;
@@ -86,6 +87,7 @@ static const TunableKey kTunableKeys[] = {
     {"attn_force_valu", &Tunables::attn_force_valu, false},
     {"attn_stream_tpw", &Tunables::attn_stream_tpw, false},
     {"attn_lds", &Tunables::attn_lds, false},
+    {"attn_merge_wave", &Tunables::attn_merge_wave, false},
     // A-B keys
     {"dequant_variant", &Tunables::dequant_variant, true},
     {"dequant_grid", &Tunables::dequant_grid, true},

@@ -2174,17 +2174,93 @@ __device__ inline void quant_new_token_regs(const NewTokenArgs& a, const uint32_
   }
 }
 
+// ONE WAVE per query head (head_dim 128, at most 16 splits: what the LDS-staged kernel leaves): the same merge without the
+// workgroup — lane s holds split s's (m, l), lane l holds d = l and d = 64 + l of every split's partial (32 loads, all
+// requested before anything waits); the weights travel by v_readlane instead of an LDS table, and there is no barrier.
+// The arithmetic, operand by operand and in the same order, is decode_attn_merge_fast_k's (its thread (g, d4) sums splits
+// g, g + 8, the final row sums the 8 groups in order; its dot product sums d < 64 in wave 0 and d >= 64 in wave 1): equal bits.
+__device__ __forceinline__ void merge_one_wave(const AttnArgs& a, const bool has_new, const uint32_t hq, const uint32_t b) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr uint32_t D = 128, G = 8, NSU = 16;  // head_dim, the block kernel's split groups, splits held in registers
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t hk = hq / a.nq;
+  const uint32_t nb = a.nsplit;  // 1 ... 16 (host)
+  const float* ml = a.ws + ((int64_t)b * a.Hq + hq) * nb * 2;
+  const float* src = a.ws + a.acc_off + ((int64_t)b * a.Hq + hq) * nb * D + lane;
+  const uint32_t t_raw = (uint32_t)scalar_load_i32(a.t_dev ? a.t_dev : reinterpret_cast<const int*>(a.ws));
+  const f32x2 ml_raw = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(ml) + (lane < nb ? lane : nb - 1u));
+  uint16_t qraw[2], kraw[2], vraw[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t di = 64u * h + lane;
+    qraw[h] = reinterpret_cast<const uint16_t*>(a.q)[(int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + di];
+    kraw[h] = reinterpret_cast<const uint16_t*>(a.kn)[(int64_t)b * a.kn_sb + (int64_t)hk * a.kn_sh + di];
+    vraw[h] = reinterpret_cast<const uint16_t*>(a.vn)[(int64_t)b * a.vn_sb + (int64_t)hk * a.vn_sh + di];
+  }
+  float x[2][NSU];
+#pragma unroll
+  for (int sp = 0; sp < (int)NSU; ++sp) {
+    const uint32_t sc = (uint32_t)sp < nb ? (uint32_t)sp : nb - 1u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) x[h][sp] = __builtin_nontemporal_load(src + (int64_t)sc * D + 64 * h);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const uint32_t T = a.t_dev ? (t_raw < a.T ? t_raw : a.T) : a.T;
+  uint32_t ns = a.t_dev ? (T + a.TS - 1u) / a.TS : nb;
+  ns = ns < nb ? ns : nb;
+  f32x2 mlv = ml_raw;
+  if (lane >= ns) mlv = f32x2{-INFINITY, 0.0f};
+  auto widen = [&](uint16_t h) { return a.dtype == KVQ_F16 ? Elem<KVQ_F16>::widen(h) : Elem<KVQ_BF16>::widen(h); };
+  const float p0 = wave_fsum(widen(has_new ? qraw[0] : (uint16_t)0) * widen(kraw[0]));
+  const float p1 = wave_fsum(widen(has_new ? qraw[1] : (uint16_t)0) * widen(kraw[1]));
+  const float s_tok = has_new ? ((p0 + p1) + (0.0f + 0.0f)) * a.sm_scale : -INFINITY;
+  const float M = fmaxf(wave_fmax(mlv[0]), s_tok);
+  const float w = lane < ns ? __expf(mlv[0] - M) : 0.0f;
+  const float lw = wave_fsum(lane < ns ? mlv[1] * w : 0.0f);
+  const float w_new = has_new ? __expf(s_tok - M) : 0.0f;
+  const float L = ((lw + 0.0f) + (0.0f + 0.0f)) + w_new;
+  const float inv = 1.0f / L;
+  float wt[NSU];
+#pragma unroll
+  for (int sp = 0; sp < (int)NSU; ++sp) wt[sp] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(w), sp));
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < (int)G; ++k) {
+      float o = 0.0f;
+#pragma unroll
+      for (int u = 0; u < (int)(NSU / G); ++u) {
+        const int sp = k + u * (int)G;
+        if ((uint32_t)sp < ns) o += x[h][sp] * wt[sp];
+      }
+      t += o;
+    }
+    if (has_new) t = fmaf(w_new, widen(vraw[h]), t);
+    t *= inv;
+    const int64_t oi = (int64_t)b * a.o_sb + (int64_t)hq * a.o_sh + 64 * h + lane;
+    if (a.dtype == KVQ_F16) reinterpret_cast<f16*>(a.out)[oi] = (f16)t;
+    else reinterpret_cast<__bf16*>(a.out)[oi] = (__bf16)t;
+  }
+}
+
 // (has_new: without a new token the host points kn / vn at the query, so that the three loads need no branch)
 // PF: partial rows each thread requests up front (and holds): ceil(nsplit / (256 / (D/4))) rounded up to 2 / 4 / 16 by the
 // host — the 16 splits per head of the LDS-staged kernel need 2, not 16 (14 clamped re-reads of the last row per thread)
 template <int PF>
-__global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_fast_k(const AttnArgs a, const NewTokenArgs nt, const int fuse_quant,
+__global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_fast_k(const AttnArgs a, const NewTokenArgs nt, const int fuse_quant_i,
                                                                        const int has_new_i) {
   __shared__ float s_red[3][kAttnBlock / kWave];
-  if (blockIdx.x >= a.Hq) {
-    if (fuse_quant && blockIdx.y == 0u && new_token_fits_registers(nt, blockIdx.x - a.Hq)) {
-      if (a.dtype == KVQ_F16) quant_new_token_regs<KVQ_F16>(nt, blockIdx.x - a.Hq, s_red[0], a.t_dev, a.T, a.q);
-      else quant_new_token_regs<KVQ_BF16>(nt, blockIdx.x - a.Hq, s_red[0], a.t_dev, a.T, a.q);
+  // fuse_quant_i bit 0: the launch's last two workgroups quantise-append the new token; bit 1 (PF == 2, head_dim 128, <= 16
+  // splits): ONE WAVE per head, four heads per workgroup (merge_one_wave)
+  const int fuse_quant = fuse_quant_i & 1;
+  const bool by_wave = PF == 2 && (fuse_quant_i & 2) != 0;
+  const uint32_t n_head_wgs = by_wave ? (a.Hq + 3u) / 4u : a.Hq;
+  if (blockIdx.x >= n_head_wgs) {
+    const uint32_t w_new_tok = blockIdx.x - n_head_wgs;
+    if (fuse_quant && blockIdx.y == 0u && new_token_fits_registers(nt, w_new_tok)) {
+      if (a.dtype == KVQ_F16) quant_new_token_regs<KVQ_F16>(nt, w_new_tok, s_red[0], a.t_dev, a.T, a.q);
+      else quant_new_token_regs<KVQ_BF16>(nt, w_new_tok, s_red[0], a.t_dev, a.T, a.q);
     } else if (fuse_quant && blockIdx.y == 0u) {
       NewTokenArgs slot = nt;
       if (a.t_dev) {
@@ -2195,10 +2271,17 @@ __global__ __launch_bounds__(kAttnBlock) void decode_attn_merge_fast_k(const Att
           slot.scale[w] += T;
         }
       }
-      if (a.dtype == KVQ_F16) quant_new_token_block<KVQ_F16>(slot, blockIdx.x - a.Hq, s_red[0]);
-      else quant_new_token_block<KVQ_BF16>(slot, blockIdx.x - a.Hq, s_red[0]);
+      if (a.dtype == KVQ_F16) quant_new_token_block<KVQ_F16>(slot, w_new_tok, s_red[0]);
+      else quant_new_token_block<KVQ_BF16>(slot, w_new_tok, s_red[0]);
     }
     return;
+  }
+  if constexpr (PF == 2) {
+    if (by_wave) {
+      const uint32_t hq_w = blockIdx.x * 4u + (threadIdx.x >> 6);
+      if (hq_w < a.Hq) merge_one_wave(a, has_new_i != 0, hq_w, blockIdx.y);
+      return;
+    }
   }
   __shared__ float s_wt[kAttnBlock];
   __shared__ __attribute__((aligned(16))) float s_out[kAttnBlock * 4];
@@ -2672,7 +2755,10 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
     }
     const uint32_t groups = (uint32_t)kAttnBlock / (a.D / 4u), need = (a.nsplit + groups - 1u) / groups;
     const dim3 mgrid(a.Hq + (nt ? 2u : 0u), a.B);
-    if (need <= 2u) KVQ_LAUNCH((decode_attn_merge_fast_k<2>), mgrid, dim3(kAttnBlock), 0, st, af, nt ? *nt : none, nt ? 1 : 0, a.kn ? 1 : 0);
+    if (need <= 2u && a.D == 128u && a.nsplit <= 16u && tunables().attn_merge_wave != 0) {  // one wave per head, no workgroup
+      const dim3 wgrid((a.Hq + 3u) / 4u + (nt ? 2u : 0u), a.B);
+      KVQ_LAUNCH((decode_attn_merge_fast_k<2>), wgrid, dim3(kAttnBlock), 0, st, af, nt ? *nt : none, (nt ? 1 : 0) | 2, a.kn ? 1 : 0);
+    } else if (need <= 2u) KVQ_LAUNCH((decode_attn_merge_fast_k<2>), mgrid, dim3(kAttnBlock), 0, st, af, nt ? *nt : none, nt ? 1 : 0, a.kn ? 1 : 0);
 #if KVQ_AB  // (17-32 splits: depth 4 measured within 0.1 us of depth 16; one instantiation less in the default library)
     else if (need <= 4u) KVQ_LAUNCH((decode_attn_merge_fast_k<4>), mgrid, dim3(kAttnBlock), 0, st, af, nt ? *nt : none, nt ? 1 : 0, a.kn ? 1 : 0);
 #endif

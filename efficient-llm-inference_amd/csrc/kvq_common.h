@@ -75,6 +75,7 @@ struct Tunables {
   int64_t pool_wave;             // chunk mean-pool: one wave per output row when the shape allows (1, default) or the per-lane-group walk (0)
   int64_t attn_force_valu;       // 1 = decode attention never takes an MFMA kernel
   int64_t attn_stream_tpw;       // streaming MFMA kernel: 64-token tiles per wave; 0 = by size (only when tiles exceed wave slots), -1 = never
+  int64_t attn_merge_wave;       // merge of <= 16 splits at head_dim 128: 1 (default) = one wave per head, 0 = the 256-thread workgroup per head (same bits)
   int64_t attn_lds;              // LDS-staged MFMA kernel (contiguous row loads): -1 = by shape (default), 0 = never, 1 = wherever it applies
   // ---- A-B keys
   int64_t dequant_variant;       // -1 = shipped default

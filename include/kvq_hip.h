@@ -286,7 +286,8 @@ int64_t kvq_kernel_log(char* buf, int64_t n);
  *   0 = general kernels), "quant_wide" (1 = single-pass 1024-thread register tile for batched slices of 16384 < B*H*D <=
  *   131072 two-byte elements, default; 0 = split phases / swept tile), "quant_block" (general quantise kernel: 64-thread one-wave tiles, default, or 256; 128 in A-B builds), "pool_wave" (1 = one wave per output row where the shape allows, default; 0 = per-lane-group
  *   walk), "attn_force_valu" (0/1), "attn_stream_tpw" (tiles per wave of the streaming attention kernel: -1 never,
- *   0 by size, > 0 that many), "attn_lds" (LDS-staged MFMA attention: -1 by shape, 0 never, 1 wherever it applies).
+ *   0 by size, > 0 that many), "attn_lds" (LDS-staged MFMA attention: -1 by shape, 0 never, 1 wherever it applies),
+ *   "attn_merge_wave" (merge of <= 16 splits at head_dim 128: 1 = one wave per head, default; 0 = one workgroup per head).
  * A-B keys select variants that lost a measurement and exist only in the A-B library (`make -C csrc ab` ->
  *   lib/ab/libkvq_hip.so, kvq_is_ab_build() == 1); the default library returns KVQ_E_DIMS for them:
  *   dequantise  "dequant_variant" (0..35), "dequant_grid", "dequant_xcd_group"

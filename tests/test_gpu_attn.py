@@ -705,6 +705,55 @@ def test_merge_one_round_trip_equals_chained_merge(K, tunable, case):
                 assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("case", [(2, 32, 8, 1500, 3), (1, 8, 2, 1000, 1), (3, 6, 2, 449, 2), (1, 4, 1, 64, 1), (5, 32, 8, 1024, 1)])
+def test_merge_by_one_wave_equals_the_workgroup_merge(K, tunable, case):
+    """attn_merge_wave (default 1): up to 16 split partials per head at head_dim 128 — what the LDS-staged kernel leaves — are
+    merged by ONE WAVE per head (weights by v_readlane, no LDS table, no barrier); 0 = the 256-thread workgroup per head.
+    Same operands in the same order: equal output BITS — with and without the new token, fp16 and bf16, through
+    decode_attn and through decode_step (whose merge launch also quantise-appends the new token: equal stores and scales)."""
+    B, Hq, Hkv, T, tpw = case
+    D = 128
+    from efficient_llm_inference_amd import _lib
+    tunable("attn_stream_tpw", tpw)
+    g = torch.Generator(device="cuda").manual_seed(T + tpw)
+    for dtype in (torch.float16, torch.bfloat16):
+        k_store = torch.randint(-127, 128, (B, Hkv, T + 4, D), dtype=torch.int8, device="cuda", generator=g)
+        v_store = torch.randint(0, 256, (B, Hkv, T + 4, D // 2), dtype=torch.uint8, device="cuda", generator=g)
+        k_sc = torch.rand(T + 4, device="cuda", generator=g) * 0.02 + 1e-3
+        v_sc = torch.rand(T + 4, device="cuda", generator=g) * 0.2 + 1e-3
+        q = torch.randn(B, Hq, D, device="cuda", generator=g).to(dtype)
+        kn = torch.randn(B, Hkv, D, device="cuda", generator=g).to(dtype)
+        vn = torch.randn(B, Hkv, D, device="cuda", generator=g).to(dtype)
+        ws = torch.empty(K.decode_attn_workspace_cap(B, Hq, Hkv, T + 4, D), dtype=torch.float32, device="cuda")
+        for with_new in (True, False):
+            outs = []
+            for wave in (1, 0):
+                tunable("attn_merge_wave", wave)
+                out = torch.full((B, Hq, D), float("nan"), dtype=dtype, device="cuda")
+                ws.fill_(float("nan"))
+                _lib.kernel_log_clear()
+                K.decode_attn(q, k_store, k_sc, "int8", v_store, v_sc, "int4", T, out, ws, D ** -0.5,
+                              kn if with_new else None, vn if with_new else None)
+                torch.cuda.synchronize()
+                log = _lib.kernel_log()
+                assert log[0].startswith("decode_attn_lds_mfma_k<") and log[1] == "decode_attn_merge_fast_k<2>", log
+                assert torch.isfinite(out.float()).all()
+                outs.append(out)
+            assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), (dtype, with_new)
+        res = []
+        for wave in (1, 0):  # the whole step: attention + the new token quantised into slot T by the merge launch's last workgroups
+            tunable("attn_merge_wave", wave)
+            ks, vs, ksc, vsc = k_store.clone(), v_store.clone(), k_sc.clone(), v_sc.clone()
+            plan = K.DecodeStepPlan(q, ks, ksc, "int8", vs, vsc, "int4", 1e-8)
+            out = torch.full((B, Hq, D), float("nan"), dtype=dtype, device="cuda")
+            K.decode_step(plan, q, kn, vn, T, out, ws, D ** -0.5)
+            torch.cuda.synchronize()
+            res.append((out, ks, vs, ksc, vsc))
+        for a_, b_ in zip(res[0], res[1]):
+            assert torch.equal(a_, b_)
+        assert not torch.equal(res[0][1][:, :, T], k_store[:, :, T])  # slot T was written
+
+
 @pytest.mark.parametrize("kinds", [("int8", "int4"), ("int8", "int8"), ("int4", "int4")])
 @pytest.mark.parametrize("shape", [(1, 32, 8, 16384, 128), (8, 32, 8, 16384, 128), (1, 16, 16, 4096, 64)])
 def test_decode_attn_full_size_against_float64_attention_on_the_device(K, shape, kinds):
