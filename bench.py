@@ -100,8 +100,8 @@ def parse():
                     help="independent quantised caches visited round-robin by consecutive steps, so that no "
                          "step re-reads lines the 256 MiB Infinity Cache may still hold (1 = the decode loop's "
                          "behaviour: the same cache every step; its 256 MiB INT4 store then stays cache-resident)")
-    ap.add_argument("--cpu-sample-layers", type=int, default=8)
-    ap.add_argument("--cpu-reps", type=int, default=3, help="timed repetitions per cpu_baseline entry (median reported)")
+    ap.add_argument("--cpu-sample-layers", type=int, default=4)
+    ap.add_argument("--cpu-reps", type=int, default=5, help="timed repetitions per cpu_baseline entry (median reported)")
     ap.add_argument("--tunable", action="append", default=[], metavar="KEY=VALUE",
                     help="kvq_set_tunable(KEY, VALUE) before the run (include/kvq_hip.h lists the keys; A-B keys need "
                          "KVQ_HIP_LIB=<pkg>/lib/ab/libkvq_hip.so)")
@@ -226,7 +226,7 @@ def cpu_baseline(L, B, H, T, D, sample_layers, reps=5, gpu_check=None):
     sc = (rng.random((n_layers, T), dtype=np.float32) * 0.02 + 0.001).astype(np.float32)
     dt = _median_time(lambda: C.dequantize_tokens(q, sc, "int4", D, "f16"), reps)
     n = n_layers * B * H * T * D
-    nq_layers = max(1, min(4, n_layers))
+    nq_layers = max(1, min(2, n_layers))
     xq = (rng.standard_normal((nq_layers, B, H, T, D), dtype=np.float32)).astype(np.float16)
     dq_s = _median_time(lambda: C.quantize_tokens(xq, "int4"), reps)
     nq = nq_layers * B * H * T * D
@@ -273,7 +273,7 @@ def cpu_baseline(L, B, H, T, D, sample_layers, reps=5, gpu_check=None):
 
     # ---- vectorised: whole-tensor torch-CPU, all cores ------------------------------------------
     _t.set_num_threads(cores)
-    nv_layers = max(1, min(4, n_layers))
+    nv_layers = max(1, min(2, n_layers))
     xv = _t.from_numpy(xq[:nv_layers])
     qv, sv = VT.quantize_tokens(xv, "int4")
     dv = _median_time(lambda: VT.dequantize_tokens(qv, sv, "int4", D, _t.float16), reps)
