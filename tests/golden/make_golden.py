@@ -3,7 +3,7 @@
 
 Run ONLY in the build container, where the reference checkout is mounted read-only:
 
-    python tests/golden/make_golden.py [/root/reference]
+    python tests/golden/make_golden.py [/root/reference [out_dir]]      (out_dir: default = this directory)
 
 It imports the reference's own Python functions (CPU branches: src/quantization/ops.py:88-90
 and :120-133 are taken because no GPU is visible) and stores inputs + outputs as ``.npz``
@@ -56,7 +56,9 @@ from src.quantization.ops import (  # noqa: E402
     quantize_int8_per_tensor,
 )
 
-OUT = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.abspath(sys.argv[2]) if len(sys.argv) > 2 else HERE
+os.makedirs(OUT, exist_ok=True)
 TD = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
 
 
@@ -310,7 +312,7 @@ def gen_benchmarker():
     reference's examples download 'gpt2', which this container cannot); every benchmarker line that runs is the
     reference's."""
     import math
-    repo = os.path.dirname(os.path.dirname(OUT))
+    repo = os.path.dirname(os.path.dirname(HERE))
     if repo not in sys.path:
         sys.path.insert(1, repo)
     import transformers
