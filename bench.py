@@ -231,8 +231,8 @@ def cpu_baseline(L, B, H, T, D, sample_layers, reps=5, gpu_check=None):
     dq_s = _median_time(lambda: C.quantize_tokens(xq, "int4"), reps)
     nq = nq_layers * B * H * T * D
     q8 = rng.integers(-127, 128, size=(nq_layers, B, H, T, D), dtype=np.int8)
-    d8 = _median_time(lambda: C.dequantize_tokens(q8, sc[:nq_layers], "int8", D, "f16"), reps)
-    dq8 = _median_time(lambda: C.quantize_tokens(xq, "int8"), reps)
+    d8 = _median_time(lambda: C.dequantize_tokens(q8, sc[:nq_layers], "int8", D, "f16"), max(2, reps // 2))
+    dq8 = _median_time(lambda: C.quantize_tokens(xq, "int8"), max(2, reps // 2))
     port = {"value": gbps(n, dt), "unit": "GB/s", "cores": 1, "reps": reps, "kind": "port",
             "sample": f"INT4->fp16 dequantise of {n_layers}/{L} layers of the V set [{n_layers},{B},{H},{T},{D}] "
                       f"({n} elements, median {dt:.3f} s), oracle/kvq_oracle.c scalar",
@@ -310,9 +310,9 @@ def cpu_baseline(L, B, H, T, D, sample_layers, reps=5, gpu_check=None):
     xe = _t.from_numpy(xq[0])
     W, chunk, keep = 256, 64, 256
     tw = _median_time(lambda: VT.trim_kv_sliding_window(xe, W), reps)
-    tp = _median_time(lambda: VT.chunk_summarize_kv(xe, chunk, keep), reps)
+    tp = _median_time(lambda: VT.chunk_summarize_kv(xe, chunk, keep), max(2, reps // 2))
     Tout = (max(T - keep, 0) + chunk - 1) // chunk + min(keep, T)
-    evict = {"cores": cores, "reps": reps, "kind": "port", "unit": "GB/s",
+    evict = {"cores": cores, "reps": reps, "pool_reps": max(2, reps // 2), "kind": "port", "unit": "GB/s",
              "window_value": round(4.0 * B * H * min(W, T) * D / tw / 1e9, 5),
              "pool_value": round(2.0 * B * H * D * (T + Tout) / tp / 1e9, 5),
              "sample": f"trim_kv_sliding_window(W={W}) + materialise and chunk_summarize_kv(chunk={chunk}, keep_last={keep}) of one "
