@@ -44,6 +44,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -101,6 +102,8 @@ def parse():
                          "step re-reads lines the 256 MiB Infinity Cache may still hold (1 = the decode loop's "
                          "behaviour: the same cache every step; its 256 MiB INT4 store then stays cache-resident)")
     ap.add_argument("--cpu-sample-layers", type=int, default=4)
+    ap.add_argument("--cpu-sample-tokens", type=int, default=0,
+                    help="cpu_baseline on the first N tokens of the sampled layers (0 = the whole sequence); the samples say so")
     ap.add_argument("--cpu-reps", type=int, default=5, help="timed repetitions per cpu_baseline entry (median reported)")
     ap.add_argument("--tunable", action="append", default=[], metavar="KEY=VALUE",
                     help="kvq_set_tunable(KEY, VALUE) before the run (include/kvq_hip.h lists the keys; A-B keys need "
@@ -1106,7 +1109,16 @@ def run_dequant(args, rank, world, dev, backend):
     mark("subrecords")
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            line["cpu_baseline"] = cpu_baseline(L, B, H, T, D, args.cpu_sample_layers, reps=max(1, args.cpu_reps), gpu_check=gpu_check)
+            Tc = min(T, args.cpu_sample_tokens) if args.cpu_sample_tokens > 0 else T
+            if gpu_check is not None and Tc < T:  # the same tokens of what the GPU produced (token axis: -2 of the rows, -1 of the scales)
+                for key in ("x", "q", "out"):
+                    for name in ("k", "v"):
+                        gpu_check[f"{key}_{name}"] = np.ascontiguousarray(gpu_check[f"{key}_{name}"][..., :Tc, :])
+                for name in ("k", "v"):
+                    gpu_check[f"s_{name}"] = np.ascontiguousarray(gpu_check[f"s_{name}"][..., :Tc])
+            line["cpu_baseline"] = cpu_baseline(L, B, H, Tc, D, args.cpu_sample_layers, reps=max(1, args.cpu_reps), gpu_check=gpu_check)
+            if Tc < T:
+                line["cpu_baseline"]["tokens_sampled"] = f"first {Tc} of {T} tokens (per-token work: the rates do not depend on T)"
             mark("cpu_baseline")
         line["run_s"] = round(time.perf_counter() - t_run0, 2)
         phases["startup_before_workload"] = round(t_run0 - _T_PROCESS0, 2)

@@ -99,7 +99,7 @@ def test_bench_line_carries_the_contract_fields(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
-                           "--cpu-sample-layers", "1", "--cpu-reps", "1"], capture_output=True, text=True, timeout=900, cwd=root)
+                           "--cpu-sample-layers", "1", "--cpu-reps", "1", "--cpu-sample-tokens", "2048"], capture_output=True, text=True, timeout=900, cwd=root)
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
