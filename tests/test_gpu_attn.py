@@ -447,6 +447,8 @@ def test_decode_attn_lds_staged_kernel(K, tunable, tpw, which):
     every = tpw == 3 or which != 1  # the shipped kernel: every kind pair at 3 tiles per wave, the headline pair (+ bf16) at the other splits
     for case in LDS_CASES:
         big = case[0] * case[3] > 20000  # the batch-8 case: the float64 oracle on the host is what takes the time
+        if big and not (every or tpw == 0):  # (it runs at the split the library picks and at 3 tiles per wave)
+            continue
         for kinds in (("int8", "int4"),) if big or not every else (("int8", "int4"), ("int4", "int8"), ("int8", "int8"), ("int4", "int4")):
             _run_case(K, *case, kinds[0], kinds[1], "f16", True)
         if not big:
