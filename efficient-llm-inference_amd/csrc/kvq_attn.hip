@@ -1132,17 +1132,34 @@ struct AttnStream {
     float alpha;
     if constexpr (TG == 4) {
       // ---- S = K Q^T, one output for the tile: column x = (token group x >> 2, head x & 3) ---------------------------
+#ifndef KVQ_TG4_CHAINS  // calibration (`make calib_tg4`): 2 = two accumulators per plane (dependent chains of 4 MFMAs instead of 8)
+#define KVQ_TG4_CHAINS 1
+#endif
       i32x4 c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
+#if KVQ_TG4_CHAINS == 2
+      i32x4 c1b = {0, 0, 0, 0}, c2b = {0, 0, 0, 0};
+#endif
 #pragma unroll
       for (int tg = 0; tg < 4; ++tg) {
 #pragma unroll
         for (int c = 0; c < NL; ++c) {
           const i32x4 ka = {(int)r.k[tg][c][0], (int)r.k[tg][c][1], (int)r.k[tg][c][2], (int)r.k[tg][c][3]};
+#if KVQ_TG4_CHAINS == 2
+          if (tg & 1) {
+            c1b = __builtin_amdgcn_mfma_i32_16x16x64_i8(ka, qt[tg][c].p1, c1b, 0, 0, 0);
+            c2b = __builtin_amdgcn_mfma_i32_16x16x64_i8(ka, qt[tg][c].p2, c2b, 0, 0, 0);
+            continue;
+          }
+#endif
           c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ka, qt[tg][c].p1, c1, 0, 0, 0);
           c2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ka, qt[tg][c].p2, c2, 0, 0, 0);
         }
         if constexpr (ROLL) issue_k(a, nx, tg, r);
       }
+#if KVQ_TG4_CHAINS == 2
+      c1 += c1b;
+      c2 += c2b;
+#endif
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // s_ks / s_vs written above by this wave's lanes
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
