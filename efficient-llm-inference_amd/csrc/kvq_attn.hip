@@ -1132,6 +1132,9 @@ struct AttnStream {
     float alpha;
     if constexpr (TG == 4) {
       // ---- S = K Q^T, one output for the tile: column x = (token group x >> 2, head x & 3) ---------------------------
+#ifndef KVQ_ATTN_SKIP  // calibration bit mask: 1 = no score MFMAs, 2 = no P·V MFMAs, 4 = no V byte -> f16 conversion, 8 = no exp2
+#define KVQ_ATTN_SKIP 0
+#endif
 #ifndef KVQ_TG4_CHAINS  // calibration (`make calib_tg4`): 2 = two accumulators per plane (dependent chains of 4 MFMAs instead of 8)
 #define KVQ_TG4_CHAINS 1
 #endif
@@ -1150,6 +1153,11 @@ struct AttnStream {
             c2b = __builtin_amdgcn_mfma_i32_16x16x64_i8(ka, qt[tg][c].p2, c2b, 0, 0, 0);
             continue;
           }
+#endif
+#if KVQ_ATTN_SKIP & 1  // calibration (`make calib_attn_skip`, inexact): the score MFMAs replaced by one VALU op per operand word
+          c1 ^= ka;
+          c2 += qt[tg][c].p2;
+          continue;
 #endif
           c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ka, qt[tg][c].p1, c1, 0, 0, 0);
           c2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ka, qt[tg][c].p2, c2, 0, 0, 0);
@@ -1185,7 +1193,11 @@ struct AttnStream {
       float lt = 0.0f, pv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
+#if KVQ_ATTN_SKIP & 8
+        const float p = fminf(fabsf(s4[q] - mnew), 1.0f);
+#else
         const float p = __builtin_amdgcn_exp2f(s4[q] - mnew);  // tokens past nt: 2^(-inf) = 0
+#endif
         lt += p;
         pv[q] = p * sv[q];
       }
@@ -1329,15 +1341,137 @@ struct AttnStream {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
           uint32_t h[4];
+#if KVQ_ATTN_SKIP & 4
+          h[0] = ca[n]; h[1] = cb[n]; h[2] = ca[n] >> 1; h[3] = cb[n] >> 1;
+#else
           bytes_to_h4<BIAS>(ca[n], h[0], h[1]);
           bytes_to_h4<BIAS>(cb[n], h[2], h[3]);
+#endif
+#if KVQ_ATTN_SKIP & 2
+          acc[4 * half + n][0] += __uint_as_float((h[0] ^ h[1] ^ h[2] ^ h[3] ^ pp[sidx][n]) & 0x3FFFFFFFu);
+#else
           acc[4 * half + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, pack_h8(h[0], h[1], h[2], h[3]), acc[4 * half + n], 0, 0, 0);
+#endif
         }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next tile's staging writes stay below this tile's LDS reads
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+
+  // ---- TG = 4, scales straight from the LDS slot (the LDS-staged kernel) -------------------------------------------------
+  // The same tile reduction with the wave's serial chain cut down: what a tile costs one wave per SIMD is less its arithmetic
+  // (builds without any MFMA, V conversion and exp2 run 1 us faster out of 40, profiles/r03skip_*) than the LDS round trips
+  // and lane exchanges between its steps. Here
+  //   * the K / V scales are read as f32x4 from the slot the DMA left them in (no staging write, no wave barrier);
+  //   * the V reference scale is the wave's own maximum, taken once before the first tile (`svref`, `svn` fixed by the
+  //     kernel): no per-tile wave maximum, no rescale ratio;
+  //   * l is summed per lane and reduced across the head's lanes once, at the end (`reduce_l`);
+  //   * alpha reaches the accumulator rows by v_readlane (heads 0..3 live in lanes 0..3; rows 4..15 are padding) instead of
+  //     an LDS round trip, and the rescale is skipped while no head's maximum moved;
+  //   * nothing is written to LDS, so no fence closes the tile.
+  // sc_slot: the slot's 64 K scales followed by its 64 V scales. Same sums as consume() up to the order l is added in.
+  float svn;  // 1 / svref (0 when every V scale of the wave is 0)
+  __device__ __forceinline__ void consume_direct(const AttnArgs& a, const uint32_t nt, Raw& r, const float* sc_slot) {
+    static_assert(TG == 4, "the one-output score product");
+    const uint32_t lane = threadIdx.x & 63u, x = lane & 15u, g = lane >> 4;
+    const bool full = nt == (uint32_t)TC;  // uniform
+    i32x4 c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
+#pragma unroll
+    for (int tg = 0; tg < 4; ++tg) {
+#pragma unroll
+      for (int c = 0; c < NL; ++c) {
+        const i32x4 ka = {(int)r.k[tg][c][0], (int)r.k[tg][c][1], (int)r.k[tg][c][2], (int)r.k[tg][c][3]};
+        c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ka, qt[tg][c].p1, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ka, qt[tg][c].p2, c2, 0, 0, 0);
+      }
+    }
+    const uint32_t tb = 16u * (x >> 2) + 4u * g;
+    const f32x4 ks = *reinterpret_cast<const f32x4*>(sc_slot + tb);
+    const f32x4 sv = *reinterpret_cast<const f32x4*>(sc_slot + 64 + tb);
+    const float kq = aq * (a.sm_scale * 1.44269504088896341f);
+    float s4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s4[q] = fmaf((float)c2[q], 1.0f / 254.0f, (float)c1[q]) * (kq * ks[q]);
+    if (!full) {  // uniform: only a ragged last tile pays for the masks (its rows past nt hold an older tile's bytes)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (tb + (uint32_t)q >= nt) s4[q] = -INFINITY;
+    }
+    float mt = fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3]));
+    mt = fmaxf(mt, __uint_as_float(dpp_u32_attn<0x128>(__float_as_uint(mt))));
+    mt = fmaxf(mt, __uint_as_float(dpp_u32_attn<0x124>(__float_as_uint(mt))));
+    mt = xor32_max(xor16_max(mt));
+    const float mnew = fmaxf(m, mt);                       // finite: every tile holds >= 1 token
+    const float alpha = __builtin_amdgcn_exp2f(m - mnew);  // first tile: 2^(-inf) = 0
+    m = mnew;
+    float lt = 0.0f, pv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float p = __builtin_amdgcn_exp2f(s4[q] - mnew);  // tokens past nt: 2^(-inf) = 0
+      lt += p;
+      pv[q] = p * (full || tb + (uint32_t)q < nt ? sv[q] * svn : 0.0f);
+    }
+    l = l * alpha + lt;  // this lane's share of the head's sum (reduce_l() at the end)
+    const uint32_t p01 = Elem<KVQ_F16>::pack2(pv[0], pv[1]), p23 = Elem<KVQ_F16>::pack2(pv[2], pv[3]);
+    uint32_t pp[NS][4];
+    pp[0][0] = p01;
+    pp[0][1] = p23;
+    pp[0][2] = dpp_u32_attn<0x12C>(p01);
+    pp[0][3] = dpp_u32_attn<0x12C>(p23);
+    pp[1][0] = dpp_u32_attn<0x128>(p01);
+    pp[1][1] = dpp_u32_attn<0x128>(p23);
+    pp[1][2] = dpp_u32_attn<0x124>(p01);
+    pp[1][3] = dpp_u32_attn<0x124>(p23);
+    // accumulator rows of this lane = heads 4 g + q; heads 0..3 (the real ones) keep their alpha in lanes 0..3
+    f32x4 al;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) al[q] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(alpha), q));
+    if (!(al[0] == 1.0f && al[1] == 1.0f && al[2] == 1.0f && al[3] == 1.0f)) {  // uniform
+#pragma unroll
+      for (int n = 0; n < DVN; ++n) acc[n] *= al;
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      uint32_t img[DVN / 4][8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t w0 = r.v[sidx][j][0];
+        if constexpr (HD == 128 && VBITS == 8) {
+          img[0][j] = w0 ^ 0x80808080u;
+          img[1][j] = r.v[sidx][j][VB == 8 ? 1 : 0] ^ 0x80808080u;
+        } else if constexpr (HD == 128) {
+          img[0][j] = (w0 >> 4) & 0x0F0F0F0Fu;
+          img[1][j] = w0 & 0x0F0F0F0Fu;
+        } else if constexpr (VBITS == 8) {
+          img[0][j] = w0 ^ 0x80808080u;
+        } else {
+          img[0][j] = ((w0 >> 4) & 0x0F0Fu) | ((w0 & 0x0F0Fu) << 16);
+        }
+      }
+      const f16x8 pa = pack_h8(pp[sidx][0], pp[sidx][1], pp[sidx][2], pp[sidx][3]);
+      constexpr int BIAS = VBITS == 8 ? 128 : 8;
+#pragma unroll
+      for (int half = 0; half < DVN / 4; ++half) {
+        uint32_t ca[4], cb[4];
+        transpose4x4(img[half][0], img[half][1], img[half][2], img[half][3], ca);  // tokens j = 0..3
+        transpose4x4(img[half][4], img[half][5], img[half][6], img[half][7], cb);  // tokens j = 4..7
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          uint32_t h[4];
+          bytes_to_h4<BIAS>(ca[n], h[0], h[1]);
+          bytes_to_h4<BIAS>(cb[n], h[2], h[3]);
+          acc[4 * half + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, pack_h8(h[0], h[1], h[2], h[3]), acc[4 * half + n], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // consume_direct's per-lane shares of l -> the head's sum, in every lane of the head
+  __device__ __forceinline__ void reduce_l() {
+    l += __uint_as_float(dpp_u32_attn<0x128>(__float_as_uint(l)));
+    l += __uint_as_float(dpp_u32_attn<0x124>(__float_as_uint(l)));
+    l = xor32_add(xor16_add(l));
   }
 };
 
@@ -1544,6 +1678,32 @@ __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_lds_mfma_
 #pragma unroll
   for (int k = 0; k < PRE; ++k) request((uint32_t)k);
   st.init(a, b, hk);
+  if constexpr (TG == 4) {
+    // the largest V scale of the wave's own tokens, once: consume_direct's fixed reference (P is carried as p sv / svref <= 1)
+    float vm = 0.0f;
+    if (!strided) {
+      const uint32_t tok0 = first * (uint32_t)TC;
+      const uint32_t cnt = a.T - tok0 < n * (uint32_t)TC ? a.T - tok0 : n * (uint32_t)TC;
+      const __amdgpu_buffer_rsrc_t vsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.v_scale + tok0), 0, (int)(cnt * 4u), 0x00020000);
+      for (uint32_t i0 = 0; i0 < cnt; i0 += 1024u) {  // 256 floats per wave load, four loads in flight
+        u32x4 w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = __builtin_amdgcn_raw_buffer_load_b128(vsr, (i0 + 256u * j + 4u * lane) * 4u, 0, 0);  // past cnt: zeros
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vm = fmaxf(vm, __uint_as_float(w[j][e]));
+      }
+    } else {
+      for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t t = (first + k * step) * (uint32_t)TC + lane;
+        if (t < a.T) vm = fmaxf(vm, a.v_scale[t]);
+      }
+    }
+    vm = wave_fmax(vm);
+    st.svref = vm;
+    st.svn = vm > 0.0f ? 1.0f / vm : 0.0f;
+  }
   typename ST::Raw r;
   const typename ST::Src none = st.src(a, b, hk, 0u, 0u);
   for (uint32_t k = 0; k < n; ++k) {
@@ -1563,6 +1723,10 @@ __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_lds_mfma_
     read_fragments<KBITS, VBITS, TC, KI8>(slot, r);
     static_assert(TC <= kWave, "one scale per lane");
     const float* sc = reinterpret_cast<const float*>(slot + TC * (KROW + VROW));
+    if constexpr (TG == 4 && NB > 1) {
+      st.consume_direct(a, nt, r, sc);
+      continue;
+    }
     const float ksv = sc[lane < (uint32_t)TC ? lane : 0u], vsv = sc[64 + (lane < (uint32_t)TC ? lane : 0u)];
     r.ks[0] = lane < nt ? ksv : 0.0f;  // rows past nt: the request's range check left the slot's old bytes there
     r.vs[0] = lane < nt ? vsv : 0.0f;
@@ -1576,6 +1740,7 @@ __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_lds_mfma_
     st.consume(a, nt, r, none, s_ks, s_vs, s_al);
   }
   wait_vmcnt<0>();  // the empty tail requests retire before the wave's LDS is released
+  if constexpr (TG == 4 && NB > 1) st.reduce_l();
   // ---- workspace: (m, l) per head, acc[heads][D] — the layout the merge kernels read ---------------------------
   if (g == 0u && x < a.nq) {
     float* o = a.ws + (((int64_t)b * a.Hq + hk * a.nq + x) * a.nsplit + split) * 2;
