@@ -2730,7 +2730,13 @@ static void launch_partial(const AttnArgs& a, hipStream_t st) {
       return;
     }
     if (nb == 4) { KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 64, kI8, 4>), grid, dim3(kWave), (size_t)(4 * kSlot), st, a, a.stream_tpw); return; }
-    if (nb == 3) { KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 64, kI8, 3>), grid, dim3(kWave), (size_t)(3 * kSlot), st, a, a.stream_tpw); return; }
+    if (nb == 3) {
+      if constexpr (kI8) {  // (with the one-output score product / consume_direct too)
+        if (a.nq <= 4u && tunables().attn_tg != 1) { KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 64, kI8, 3, 4>), grid, dim3(kWave), (size_t)(3 * kSlot), st, a, a.stream_tpw); return; }
+      }
+      KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 64, kI8, 3>), grid, dim3(kWave), (size_t)(3 * kSlot), st, a, a.stream_tpw);
+      return;
+    }
 #endif
     (void)nb;
     if constexpr (kI8) {  // at most 4 query heads per kv head: one score output per tile (AttnStream TG = 4)
