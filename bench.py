@@ -203,13 +203,18 @@ def _free():
 def cpu_baseline(L, B, H, T, D, sample_layers, reps=5, gpu_check=None):
     """the reference's CPU algorithm for the INT4 dequantise (the roofline kernel's
     op) and quantise of the same V set, on this box's host cores, three ways — each one warm-up +
-    `reps` timed repetitions, median reported, on a bounded sample (stated per entry):
-      port        scalar C restatement (oracle/kvq_oracle.c), 1 core
-      vectorised  whole-tensor torch-CPU ops (oracle/vectorised_torch.py), every host core
+    `reps` (>= 5 by default, every entry) timed repetitions, median reported, on a bounded sample (stated per entry):
+      port        scalar C restatement (oracle/kvq_oracle.c): on 1 core, and the same loops cut into token ranges over
+                  one pthread per USABLE core (`port.all_cores`) — the fair CPU ceiling
+      vectorised  whole-tensor torch-CPU ops (oracle/vectorised_torch.py), torch threads = usable cores
       literal     the reference's own call structure: one op chain per [B,H,1,D] slice + a T-way
-                  cat (oracle/literal_loop.py), torch-CPU, every host core
-    plus the two eviction ops as the reference writes them (whole-tensor torch ops) on one [B,H,T,D] tensor.
-    The top-level value / cores / kind / sample are the port's dequantise figure.
+                  cat (oracle/literal_loop.py), torch-CPU, torch threads = usable cores
+    plus the two eviction ops, as the reference writes them (whole-tensor torch ops) and as the C port, on one [B,H,T,D] tensor.
+    USABLE cores = min(os.cpu_count(), affinity mask, cgroup CFS quota) (oracle/hostcpu.py): a pool sized to the machine's
+    256 cores under a quota of 16 spends the period's budget in a few milliseconds and is frozen until the next 100 ms
+    period — round 3's 100.0 ms / 999.3 ms medians. `host_cpu` records the three limits and the cgroup's throttle counters
+    around the run; `timer_quantum_suspects` lists any median that still sits within 1 % of a multiple of 100 ms.
+    The top-level value / cores / kind / sample are the 1-core port's dequantise figure.
     gpu_check: host copies of layer 0 as the GPU quantised / dequantised / evicted it in this run (x_k, q_k, s_k, out_k, the
     same for v, evict_x / evict_pool / evict_window, kinds): the port recomputes every op from the same bytes and reports
     bit-exactness and the largest relative difference per op (`parity`; `max_rel_err_vs_gpu` = the INT4 dequantise's —
@@ -217,32 +222,45 @@ def cpu_baseline(L, B, H, T, D, sample_layers, reps=5, gpu_check=None):
     import numpy as np
     import torch as _t
     from oracle import c_oracle as C
+    from oracle import hostcpu
     from oracle import literal_loop as LL
     from oracle import vectorised_torch as VT
-    cores = os.cpu_count() or 1
+    hc = hostcpu.usable_cores()
+    cores = hc["usable"]
+    thr0 = hostcpu.throttle_counters()
     rng = np.random.default_rng(42)
     gbps = lambda n, dt, kind="int4": round(n * BYTES_PER_ELT[kind] / dt / 1e9, 5)  # noqa: E731
+    medians = {}  # entry -> median seconds, for the timer-quantum check
 
-    # ---- port: scalar C, 1 core --------------------------------------------------------------
+    def med(name, fn):
+        medians[name] = _median_time(fn, reps)
+        return medians[name]
+
+    # ---- port: scalar C, 1 core and every usable core -------------------------------------------------
     n_layers = max(1, min(sample_layers, L))
     q = rng.integers(0, 256, size=(n_layers, B, H, T, D // 2), dtype=np.uint8)
     sc = (rng.random((n_layers, T), dtype=np.float32) * 0.02 + 0.001).astype(np.float32)
-    dt = _median_time(lambda: C.dequantize_tokens(q, sc, "int4", D, "f16"), reps)
     n = n_layers * B * H * T * D
     nq_layers = max(1, min(2, n_layers))
     xq = (rng.standard_normal((nq_layers, B, H, T, D), dtype=np.float32)).astype(np.float16)
-    dq_s = _median_time(lambda: C.quantize_tokens(xq, "int4"), reps)
     nq = nq_layers * B * H * T * D
     q8 = rng.integers(-127, 128, size=(nq_layers, B, H, T, D), dtype=np.int8)
-    d8 = _median_time(lambda: C.dequantize_tokens(q8, sc[:nq_layers], "int8", D, "f16"), max(2, reps // 2))
-    dq8 = _median_time(lambda: C.quantize_tokens(xq, "int8"), max(2, reps // 2))
-    port = {"value": gbps(n, dt), "unit": "GB/s", "cores": 1, "reps": reps, "kind": "port",
-            "sample": f"INT4->fp16 dequantise of {n_layers}/{L} layers of the V set [{n_layers},{B},{H},{T},{D}] "
-                      f"({n} elements, median {dt:.3f} s), oracle/kvq_oracle.c scalar",
-            "quantise_value": gbps(nq, dq_s),
-            "quantise_sample": f"fp16->INT4 per-token quantise of {nq_layers}/{L} layers ({nq} elements, median {dq_s:.3f} s)",
-            "int8": {"dequantise_value": gbps(nq, d8, "int8"), "quantise_value": gbps(nq, dq8, "int8"),
-                     "sample": f"{nq_layers}/{L} layers of the K set ({nq} elements; medians {d8:.3f} / {dq8:.3f} s)"}}
+
+    def port_at(threads, tag):
+        dt = med(f"port{tag}.dequant_int4", lambda: C.dequantize_tokens(q, sc, "int4", D, "f16", threads=threads))
+        dq_s = med(f"port{tag}.quant_int4", lambda: C.quantize_tokens(xq, "int4", threads=threads))
+        d8 = med(f"port{tag}.dequant_int8", lambda: C.dequantize_tokens(q8, sc[:nq_layers], "int8", D, "f16", threads=threads))
+        dq8 = med(f"port{tag}.quant_int8", lambda: C.quantize_tokens(xq, "int8", threads=threads))
+        return {"value": gbps(n, dt), "unit": "GB/s", "cores": threads, "reps": reps, "kind": "port",
+                "sample": f"INT4->fp16 dequantise of {n_layers}/{L} layers of the V set [{n_layers},{B},{H},{T},{D}] "
+                          f"({n} elements, median {dt:.3f} s), oracle/kvq_oracle.c scalar loops" + (f" over {threads} pthreads (token ranges)" if threads > 1 else ""),
+                "quantise_value": gbps(nq, dq_s),
+                "quantise_sample": f"fp16->INT4 per-token quantise of {nq_layers}/{L} layers ({nq} elements, median {dq_s:.3f} s)",
+                "int8": {"dequantise_value": gbps(nq, d8, "int8"), "quantise_value": gbps(nq, dq8, "int8"),
+                         "sample": f"{nq_layers}/{L} layers of the K set ({nq} elements; medians {d8:.3f} / {dq8:.3f} s)"}}
+
+    port = port_at(1, "1")
+    port["all_cores"] = port_at(cores, "N") if cores > 1 else None
     parity = None
     if gpu_check is not None:
         # SURVEY §8d's accuracy gate, op by op: what the GPU produced in this run for layer 0 against the port on the same
@@ -256,10 +274,10 @@ def cpu_baseline(L, B, H, T, D, sample_layers, reps=5, gpu_check=None):
         parity = {}
         for name, kind in (("k", gpu_check["kinds"][0]), ("v", gpu_check["kinds"][1])):
             x, gq, gs, gout = (gpu_check[f"{key}_{name}"] for key in ("x", "q", "s", "out"))
-            rq, rs = C.quantize_tokens(x, kind)
-            rdq = C.dequantize_tokens(gq, gs, kind, D, "f16")
+            rq, rs = C.quantize_tokens(x, kind, threads=cores)
+            rdq = C.dequantize_tokens(gq, gs, kind, D, "f16", threads=cores)
             parity[f"quantise_{kind}"] = {"bit_exact": bool(np.array_equal(rq.view(np.uint8), gq.view(np.uint8)) and np.array_equal(rs.view(np.uint32), gs.view(np.uint32))),
-                                          "max_rel_err": rel(C.dequantize_tokens(rq, rs, kind, D, "f16"), rdq)}
+                                          "max_rel_err": rel(C.dequantize_tokens(rq, rs, kind, D, "f16", threads=cores), rdq)}
             parity[f"dequantise_{kind}"] = {"bit_exact": bool(np.array_equal(gout.view(np.uint16), rdq.view(np.uint16))), "max_rel_err": rel(gout, rdq)}
         xe = gpu_check["evict_x"]
         rp = O.chunk_summarize_kv(xe, 64, 256)
@@ -274,55 +292,74 @@ def cpu_baseline(L, B, H, T, D, sample_layers, reps=5, gpu_check=None):
         port["max_rel_err_vs_gpu"] = parity[f"dequantise_{vk}"]["max_rel_err"]
         port["max_rel_err_sample"] = parity["sample"]
 
-    # ---- vectorised: whole-tensor torch-CPU, all cores ------------------------------------------
+    # ---- vectorised: whole-tensor torch-CPU, usable cores ------------------------------------------
+    threads_before = _t.get_num_threads()
     _t.set_num_threads(cores)
     nv_layers = max(1, min(2, n_layers))
     xv = _t.from_numpy(xq[:nv_layers])
     qv, sv = VT.quantize_tokens(xv, "int4")
-    dv = _median_time(lambda: VT.dequantize_tokens(qv, sv, "int4", D, _t.float16), reps)
-    dvq = _median_time(lambda: VT.quantize_tokens(xv, "int4"), reps)
+    dv = med("vectorised.dequant_int4", lambda: VT.dequantize_tokens(qv, sv, "int4", D, _t.float16))
+    dvq = med("vectorised.quant_int4", lambda: VT.quantize_tokens(xv, "int4"))
     nvv = nv_layers * B * H * T * D
     qv8, sv8 = VT.quantize_tokens(xv, "int8")
-    dv8 = _median_time(lambda: VT.dequantize_tokens(qv8, sv8, "int8", D, _t.float16), max(2, reps // 2))
-    dvq8 = _median_time(lambda: VT.quantize_tokens(xv, "int8"), max(2, reps // 2))
+    dv8 = med("vectorised.dequant_int8", lambda: VT.dequantize_tokens(qv8, sv8, "int8", D, _t.float16))
+    dvq8 = med("vectorised.quant_int8", lambda: VT.quantize_tokens(xv, "int8"))
     vect = {"value": gbps(nvv, dv), "unit": "GB/s", "cores": cores, "reps": reps, "kind": "port",
             "sample": f"INT4->fp16 dequantise of {nv_layers}/{L} layers [{nv_layers},{B},{H},{T},{D}] as whole-tensor "
                       f"torch-CPU ops ({nvv} elements, median {dv:.3f} s), oracle/vectorised_torch.py",
             "quantise_value": gbps(nvv, dvq), "quantise_sample": f"same tensors, fp16->INT4 (median {dvq:.3f} s)",
             "int8": {"dequantise_value": gbps(nvv, dv8, "int8"), "quantise_value": gbps(nvv, dvq8, "int8")},
-            "torch_threads": _t.get_num_threads()}
+            "torch_threads": _t.get_num_threads(),
+            "note": "a chain of ~10 whole-tensor ops, each a full pass over an fp32 / int16 intermediate: ~10x the port's memory "
+                    "traffic, so it can sit below the all-core port"}
 
     # ---- literal: the reference's per-slice loop, sub-sampled in T -------------------------------
     Ts = min(T, 1024)
     xl = _t.from_numpy(xq[0, :, :, :Ts].copy())
     qs, ss = LL.quantize_slices(xl, "int4")
-    dl = _median_time(lambda: LL.dequantize_slices(qs, ss, "int4", D, _t.float16), reps)
-    dlq = _median_time(lambda: LL.quantize_slices(xl, "int4"), reps)
+    dl = med("literal.dequant_int4", lambda: LL.dequantize_slices(qs, ss, "int4", D, _t.float16))
+    dlq = med("literal.quant_int4", lambda: LL.quantize_slices(xl, "int4"))
     n_lit = B * H * Ts * D
     qs8, ss8 = LL.quantize_slices(xl, "int8")
-    dl8 = _median_time(lambda: LL.dequantize_slices(qs8, ss8, "int8", D, _t.float16), max(2, reps // 2))
-    dlq8 = _median_time(lambda: LL.quantize_slices(xl, "int8"), max(2, reps // 2))
+    dl8 = med("literal.dequant_int8", lambda: LL.dequantize_slices(qs8, ss8, "int8", D, _t.float16))
+    dlq8 = med("literal.quant_int8", lambda: LL.quantize_slices(xl, "int8"))
     lit = {"value": gbps(n_lit, dl), "unit": "GB/s", "cores": cores, "reps": reps, "kind": "port",
            "int8": {"dequantise_value": gbps(n_lit, dl8, "int8"), "quantise_value": gbps(n_lit, dlq8, "int8")},
            "sample": f"per-slice dequantise + {Ts}-way cat of one layer's V [{B},{H},{Ts},{D}] (T sub-sampled {Ts}/{T}; the "
                      f"loop is linear in T) with torch-CPU ops (median {dl:.3f} s), oracle/literal_loop.py",
            "quantise_value": gbps(n_lit, dlq), "quantise_sample": f"same slices, per-slice fp16->INT4 (median {dlq:.3f} s)",
-           "torch_threads": _t.get_num_threads()}
+           "torch_threads": _t.get_num_threads(),
+           "note": "1,024-element slices: every op is below torch's parallel grain, so the loop is single-threaded dispatch overhead whatever the pool size"}
 
-    # ---- eviction: the reference's own whole-tensor op chains on ONE [B,H,T,D] tensor ---------------
+    # ---- eviction: the reference's own whole-tensor op chains, and the C port, on ONE [B,H,T,D] tensor ---------------
     xe = _t.from_numpy(xq[0])
     W, chunk, keep = 256, 64, 256
-    tw = _median_time(lambda: VT.trim_kv_sliding_window(xe, W), reps)
-    tp = _median_time(lambda: VT.chunk_summarize_kv(xe, chunk, keep), max(2, reps // 2))
+    tw = med("eviction.window_torch", lambda: VT.trim_kv_sliding_window(xe, W))
+    tp = med("eviction.pool_torch", lambda: VT.chunk_summarize_kv(xe, chunk, keep))
+    tp1 = med("eviction.pool_port1", lambda: C.chunk_summarize(xq[0], chunk, keep, threads=1))
+    tpn = med("eviction.pool_portN", lambda: C.chunk_summarize(xq[0], chunk, keep, threads=cores)) if cores > 1 else None
     Tout = (max(T - keep, 0) + chunk - 1) // chunk + min(keep, T)
-    evict = {"cores": cores, "reps": reps, "pool_reps": max(2, reps // 2), "kind": "port", "unit": "GB/s",
+    pool_bytes = 2.0 * B * H * D * (T + Tout)
+    evict = {"cores": cores, "reps": reps, "pool_reps": reps, "kind": "port", "unit": "GB/s",
              "window_value": round(4.0 * B * H * min(W, T) * D / tw / 1e9, 5),
-             "pool_value": round(2.0 * B * H * D * (T + Tout) / tp / 1e9, 5),
+             "pool_value": round(pool_bytes / tp / 1e9, 5),
+             "pool_port": {"cores_1": round(pool_bytes / tp1 / 1e9, 5), f"cores_{cores}": None if tpn is None else round(pool_bytes / tpn / 1e9, 5),
+                           "sample": f"oracle/kvq_oracle.c chunk summary of the same tensor (medians {tp1 * 1e3:.2f} ms on 1 core"
+                                     + (f", {tpn * 1e3:.2f} ms on {cores}" if tpn is not None else "") + ")"},
+             "torch_threads": _t.get_num_threads(),
              "sample": f"trim_kv_sliding_window(W={W}) + materialise and chunk_summarize_kv(chunk={chunk}, keep_last={keep}) of one "
                        f"[{B},{H},{T},{D}] fp16 tensor as the reference's torch ops (medians {tw * 1e3:.3f} ms / {tp * 1e3:.2f} ms), "
                        f"oracle/vectorised_torch.py"}
+    _t.set_num_threads(threads_before)
+    thr1 = hostcpu.throttle_counters()
+    hc["throttle_counters_before_after"] = [thr0, thr1]
+    hc["nr_throttled_during_baseline"] = None if thr0 is None or thr1 is None else thr1[1] - thr0[1]
+    # a median that lands on a multiple of the 100 ms CFS period is a scheduler quantum, not a rate
+    suspects = [f"{k}: {v * 1e3:.2f} ms" for k, v in medians.items()
+                if v >= 0.095 and abs(v * 10 - round(v * 10)) <= 0.01 * round(v * 10)]
     out = {"value": port["value"], "unit": "GB/s", "cores": 1, "kind": "port", "sample": port["sample"], "reps": reps,
-           "host_cores_available": cores, "port": port, "vectorised": vect, "literal": lit, "eviction": evict}
+           "host_cores_available": cores, "host_cpu": hc, "timer_quantum_suspects": suspects,
+           "port": port, "vectorised": vect, "literal": lit, "eviction": evict}
     if parity is not None:
         out["parity"] = parity
         out["max_rel_err_vs_gpu"] = port["max_rel_err_vs_gpu"]
@@ -890,6 +927,45 @@ def _subrecord(fn, *a, **kw):
         return {"error": f"{type(exc).__name__}: {exc}"[:400]}
 
 
+QUANT_ROW_PAD_TOKENS = 48  # profiles/r04a_quant_stride_table.md: any pad >= 4 tokens moves the input rows off the 4 MiB stride
+
+
+def _quant_variants(tensors, kind, n_elts, dev):
+    """Two more timings of the quantise launch on the same set (side measurements; scratch stores, rotating):
+      padded_rows       the same values as a [:, :, :, :T] view of a [G,B,H,T+48,D] allocation — what a caller with a
+                        preallocated fp16 KV buffer hands over; the 8 head rows of a tile are then 4 MiB + 12 KiB apart
+                        instead of exactly 4 MiB (profiles/r04a_quant_stride_table.md: the input stride matters, the store's does not)
+      outlier_channels  SURVEY §8d's second distribution: 1 % of the (head, d) channels x 8 in every token, contiguous rows —
+                        times the data-dependent IEEE-divide redo of the quotient guard (kvq_quant.hip quotient_bits8)"""
+    from efficient_llm_inference_amd import kernels as _k
+    G = len(tensors)
+    B, H, T, D = tensors[0].shape
+    Dq = D if kind == "int8" else D // 2
+    qdt = torch.int8 if kind == "int8" else torch.uint8
+    scratch = [(torch.empty(G, B, H, T, Dq, device=dev, dtype=qdt), torch.zeros(G, T, device=dev, dtype=torch.float32)) for _ in range(2)]
+    ws = torch.empty(G * T, device=dev, dtype=torch.float32)
+    nbytes = n_elts * BYTES_PER_ELT[kind]
+    out = {}
+    full = torch.empty(G, B, H, T + QUANT_ROW_PAD_TOKENS, D, device=dev, dtype=tensors[0].dtype)
+    xp = full[:, :, :, :T]
+    for g, t in enumerate(tensors):
+        xp[g].copy_(t)
+    fn = lambda i: _k.quant_tokens(xp, scratch[i % 2][0], scratch[i % 2][1], ws, kind)  # noqa: E731
+    out["padded_rows"] = _roofline(_kernels_of(lambda: fn(0)), nbytes, _time_launches(fn, 12), _DISPATCH_TIMER,
+                                   input=f"[G,B,H,T+{QUANT_ROW_PAD_TOKENS},D][:, :, :, :T] view of one allocation, same values")
+    del xp, full
+    xo = torch.stack(list(tensors))  # contiguous [G,B,H,T,D]
+    gen = torch.Generator(device="cpu").manual_seed(42)
+    mask = (torch.rand(H, D, generator=gen) < 0.01).to(dev)
+    xo.mul_(torch.where(mask, 8.0, 1.0).to(xo.dtype)[None, None, :, None, :])
+    fn2 = lambda i: _k.quant_tokens(xo, scratch[i % 2][0], scratch[i % 2][1], ws, kind)  # noqa: E731
+    out["outlier_channels"] = _roofline(_kernels_of(lambda: fn2(0)), nbytes, _time_launches(fn2, 12), _DISPATCH_TIMER,
+                                        input=f"contiguous rows, {int(mask.sum())} of {H * D} (head, d) channels x 8")
+    del xo, scratch, ws
+    _free()
+    return out
+
+
 def run_dequant(args, rank, world, dev, backend):
     """The headline workload (module docstring): one STEP = dequantise the whole quantised cache (2 launches)."""
     import efficient_llm_inference_amd as E
@@ -952,7 +1028,9 @@ def run_dequant(args, rank, world, dev, backend):
 
         kern = _kernels_of(lambda: qfn(0))
         ms = _time_launches(qfn, 12)
-        quant_info[f"quant_{stores[0].kind}"] = _roofline(kern, n_elts * BYTES_PER_ELT[stores[0].kind], ms, _DISPATCH_TIMER, set=name.upper())
+        quant_info[f"quant_{stores[0].kind}"] = _roofline(kern, n_elts * BYTES_PER_ELT[stores[0].kind], ms, _DISPATCH_TIMER, set=name.upper(),
+                                                          input="the legacy tuple: 32 contiguous [B,H,T,D] tensors, N(0,1); head rows T*D*2 B apart (4 MiB at T = 16384)",
+                                                          **_quant_variants(tensors, stores[0].kind, n_elts, dev))
 
     k_kernel = _kernels_of(lambda: caches[0]._k.dequant(torch.float16, out=outs[0][0]))
     v_kernel = _kernels_of(lambda: caches[0]._v.dequant(torch.float16, out=outs[0][1]))

@@ -207,6 +207,47 @@ __global__ __launch_bounds__(64) void rw_quant_tile_i8_k(const u32x4* __restrict
     else *dst = v;
   }
 }
+// Round 4: the one-wave tile's loads (8 x 1 KiB, one per head row, real strides) with the OUTPUT pieces of WAVES
+// neighbouring tiles merged through LDS by a WAVES-wave workgroup: wave w still loads only its own 4-token tile, writes
+// its 4 B (INT4) / 8 B (INT8) per lane and row into an LDS image [8 rows][WAVES x 4 tokens], ONE workgroup barrier, then
+// every wave stores whole 1-KiB instructions of the image: a row's run is WAVES x 256 B (INT4) / WAVES x 512 B (INT8)
+// contiguous instead of 256 / 512 B. pad_in / pad_out: extra tokens in the row strides (the stride experiment).
+template <int WAVES, int BITS>
+__global__ __launch_bounds__(WAVES * 64) void rw_quant_tile_wg_k(const u32x4* __restrict__ in, u32x4* __restrict__ out, uint32_t T,
+                                                                 uint32_t pad_in, uint32_t pad_out) {
+  constexpr int QW = BITS / 4;                   // dwords per lane and row (INT4 1, INT8 2)
+  constexpr int ROWV = WAVES * 4 * BITS;         // 16-byte vectors of one row's merged run (INT4: WAVES x 16)
+  constexpr int NI = BITS / 2;                   // store instructions per wave (INT4 2, INT8 4)
+  __shared__ __attribute__((aligned(16))) uint32_t s_o[8 * WAVES * 64 * QW];
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  const int64_t hv_in = (int64_t)(T + pad_in) * 16, hv_out = (int64_t)(T + pad_out) * BITS;  // INT4: 4 vectors per token, INT8: 8
+  const u32x4* p = in + (int64_t)blockIdx.y * 8 * hv_in + ((int64_t)blockIdx.x * WAVES + w) * 64 + lane;
+  u32x4 x[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = __builtin_nontemporal_load(p + (int64_t)i * hv_in);
+  u32x4 all = x[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) all ^= x[i];     // like the abs-max: nothing leaves before every load is back
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint32_t* d = &s_o[((i * WAVES + w) * 64 + lane) * QW];
+    d[0] = x[i][0] ^ all[1];
+    if (QW == 2) d[1] = x[i][2] ^ all[3];
+  }
+  if (WAVES > 1) __syncthreads();
+  else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  u32x4* q = out + (int64_t)blockIdx.y * 8 * hv_out + (int64_t)blockIdx.x * ROWV;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const uint32_t f = (w * NI + j) * 64 + lane;  // vector of the image, row-major
+    const u32x4 v = *reinterpret_cast<const u32x4*>(&s_o[f * 4]);
+    __builtin_nontemporal_store(v, q + (int64_t)(f / ROWV) * hv_out + f % ROWV);
+  }
+}
 template <bool COOP, int NVALU = 0>
 __global__ __launch_bounds__(COOP ? 512 : 64) void rw_quant_tile_k(const u32x4* __restrict__ in, u32x4* __restrict__ out, int64_t head_vec_in,
                                                                    int64_t head_vec_out) {
@@ -535,6 +576,27 @@ int main(int argc, char** argv) {
       ms = tm.ms_per([&] { rotate(); rw_dequant_chunk_k<4, 8, 4, true><<<(unsigned)(N / 2048), 64>>>((const uint8_t*)q8, (u32x4*)out); }, iters);
       printf("calib dequantpat INT8 traffic (2 KiB in, 4 KiB out per wave, nt loads)   %8.3f ms  %8.1f GB/s\n", ms, 3.0 * N / ms / 1e6);
     }
+  }
+  if (what == "quantwg") {  // round 4: merged output pieces through a WAVES-wave workgroup, and padded row strides (KVQ_PAD_IN / KVQ_PAD_OUT tokens)
+    const uint32_t pad_in = getenv("KVQ_PAD_IN") ? (uint32_t)atoll(getenv("KVQ_PAD_IN")) : 0u, pad_out = getenv("KVQ_PAD_OUT") ? (uint32_t)atoll(getenv("KVQ_PAD_OUT")) : 0u;
+    const uint32_t padm = pad_in > pad_out ? pad_in : pad_out;
+    const uint32_t Te = (uint32_t)((T - padm) / 32 * 32);  // tokens walked: rows of Te + pad tokens fit the T-token allocations
+    const double n_e = (double)G * 8 * Te * 128;
+    printf("# quantwg: pad_in=%u pad_out=%u tokens (row strides %lld / %lld B in, INT4 / INT8 %lld / %lld B out), %u tokens walked\n", pad_in, pad_out,
+           (long long)(Te + pad_in) * 256, (long long)(Te + pad_in) * 256, (long long)(Te + pad_out) * 64, (long long)(Te + pad_out) * 128, Te);
+#define RUN_WG(WV, BITS_)                                                                                          \
+  {                                                                                                               \
+    double best = 1e9, sum = 0;                                                                                   \
+    for (int rep = 0; rep < 3; ++rep) {                                                                           \
+      const double ms = tm.ms_per([&] { rotate(); rw_quant_tile_wg_k<WV, BITS_><<<dim3(Te / (4 * WV), (unsigned)G), WV * 64>>>((const u32x4*)in16, (u32x4*)out, Te, pad_in, pad_out); }, iters); \
+      best = ms < best ? ms : best; sum += ms;                                                                    \
+    }                                                                                                             \
+    const double bpe = BITS_ == 4 ? 2.5 : 3.0;                                                                    \
+    printf("calib quantwg INT%d waves=%d (row run %5d B)  best %8.3f ms  mean %8.3f ms  %8.1f GB/s  frac8T=%.3f\n", BITS_, WV, WV * 64 * BITS_, best, sum / 3, bpe * n_e / best / 1e6, bpe * n_e / best / 1e6 / 8000.0); \
+  }
+    RUN_WG(1, 4) RUN_WG(2, 4) RUN_WG(4, 4) RUN_WG(8, 4) RUN_WG(16, 4)
+    RUN_WG(1, 8) RUN_WG(2, 8) RUN_WG(4, 8) RUN_WG(8, 8)
+#undef RUN_WG
   }
   if (what == "quantpat") {  // the quantise kernels' loads + stores without arithmetic: one-wave tiles vs head-per-wave tiles
     const int64_t T_all = N / (8 * 128);           // tokens if the 1 GiB input were one [8][T][128] tensor
