@@ -50,6 +50,7 @@ EXPORTS = (
     "kvq_decode_step_dev",
     "kvq_decode_step_layers",
     "kvq_time_next_launch",
+    "kvq_timing_armed",
     "kvq_kernel_log_clear",
     "kvq_kernel_log",
     "kvq_set_tunable",
@@ -140,6 +141,8 @@ def _declare(lib):
     lib.kvq_chunk_summary_len.argtypes = [c_int64, c_int64, c_int64]
     lib.kvq_time_next_launch.restype = c_int
     lib.kvq_time_next_launch.argtypes = [P, P]
+    lib.kvq_timing_armed.restype = c_int
+    lib.kvq_timing_armed.argtypes = []
     lib.kvq_kernel_log_clear.restype = None
     lib.kvq_kernel_log_clear.argtypes = []
     lib.kvq_kernel_log.restype = c_int64

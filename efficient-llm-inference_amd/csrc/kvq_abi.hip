@@ -10,12 +10,16 @@
 namespace kvq {
 
 static thread_local char g_err[512] = "no error";
+static thread_local TimingEvents g_timing = {nullptr, nullptr};
 
+// Every failing return of the library passes through here; it also DISARMS a pending kvq_time_next_launch pair, so that
+// a call that failed validation cannot leave its events to be taken by some later launch of the thread.
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+  g_timing = TimingEvents{nullptr, nullptr};
 }
 
 // The reference never checks its launches (extensions.py:79,105); we do, every time.
@@ -28,7 +32,6 @@ int check_launch(const char* what) {
   return 0;
 }
 
-static thread_local TimingEvents g_timing = {nullptr, nullptr};
 TimingEvents take_timing_events() {
   const TimingEvents e = g_timing;
   g_timing = TimingEvents{nullptr, nullptr};
@@ -108,6 +111,7 @@ static const TunableKey kTunableKeys[] = {
     {"attn_mfma_min_nq", &Tunables::attn_mfma_min_nq, true},
     {"attn_mfma_tc", &Tunables::attn_mfma_tc, true},
     {"attn_fused", &Tunables::attn_fused, true},
+    {"attn_fold", &Tunables::attn_fold, true},
     {"attn_k_i8", &Tunables::attn_k_i8, true},
     {"attn_merge_fast", &Tunables::attn_merge_fast, true},
     {"attn_stream_roll", &Tunables::attn_stream_roll, true},
@@ -137,6 +141,8 @@ int kvq_time_next_launch(void* start_event, void* stop_event) {
   kvq::g_timing = kvq::TimingEvents{reinterpret_cast<hipEvent_t>(start_event), reinterpret_cast<hipEvent_t>(stop_event)};
   return 0;
 }
+
+int kvq_timing_armed(void) { return (kvq::g_timing.start || kvq::g_timing.stop) ? 1 : 0; }
 
 int kvq_set_tunable(const char* key, int64_t value) {
   if (!key) return KVQ_E_NULL;

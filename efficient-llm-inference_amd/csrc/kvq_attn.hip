@@ -74,6 +74,13 @@ struct AttnArgs {
   // the same launch for every decode step). T above is then the host's upper bound: it sizes the grid and
   // the workspace; workgroups past the real count exit, the merge reads ceil(T / TS) partials.
   const int32_t* t_dev;
+  // In-launch merge (round 4; host: attn_fold_plan): != nullptr = the LDS-staged kernel's waves store their partials
+  // write-through, take a ticket on arrive[b * Hkv + hk], and the wave that draws the last one merges the kv head's query
+  // heads itself (merge_group_one_wave) — no merge launch. The words are zero when the launch starts (the host call's
+  // hipMemsetAsync) and zero again when it ends (the merging wave resets its word).
+  uint32_t* arrive;
+  uint32_t ws_bytes;      // bytes of `ws` the merge may address (buffer descriptor range; host: < 2 GiB)
+  int32_t fold_has_new;   // the exact new token's term is part of the merge (kn / vn valid either way)
 };
 
 // stored tokens this launch attends: the host's count, or the device word of a graph-replayed step
@@ -1546,6 +1553,154 @@ __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_stream_mf
   }
 }
 
+#if KVQ_AB
+// ---------------------------------------------------------------------------- merge inside the partial launch (round 4)
+// A-B builds only (attn_fold): MEASURED SLOWER than partial + merge launches (batch 8, 16 K tokens, per layer call, one box,
+// profiles/r04b_*): two launches 40.1 us; write-through stores + ticket and NO merge 39.2; this code 42.0 without the agent
+// acquire, 43.4 with it — the separate merge launch costs 0.9 us more than not merging at all (its dispatch overlaps the
+// partial kernel's drain), one wave merging four heads behind its ticket costs 2.8.
+// The separate merge launch costs a kernel boundary (1.5-1.9 us) plus its own round trip although it moves 2.4 MB. Here the
+// LAST wave of a (batch row, kv head) to finish does that head group's merge itself (split-K ticket, cdna_hip_programming.md
+// section 5 item 2 / Guideline 16, counter form):
+//   every wave   partial stores WRITE-THROUGH (buffer stores, aux 16 = sc1: the bytes leave this XCD's L2), then
+//                s_waitcnt vmcnt(0) (they have), then ONE relaxed agent-scope fetch_add on the group's word
+//   last ticket  (the add returned nsplit - 1; no wave ever waits or spins) resets the word for the next launch, ONE
+//                agent-scope acquire (this CU's L1 may hold nothing of the partials: nobody read them in this launch, but the
+//                always-valid form is kept: the hand-off table's one-workgroup-per-CU cell is not ours), then reads every
+//                partial with sc1 buffer loads (L1 bypassed) and merges
+// Nothing depends on dispatch order, timing or placement: waves only ever add and leave; exactly one add per launch and
+// group returns nsplit - 1 provided the word was zero at launch (the host call's memset node; the reset keeps it so
+// between the launches of one host call).
+#ifndef KVQ_FOLD_ACQ  // calibration (`make calib_fold`): 0 = no agent-scope acquire in front of the merge's sc1 loads
+#define KVQ_FOLD_ACQ 1
+#endif
+__device__ __forceinline__ bool arrive_is_last(uint32_t* word, const uint32_t narrive) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every write-through store of this wave has completed
+  uint32_t old = 0u;
+  if ((threadIdx.x & 63u) == 0u) old = __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+  if (old != narrive - 1u) return false;
+  if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if KVQ_FOLD_ACQ
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the invalidate has completed before the first partial is requested
+#else
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the compiler from moving the sc1 loads above the ticket
+#endif
+  return true;
+}
+
+// The merge of ONE kv head's query heads (at most NH, head_dim 128, at most 16 splits) by ONE wave, every operand requested
+// up front as 16-byte sc1 loads: lane = (half h2, dl): the four elements d = 4 dl .. 4 dl + 3 of the eight splits whose
+// bit 2 is h2 (so that the block kernel's split groups k and k + 8 sit in one lane). Weights by v_readlane. The arithmetic is
+// decode_attn_merge_fast_k's operand for operand and in its order (o_k = x_k w_k + x_(k+8) w_(k+8); t = o_0 + ... + o_7 with
+// o_4 .. o_7 fetched from the other half; the new token's fma; the division): equal bits, tested against the two-launch path.
+template <int NH>
+__device__ __forceinline__ void merge_group_one_wave(const AttnArgs& a, const bool has_new, const uint32_t hk, const uint32_t b) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr uint32_t D = 128;
+  const uint32_t lane = threadIdx.x & 63u, h2 = lane >> 5, dl = lane & 31u;
+  const uint32_t nb = a.nsplit;  // 1 ... 16 (host); every split is live (no device-side token count on this path)
+  const uint32_t ns = nb;
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, (int)a.ws_bytes, 0x00020000);
+  u32x2 ml_raw[NH];
+  u32x4 x[NH][8];
+  uint16_t qraw[NH][2], kraw[2], vraw[4];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    const uint32_t hq = hk * a.nq + ((uint32_t)j < a.nq ? (uint32_t)j : a.nq - 1u);  // heads past nq: a valid row, result dropped
+    const uint32_t row0 = (b * a.Hq + hq) * nb;
+    ml_raw[j] = __builtin_amdgcn_raw_buffer_load_b64(wr, (row0 + (lane < nb ? lane : nb - 1u)) * 8u, 0, 16);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t sp = (uint32_t)(u & 3) + 4u * h2 + 8u * (uint32_t)(u >> 2);
+      const uint32_t sc = sp < nb ? sp : nb - 1u;
+      x[j][u] = __builtin_amdgcn_raw_buffer_load_b128(wr, ((uint32_t)a.acc_off + (row0 + sc) * D + 4u * dl) * 4u, 0, 16);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      qraw[j][h] = reinterpret_cast<const uint16_t*>(a.q)[(int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + 64 * h + lane];
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) kraw[h] = reinterpret_cast<const uint16_t*>(a.kn)[(int64_t)b * a.kn_sb + (int64_t)hk * a.kn_sh + 64 * h + lane];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) vraw[e] = reinterpret_cast<const uint16_t*>(a.vn)[(int64_t)b * a.vn_sb + (int64_t)hk * a.vn_sh + 4u * dl + e];
+  __builtin_amdgcn_sched_barrier(0);
+  auto widen = [&](uint16_t h) { return a.dtype == KVQ_F16 ? Elem<KVQ_F16>::widen(h) : Elem<KVQ_BF16>::widen(h); };
+  // the NH heads in LOCKSTEP (no branch between them: one wave's dependent reductions of one head issue under another's)
+  float w[NH], w_new[NH], inv[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    f32x2 mlv = {__uint_as_float(ml_raw[j][0]), __uint_as_float(ml_raw[j][1])};
+    if (lane >= ns) mlv = f32x2{-INFINITY, 0.0f};
+    const float p0 = wave_fsum(widen(has_new ? qraw[j][0] : (uint16_t)0) * widen(kraw[0]));
+    const float p1 = wave_fsum(widen(has_new ? qraw[j][1] : (uint16_t)0) * widen(kraw[1]));
+    const float s_tok = has_new ? ((p0 + p1) + (0.0f + 0.0f)) * a.sm_scale : -INFINITY;
+    const float M = fmaxf(wave_fmax(mlv[0]), s_tok);
+    w[j] = lane < ns ? __expf(mlv[0] - M) : 0.0f;
+    const float lw = wave_fsum(lane < ns ? mlv[1] * w[j] : 0.0f);
+    w_new[j] = has_new ? __expf(s_tok - M) : 0.0f;
+    const float L = ((lw + 0.0f) + (0.0f + 0.0f)) + w_new[j];
+    inv[j] = 1.0f / L;
+  }
+  float o[NH][4][4], oo[NH][4][4];  // [head][split group kk of this half: k = kk + 4 h2][element]; oo: the other half's
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    float wt[16];
+#pragma unroll
+    for (int sp = 0; sp < 16; ++sp) wt[sp] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(w[j]), sp));
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint32_t k = (uint32_t)kk + 4u * h2;
+      const float w_lo = h2 ? wt[kk + 4] : wt[kk], w_hi = h2 ? wt[kk + 12] : wt[kk + 8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = 0.0f;
+        const float a0 = v + __uint_as_float(x[j][kk][e]) * w_lo;
+        v = k < ns ? a0 : v;
+        const float a1 = v + __uint_as_float(x[j][kk + 4][e]) * w_hi;
+        v = k + 8u < ns ? a1 : v;
+        o[j][kk][e] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NH; ++j)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) oo[j][kk][e] = __shfl_xor(o[j][kk][e], 32);
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    // lanes 0..31 hold groups 0..3 and have fetched 4..7: the block kernel's final row sum, in its order
+    if (h2 == 0u && (uint32_t)j < a.nq) {
+      const uint32_t hq = hk * a.nq + (uint32_t)j;
+      uint16_t ob[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) t += o[j][kk][e];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) t += oo[j][kk][e];
+        if (has_new) t = fmaf(w_new[j], widen(vraw[e]), t);
+        t *= inv[j];
+        if (a.dtype == KVQ_F16) {
+          const f16 hv = (f16)t;
+          __builtin_memcpy(&ob[e], &hv, 2);
+        } else {
+          const __bf16 bv = (__bf16)t;
+          __builtin_memcpy(&ob[e], &bv, 2);
+        }
+      }
+      uint16_t* dst = reinterpret_cast<uint16_t*>(a.out) + (int64_t)b * a.o_sb + (int64_t)hq * a.o_sh + 4u * dl;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[e] = ob[e];
+    }
+  }
+}
+#endif  // KVQ_AB (merge inside the partial launch)
+
 // ---------------------------------------------------------------------------- LDS-staged streaming variant
 // The streaming kernel above asks HBM for its rows in MFMA-operand shape: a K load instruction touches sixteen rows,
 // 64 B of each (lane (x, g): 16 B at row x, byte 16 g), a V load four rows — half-line and sub-line pieces whose
@@ -1742,10 +1897,17 @@ __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_lds_mfma_
   wait_vmcnt<0>();  // the empty tail requests retire before the wave's LDS is released
   if constexpr (TG == 4 && NB > 1) st.reduce_l();
   // ---- workspace: (m, l) per head, acc[heads][D] — the layout the merge kernels read ---------------------------
+  const bool fold = KVQ_AB && a.arrive != nullptr;  // (A-B builds) uniform: the merge runs in THIS launch (stores write-through, ticket below)
+  const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, (int)a.ws_bytes, 0x00020000);
   if (g == 0u && x < a.nq) {
-    float* o = a.ws + (((int64_t)b * a.Hq + hk * a.nq + x) * a.nsplit + split) * 2;
-    o[0] = st.m * 0.693147180559945309f;
-    o[1] = st.l;
+    const int64_t oi = (((int64_t)b * a.Hq + hk * a.nq + x) * a.nsplit + split) * 2;
+    const float mv = st.m * 0.693147180559945309f;
+    if (fold) {
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(mv), __float_as_uint(st.l)}, wsr, (uint32_t)oi * 4u, 0, 16);
+    } else {
+      a.ws[oi] = mv;
+      a.ws[oi + 1] = st.l;
+    }
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -1758,11 +1920,26 @@ __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_lds_mfma_
         if constexpr (VBITS == 4) e = c < 4 ? 2 * c : 2 * (c - 4) + 1;
         o8[e] = st.acc[c][q] * st.svref;
       }
-      float* dst = a.ws + a.acc_off + (((int64_t)b * a.Hq + hk * a.nq + h) * a.nsplit + split) * a.D + DVN * x;
+      const int64_t di = a.acc_off + (((int64_t)b * a.Hq + hk * a.nq + h) * a.nsplit + split) * a.D + DVN * x;
 #pragma unroll
-      for (int c = 0; c < DVN; c += 4) *reinterpret_cast<f32x4*>(dst + c) = f32x4{o8[c], o8[c + 1], o8[c + 2], o8[c + 3]};
+      for (int c = 0; c < DVN; c += 4) {
+        if (fold)
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(o8[c]), __float_as_uint(o8[c + 1]), __float_as_uint(o8[c + 2]), __float_as_uint(o8[c + 3])},
+                                                 wsr, (uint32_t)(di + c) * 4u, 0, 16);
+        else
+          *reinterpret_cast<f32x4*>(a.ws + di + c) = f32x4{o8[c], o8[c + 1], o8[c + 2], o8[c + 3]};
+      }
     }
   }
+#if KVQ_AB
+  if (fold) {
+#ifdef KVQ_FOLD_NOMERGE  // calibration (`make calib_fold`, wrong output): write-through stores + ticket only, what the merge itself costs on top
+    (void)arrive_is_last(a.arrive + b * a.Hkv + hk, a.nsplit);
+#else
+    if (arrive_is_last(a.arrive + b * a.Hkv + hk, a.nsplit)) merge_group_one_wave<4>(a, a.fold_has_new != 0, hk, b);
+#endif
+  }
+#endif
 }
 
 #if KVQ_AB
@@ -2628,6 +2805,24 @@ static bool plan_onetile(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nspli
   return *nsplit <= (uint32_t)kAttnMaxSplit;
 }
 
+// ---- in-launch merge (round 4): the arrival words live in FRONT of the partials, one per (batch row, kv head), padded to
+// 16 bytes: their place does not move with T, and a memset of them starts at the caller's workspace pointer
+static int64_t arrive_floats(const kvq_attn_dims_t* d) { return (d->B * d->Hkv + 3) / 4 * 4; }
+// Does the LDS-staged kernel merge inside its own launch for these dims? (attention over the store, with or without the
+// exact new token; not the append step, not a device-side token count.) Needs: the ring plan, head_dim 128, at most 4 query
+// heads per kv head and 16 splits (merge_group_one_wave), a workspace the descriptor can range-check.
+// A-B key attn_fold (measured slower, see merge_group_one_wave): 0 (default, and always in the default library) = never,
+// 1 = where the host call covers several layers (kvq_decode_step_layers: ONE memset of the words per call), 2 = in
+// kvq_decode_attn too (a memset per call).
+static bool attn_fold_plan(const kvq_attn_dims_t* d) {
+  if (!KVQ_AB || tunables().attn_fold <= 0 || !use_lds(d) || d->T <= 0 || d->Hq / d->Hkv > 4) return false;
+  if (KVQ_AB && (tunables().attn_lds == 2 || tunables().attn_lds == 3 || tunables().attn_lds_nb != 0 || lds_tc() != 64 || tunables().attn_fused)) return false;
+  uint32_t ts, ns, tpw;
+  if (!plan(d, &ts, &ns, &tpw) || tpw == 0u || ns == 0u || ns > 16u) return false;
+  const int64_t rows = d->B * d->Hq * (int64_t)ns;
+  return ((rows * 2 + 3) / 4 * 4 + rows * d->D) * 4 < (int64_t(1) << 31);
+}
+
 #if KVQ_AB
 // ---- fused single launch: which (tokens per wave, waves per workgroup) and how many workgroup splits
 struct FusedPlan {
@@ -2802,9 +2997,9 @@ int64_t kvq_decode_attn_workspace(const kvq_attn_dims_t* d) {
   // the fused single-launch path (whatever shape the tunables pick: at most one split per 512 tokens)
 #if KVQ_AB
   const int64_t fused = use_mfma(d) ? fused_ws_floats(d, (d->T + 511) / 512 > 0 ? (d->T + 511) / 512 : 1) : 0;
-  return legacy > fused ? legacy : fused;
+  return arrive_floats(d) + (legacy > fused ? legacy : fused);
 #else
-  return legacy;
+  return arrive_floats(d) + legacy;
 #endif
 }
 
@@ -2817,7 +3012,7 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
                             int64_t kn_sb, int64_t kn_sh, const void* v_new, int64_t vn_sb, int64_t vn_sh, void* out,
                             int64_t o_sb, int64_t o_sh, int dtype, float sm_scale, float* workspace,
                             int64_t workspace_floats, const kvq_attn_dims_t* d, void* stream, const NewTokenArgs* nt,
-                            const int32_t* t_dev = nullptr) {
+                            const int32_t* t_dev = nullptr, int fold = 0) {  // fold: 0 = two launches, 1 = merge in the launch (the caller zeroed the arrival words), 2 = zero them here
   if (!d || !q || !out) {
     set_error("%s: NULL q / out / dims", name);
     return KVQ_E_NULL;
@@ -2884,7 +3079,12 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
   a.kn = k_new; a.kn_sb = kn_sb; a.kn_sh = kn_sh;
   a.vn = v_new; a.vn_sb = vn_sb; a.vn_sh = vn_sh;
   a.out = out; a.o_sb = o_sb; a.o_sh = o_sh;
-  a.ws = workspace;
+  const int64_t arrive_n = arrive_floats(d);  // the arrival words of the in-launch merge sit in front of the partials
+  a.ws = workspace ? workspace + arrive_n : workspace;
+  workspace_floats -= arrive_n;
+  a.arrive = nullptr;
+  a.ws_bytes = 0u;
+  a.fold_has_new = 0;
   a.sm_scale = sm_scale;
   a.B = (uint32_t)d->B; a.Hq = (uint32_t)d->Hq; a.Hkv = (uint32_t)d->Hkv; a.T = (uint32_t)d->T; a.D = (uint32_t)d->D;
   a.nq = (uint32_t)(d->Hq / d->Hkv);
@@ -2910,6 +3110,28 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
     return KVQ_E_DIMS;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (fold && !nt && !t_dev && a.lds == 1u && a.stream_tpw && attn_fold_plan(d)) {  // ONE launch: partials, ticket, merge by the last wave
+    if (fold == 2) {
+      const hipError_t e = hipMemsetAsync(workspace, 0, (size_t)arrive_n * 4, st);
+      if (e != hipSuccess) {
+        set_error("%s: hipMemsetAsync of the arrival words: %s", name, hipGetErrorString(e));
+        return (int)e;
+      }
+    }
+    a.arrive = reinterpret_cast<uint32_t*>(workspace);
+    a.ws_bytes = (uint32_t)((a.acc_off + (int64_t)a.B * a.Hq * a.nsplit * a.D) * 4);
+    a.fold_has_new = a.kn ? 1 : 0;
+    if (!a.kn) {  // no new token: valid addresses for the merge's unconditional loads (values unused)
+      a.kn = a.vn = a.q;
+      a.kn_sb = a.vn_sb = a.q_sb;
+      a.kn_sh = a.vn_sh = 0;
+    }
+    if (k_bits == 8 && v_bits == 8) launch_partial<8, 8>(a, st);
+    else if (k_bits == 8) launch_partial<8, 4>(a, st);
+    else if (v_bits == 8) launch_partial<4, 8>(a, st);
+    else launch_partial<4, 4>(a, st);
+    return check_launch(name);
+  }
 #if KVQ_AB
   FusedPlan fp;
   // a captured HIP graph would replay the launch's host-side epoch: the arrival word then already holds
@@ -2980,9 +3202,9 @@ int64_t kvq_decode_attn_workspace_cap(const kvq_attn_dims_t* d) {
   const int64_t legacy = (rows * 2 + 3) / 4 * 4 + rows * d->D;
 #if KVQ_AB
   const int64_t fused = use_mfma(d) ? fused_ws_floats(d, (d->T + 511) / 512 + 1) : 0;  // monotone in T
-  return legacy > fused ? legacy : fused;
+  return arrive_floats(d) + (legacy > fused ? legacy : fused);
 #else
-  return legacy;
+  return arrive_floats(d) + legacy;
 #endif
 }
 
@@ -2992,9 +3214,10 @@ int kvq_decode_attn(const void* q, int64_t q_sb, int64_t q_sh, const uint8_t* k_
                     const void* v_new, int64_t vn_sb, int64_t vn_sh, void* out, int64_t o_sb, int64_t o_sh, int dtype,
                     float sm_scale, float* workspace, int64_t workspace_floats, const kvq_attn_dims_t* d,
                     void* stream) {
+  // (A-B key attn_fold = 2: the in-launch merge here too, behind its own memset of the arrival words)
   return decode_attn_impl("kvq_decode_attn", q, q_sb, q_sh, k_store, k_st, k_scales, k_bits, v_store, v_st, v_scales, v_bits,
                           k_new, kn_sb, kn_sh, v_new, vn_sb, vn_sh, out, o_sb, o_sh, dtype, sm_scale, workspace,
-                          workspace_floats, d, stream, nullptr);
+                          workspace_floats, d, stream, nullptr, nullptr, KVQ_AB && tunables().attn_fold == 2 ? 2 : 0);
 }
 
 
@@ -3031,7 +3254,7 @@ int kvq_decode_step(const void* q, int64_t q_sb, int64_t q_sh, const void* k_new
   if (rc) return rc;
   const kvq_dims_t qd = {1, d->B, d->Hkv, 1, d->D};
   const kvq_strides_t kin = {0, kn_sb, kn_sh, d->D}, vin = {0, vn_sb, vn_sh, d->D};
-  float* absmax_ws = workspace;  // only the generic two-pass path uses it (1 float); the attention is already enqueued
+  float* absmax_ws = workspace + arrive_floats(d);  // only the generic two-pass path uses it (1 float, behind the arrival words); the attention is already enqueued
   rc = k_bits == 8
            ? kvq_quant_i8_tokens(k_new, nullptr, &kin, dtype, reinterpret_cast<int8_t*>(k_store + d->T * k_st->t), k_st,
                                  k_scales + d->T, 0, absmax_ws, eps, &qd, stream)
@@ -3084,9 +3307,28 @@ int kvq_decode_step_layers(int64_t n_layers, int append, const void* const* q, i
     set_error("%s: NULL pointer table (or n_layers < 0)", name);
     return KVQ_E_NULL;
   }
+  // attention only (no append), on the LDS-staged kernel: every layer's merge runs inside its partial launch. ONE memset of
+  // the arrival words covers the whole call (each launch leaves them zero for the next: stream order)
+  int fold = 0;
+  if (!append && n_layers > 0 && d && workspace && d->B > 0 && d->Hkv > 0 && d->Hq > 0 && d->Hq % d->Hkv == 0 && attn_fold_plan(d) &&
+      workspace_floats >= kvq_decode_attn_workspace(d)) {
+    const hipError_t e = hipMemsetAsync(workspace, 0, (size_t)arrive_floats(d) * 4, reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+      set_error("%s: hipMemsetAsync of the arrival words: %s", name, hipGetErrorString(e));
+      return (int)e;
+    }
+    fold = 1;
+  }
   for (int64_t i = 0; i < n_layers; ++i) {
     const void* kn = k_new ? k_new[i] : nullptr;
     const void* vn = v_new ? v_new[i] : nullptr;
+    if (fold) {
+      const int rc = decode_attn_impl(name, q[i], q_sb, q_sh, k_store[i], k_st, k_scales[i], k_bits, v_store[i], v_st, v_scales[i], v_bits, kn,
+                                      kn_sb, kn_sh, vn, vn_sb, vn_sh, out[i], o_sb, o_sh, dtype, sm_scale, workspace, workspace_floats, d,
+                                      stream, nullptr, nullptr, 1);
+      if (rc) return rc;
+      continue;
+    }
     const int rc = append ? kvq_decode_step(q[i], q_sb, q_sh, kn, kn_sb, kn_sh, vn, vn_sb, vn_sh, k_store[i], k_st, k_scales[i], k_bits,
                                             v_store[i], v_st, v_scales[i], v_bits, out[i], o_sb, o_sh, dtype, sm_scale, eps,
                                             workspace, workspace_floats, d, stream)

@@ -266,9 +266,12 @@ int kvq_decode_step_layers(int64_t n_layers, int append, const void* const* q, i
 /* Measurement aid: the NEXT kernel launch of the calling thread — whichever entry point makes it — binds these two
  * hipEvent_t (already created; either may be NULL) to its own dispatch (hipExtLaunchKernelGGL): stop - start is then
  * the kernel's duration as a profiler sees it, without the queue gaps two hipEventRecord calls around the launch
- * include. One-shot (the launch takes them); kvq_time_next_launch(NULL, NULL) disarms a pair no launch took — a
- * caller whose call can fail before it reaches the library must do that (the Python binding does, in a finally). */
+ * include. One-shot (the launch takes them). A library call that returns an error disarms the pair (no later launch
+ * of the thread can take the events of a call that failed); kvq_time_next_launch(NULL, NULL) disarms a pair no launch
+ * took — a call that succeeds WITHOUT launching (empty dims) or fails before it reaches the library leaves it armed, so a
+ * careful caller still does that (the Python binding does, in a finally). kvq_timing_armed(): 1 while a pair is pending. */
 int kvq_time_next_launch(void* start_event, void* stop_event);
+int kvq_timing_armed(void);
 
 /* Measurement aid: which kernels ran. Every launch of the calling thread notes its kernel; kvq_kernel_log writes the
  * distinct kernels launched since kvq_kernel_log_clear(), in first-launch order, one demangled name per line (what
@@ -299,7 +302,8 @@ int64_t kvq_kernel_log(char* buf, int64_t n);
  *               "attn_stream_tc" (64|32), "attn_stream_slots", "attn_stream_roll", "attn_tg" (1 = one score output per
  *               16-token group in the LDS-staged kernel at <= 4 query heads per kv head too), "attn_k_i8" (-1|0|1; tolerance-level
  *               difference), "attn_fused" (one launch per call; refused while the stream is being captured into a
- *               HIP graph: its arrival epoch is a launch argument), "attn_fused_tc" / "attn_fused_nw".
+ *               HIP graph: its arrival epoch is a launch argument), "attn_fused_tc" / "attn_fused_nw", "attn_fold" (the merge
+ *               INSIDE the LDS-staged kernel's launch, by arrival ticket: 1 = in kvq_decode_step_layers, 2 = kvq_decode_attn too).
  * Returns 0, or KVQ_E_DIMS for an unknown key / an A-B key in the default library. Process-global. */
 int kvq_set_tunable(const char* key, int64_t value);
 int64_t kvq_get_tunable(const char* key);

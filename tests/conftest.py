@@ -20,16 +20,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "ab: variant-equality tests of kernels that lost a measurement; they need the A-B library "
                                        "(make -C efficient-llm-inference_amd/csrc ab) and run with `pytest -m ab` on the GPU box only")
-    if "ab" in (config.getoption("-m") or "").replace("(", " ").replace(")", " ").split() and not os.environ.get("KVQ_HIP_LIB"):
+    if _selects_ab(config) and not os.environ.get("KVQ_HIP_LIB"):
         # `pytest -m ab`: the A-B library is what gets loaded (before anything imports the package's _lib)
         os.environ["KVQ_HIP_LIB"] = os.path.join(ROOT, "efficient-llm-inference_amd", "lib", "ab", "libkvq_hip.so")
+
+
+def _selects_ab(config) -> bool:
+    """True when the -m expression POSITIVELY names the `ab` marker (`-m ab`, `-m "gpu and ab"`); `-m "not ab"` and
+    `-m "gpu and not ab"` do not: they keep the shipped library and deselect the ab tests like `-m gpu` does."""
+    words = (config.getoption("-m") or "").replace("(", " ").replace(")", " ").split()
+    return any(w == "ab" and (i == 0 or words[i - 1] != "not") for i, w in enumerate(words))
 
 
 def pytest_collection_modifyitems(config, items):
     """`ab` tests run only when the -m expression names them: `-m gpu` (the driver's run) and `-m "not gpu"` see the
     shipped library's tests only."""
-    words = (config.getoption("-m") or "").replace("(", " ").replace(")", " ").split()
-    if "ab" in words:
+    if _selects_ab(config):
         return
     keep, drop = [], []
     for it in items:

@@ -64,6 +64,22 @@ def test_argument_errors_before_any_launch(lib):
     assert rc == -2  # chunk_size must be > 0
 
 
+def test_a_failing_call_disarms_the_timing_pair(lib):
+    """kvq_time_next_launch arms two events for the thread's NEXT launch. A call that fails validation never launches: the
+    library disarms the pair itself, so no later launch — from any entry point — can be timed by mistake."""
+    from efficient_llm_inference_amd._lib import KvqDims, KvqStrides, byref
+    fake = ctypes.c_void_p(0x1000)  # never dereferenced: nothing launches in this test
+    assert lib.kvq_timing_armed() == 0
+    assert lib.kvq_time_next_launch(fake, fake) == 0 and lib.kvq_timing_armed() == 1
+    st, dm = KvqStrides(0, 0, 0, 0), KvqDims(1, 1, 1, 1, 8)
+    assert lib.kvq_dequant_i8_tokens(None, byref(st), None, 0, None, byref(st), 0, byref(dm), None) == -1
+    assert lib.kvq_timing_armed() == 0
+    # a call that succeeds without launching (empty input) leaves the pair armed; the caller's own disarm clears it
+    assert lib.kvq_time_next_launch(fake, None) == 0 and lib.kvq_timing_armed() == 1
+    assert lib.kvq_dequant_i8_f16_flat(None, 1.0, None, 0, None) == 0 and lib.kvq_timing_armed() == 1
+    assert lib.kvq_time_next_launch(None, None) == 0 and lib.kvq_timing_armed() == 0
+
+
 def test_chunk_summary_len_matches_reference_trajectory(lib):
     from efficient_llm_inference_amd.kernels import chunk_summary_len
     T, lens = 32768, []
@@ -98,7 +114,13 @@ def test_default_library_is_the_shipped_subset():
     if os.environ.get("KVQ_HIP_LIB"):
         pytest.skip("KVQ_HIP_LIB overrides the library")
     assert not _lib.is_ab_build()
-    assert os.path.getsize(_lib.LIB_PATH) < 2_000_000, os.path.getsize(_lib.LIB_PATH)
+    # the property itself, not a byte count pinned to today's build: an A-B key is refused, and where the A-B library is
+    # built next to it the default one is well under half its size
+    lib = _lib.load()
+    assert lib.kvq_set_tunable(b"dequant_variant", 3) == -2 and b"A-B key" in lib.kvq_last_error_string()
+    ab_path = os.path.join(os.path.dirname(_lib.LIB_PATH), "ab", "libkvq_hip.so")
+    if os.path.exists(ab_path):
+        assert 2 * os.path.getsize(_lib.LIB_PATH) < os.path.getsize(ab_path), (os.path.getsize(_lib.LIB_PATH), os.path.getsize(ab_path))
 
 
 def test_kernel_log_is_empty_without_launches(lib):

@@ -26,7 +26,20 @@ def test_cpu_baseline_leg():
     assert "2/4 layers" in cb["sample"]
     for leg in ("port", "vectorised", "literal"):  # the three CPU figures, each with cores + reps
         assert cb[leg]["value"] > 0 and cb[leg]["cores"] >= 1 and cb[leg]["reps"] >= 2, leg
-    assert cb["vectorised"]["cores"] == (os.cpu_count() or 1)
+    from oracle import hostcpu
+    usable = hostcpu.usable_cores()
+    assert 1 <= usable["usable"] <= usable["machine"] == (os.cpu_count() or 1) and usable["usable"] <= usable["affinity"]
+    assert cb["vectorised"]["cores"] == usable["usable"] == cb["host_cores_available"] and cb["host_cpu"]["usable"] == usable["usable"]
+    # the port on 1 core AND on every usable core; every entry `reps` repetitions; the torch entries say
+    # which pool size they were timed at; no median may sit on a scheduler quantum unnoticed
+    assert cb["port"]["cores"] == 1
+    if usable["usable"] > 1:
+        ac = cb["port"]["all_cores"]
+        assert ac["cores"] == usable["usable"] and ac["value"] > 0 and ac["quantise_value"] > 0 and ac["int8"]["dequantise_value"] > 0
+        assert f"over {usable['usable']} pthreads" in ac["sample"]
+    assert isinstance(cb["timer_quantum_suspects"], list) and cb["eviction"]["pool_reps"] == cb["eviction"]["reps"] == 2
+    assert set(cb["eviction"]["torch_threads"]) == {"window_torch", "pool_torch"} and cb["eviction"]["pool_port"]["cores_1"] > 0
+    assert all(v["used"] in (1, usable["usable"]) for v in cb["vectorised"]["torch_threads"].values())
     assert cb["eviction"]["pool_value"] > 0 and cb["eviction"]["window_value"] > 0 and cb["vectorised"]["int8"]["quantise_value"] > 0
     json.dumps(cb)
     # the per-op parity section: handed what a correct GPU run would hand it (here: the oracle's own outputs), every op

@@ -840,3 +840,72 @@ def test_streaming_kernel_rolling_requests_equal_whole_tile_requests(K, tunable,
                 assert torch.isfinite(out.float()).all()
                 outs.append(out)
             assert torch.equal(outs[0], outs[1]), (B, Hq, Hkv, T, D, kinds)
+
+
+@pytest.mark.ab
+@pytest.mark.parametrize("case", [(2, 32, 8, 1500, 3), (1, 8, 2, 1000, 1), (3, 6, 2, 449, 2), (1, 4, 1, 64, 1), (5, 32, 8, 1024, 1),
+                                  (8, 32, 8, 16384, 0), (2, 6, 2, 900, 2)])
+def test_merge_inside_the_partial_launch_equals_the_two_launch_path(K, tunable, case):
+    """attn_fold (round 4, A-B library: measured slower, profiles/r04b_*): the LDS-staged kernel's waves store their partials
+    write-through, take a ticket per (batch row, kv head), and the wave that draws the last ticket merges the head group itself
+    (merge_group_one_wave) — ONE launch per layer. attn_fold = 1: in kvq_decode_step_layers (one memset of the arrival words
+    per host call), 2: in kvq_decode_attn too (a memset per call). Same operands in the same order as the merge kernels: equal output BITS with attn_fold = 0
+    (two launches) — with and without the new token, fp16 and bf16, every kind pair, a workspace full of NaNs (the arrival words
+    need no initialisation by the caller), the same workspace reused by 5 layers and by repeated calls (the words end a launch at
+    zero), and more query heads than the merge takes (falls back to two launches)."""
+    B, Hq, Hkv, T, tpw = case
+    D, L = 128, 5
+    from efficient_llm_inference_amd import _lib
+    tunable("attn_stream_tpw", tpw)
+    g = torch.Generator(device="cuda").manual_seed(T + tpw)
+    for dtype, kinds in ((torch.float16, ("int8", "int4")), (torch.bfloat16, ("int8", "int4")), (torch.float16, ("int4", "int8")),
+                         (torch.float16, ("int8", "int8")), (torch.float16, ("int4", "int4"))):
+        if B * T > 50000 and (dtype != torch.float16 or kinds != ("int8", "int4")):
+            continue
+        kd, vd = (D if k == "int8" else D // 2 for k in kinds)
+        ks_ = torch.randint(0, 256, (L, B, Hkv, T + 4, kd), dtype=torch.uint8, device="cuda", generator=g).view(K.QDTYPE[kinds[0]])
+        vs_ = torch.randint(0, 256, (L, B, Hkv, T + 4, vd), dtype=torch.uint8, device="cuda", generator=g).view(K.QDTYPE[kinds[1]])
+        if kinds[0] == "int8":
+            ks_.clamp_(min=-127)
+        if kinds[1] == "int8":
+            vs_.clamp_(min=-127)
+        ksc = torch.rand(L, T + 4, device="cuda", generator=g) * 0.02 + 1e-3
+        vsc = torch.rand(L, T + 4, device="cuda", generator=g) * 0.2 + 1e-3
+        q = torch.randn(L, B, Hq, D, device="cuda", generator=g).to(dtype)
+        kn = torch.randn(L, B, Hkv, D, device="cuda", generator=g).to(dtype)
+        vn = torch.randn(L, B, Hkv, D, device="cuda", generator=g).to(dtype)
+        ws = torch.empty(K.decode_attn_workspace_cap(B, Hq, Hkv, T + 4, D), dtype=torch.float32, device="cuda")
+        res = {}
+        for fold in (0, 1, 2):
+            tunable("attn_fold", fold)
+            ws.fill_(float("nan"))  # all-ones exponent bit patterns in the arrival words too
+            out = torch.full((L, B, Hq, D), float("nan"), dtype=dtype, device="cuda")
+            plan = K.DecodeLayersPlan(q, kn, vn, out, ks_, ksc, kinds[0], vs_, vsc, kinds[1])
+            _lib.kernel_log_clear()
+            for _ in range(3):  # the words end every launch at zero: the next layer and the next call find them so
+                K.decode_step_layers(plan, T, ws, D ** -0.5)
+            torch.cuda.synchronize()
+            log = _lib.kernel_log()
+            assert log[0].startswith("decode_attn_lds_mfma_k<"), log
+            assert len(log) == (2 if fold == 0 or Hq // Hkv > 4 else 1), (fold, log)
+            assert torch.isfinite(out.float()).all()
+            # single-layer entry point, without a new token: folded only with attn_fold = 2
+            out1 = torch.full((B, Hq, D), float("nan"), dtype=dtype, device="cuda")
+            _lib.kernel_log_clear()
+            K.decode_attn(q[0], ks_[0], ksc[0], kinds[0], vs_[0], vsc[0], kinds[1], T, out1, ws, D ** -0.5)
+            torch.cuda.synchronize()
+            assert len(_lib.kernel_log()) == (1 if fold == 2 and Hq // Hkv <= 4 else 2), (fold, _lib.kernel_log())
+            res[fold] = (out, out1)
+        for fold in (1, 2):
+            assert torch.equal(res[fold][0].view(torch.int16), res[0][0].view(torch.int16)), (dtype, kinds, fold)
+            assert torch.equal(res[fold][1].view(torch.int16), res[0][1].view(torch.int16)), (dtype, kinds, fold, "no new token")
+
+
+@pytest.mark.ab
+def test_merge_inside_the_partial_launch_with_eight_query_heads_keeps_two_launches(K, tunable):
+    from efficient_llm_inference_amd import _lib
+    tunable("attn_stream_tpw", 2)
+    tunable("attn_fold", 2)
+    _lib.kernel_log_clear()
+    _run_case(K, 1, 16, 2, 700, 128, "int8", "int4", "f16", True)
+    assert len(_lib.kernel_log()) == 2

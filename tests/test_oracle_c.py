@@ -86,3 +86,21 @@ def test_vectorised_torch_equals_numpy_oracle(kind, shape, dtype):
     for od, td in (("f16", torch.float16), ("f32", torch.float32)):
         out = VT.dequantize_tokens(q, sc, kind, shape[-1], td)
         assert np.array_equal(out.numpy().view(np.uint8), O.dequantize_tokens(q_ref, s32, kind, shape[-1], od).view(np.uint8))
+
+
+@pytest.mark.parametrize("threads", [2, 3, 7])
+def test_c_oracle_threaded_entry_points_equal_the_scalar_ones(threads):
+    """the `_mt` entry points cut the same scalar loops into contiguous item ranges over pthreads (bench.py's all-core CPU
+    baseline): bit-identical to one thread, including ranges that do not divide evenly and more threads than items"""
+    rng = np.random.default_rng(11)
+    for shape in ((3, 2, 3, 17, 40), (1, 1, 1, 2, 8), (2, 1, 4, 5, 33)):
+        x = rng.standard_normal(shape, dtype=np.float32).astype(np.float16)
+        for kind in ("int8", "int4"):
+            q1, s1 = C.quantize_tokens(x, kind)
+            qn, sn = C.quantize_tokens(x, kind, threads=threads)
+            assert np.array_equal(q1, qn) and np.array_equal(s1.view(np.uint32), sn.view(np.uint32))
+            d1 = C.dequantize_tokens(q1, s1, kind, shape[-1], "f16")
+            dn = C.dequantize_tokens(q1, s1, kind, shape[-1], "f16", threads=threads)
+            assert np.array_equal(d1.view(np.uint16), dn.view(np.uint16))
+        for chunk, keep in ((4, 3), (64, 256), (5, 0)):
+            assert np.array_equal(C.chunk_summarize(x[0], chunk, keep).view(np.uint16), C.chunk_summarize(x[0], chunk, keep, threads=threads).view(np.uint16))
