@@ -65,6 +65,9 @@ DECODE_DEFAULT = ("gpt2", "quant_int8", 512, 512)  # arch, method, prompt tokens
 # BASELINE.json configs[4]: Llama-3-8B sliding_window + chunk_summary, seq 32K, batch 64 sharded
 # over 8 GPUs = 8 batch rows per GPU: per-rank KV [L=32, 2, B=8, H=8, T=32768, D=128] fp16 = 32 GiB
 EVICT = {"llama3_8b_evict_seq32k": (32, 8, 8, 32768, 128, 256, 64, 256)}  # L,B,H,T,D,window,chunk,keep_last
+# scope row N3 at the same per-GPU share: the index-select policies (one row-gather launch over the 64-tensor tuple each, the
+# reference's benchmark_method defaults: benchmarker.py:643-660) and PagedKVCache.get_kv of one layer; runs on EVICT's tensors
+SPARSE = {"llama3_8b_sparse_seq32k": ("llama3_8b_evict_seq32k", dict(window_size=256, block_size=64, prefix_len=32, stride=4, keep_per_block=8, old_budget=64))}
 # SURVEY §8e's one exchange step: ONE batched [B=64,H,T,D] slice per layer whose batch rows are split over the ranks
 # (strong scaling: the global batch is fixed): abs-max of the local rows -> all_reduce(MAX) of the [G,T] table ->
 # quantise with the whole batch's scales. T = 1 is a decode step's append, T = 512 a prefill chunk.
@@ -92,7 +95,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="llama3_8b_mixed_seq16k",
                     help="one of %s, or decode:<arch>:<method>[:<prompt_tokens>:<new_tokens>] "
-                         "(e.g. decode:gpt2:quant_int8:512:512; steps = prompts per rank), or shape:<%s>" % (sorted(list(WORKLOADS) + list(ATTN) + list(EVICT) + list(SHARDQ)), "|".join(SHAPE_RECORDS)))
+                         "(e.g. decode:gpt2:quant_int8:512:512; steps = prompts per rank), or shape:<%s>" % (sorted(list(WORKLOADS) + list(ATTN) + list(EVICT) + list(SPARSE) + list(SHARDQ)), "|".join(SHAPE_RECORDS)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subrecords", action="store_true",
                     help="headline workload only: skip the decode / configs / sharded_quant sub-records of the default line "
@@ -230,10 +233,14 @@ def cpu_baseline(L, B, H, T, D, sample_layers, reps=5, gpu_check=None):
     thr0 = hostcpu.throttle_counters()
     rng = np.random.default_rng(42)
     gbps = lambda n, dt, kind="int4": round(n * BYTES_PER_ELT[kind] / dt / 1e9, 5)  # noqa: E731
-    medians = {}  # entry -> median seconds, for the timer-quantum check
+    medians = {}    # entry -> median seconds, for the timer-quantum check
+    throttled = {}  # entry -> CFS periods in which this cgroup was throttled while the entry was being timed (None: unreadable)
 
     def med(name, fn):
+        t0 = hostcpu.throttle_counters()
         medians[name] = _median_time(fn, reps)
+        t1 = hostcpu.throttle_counters()
+        throttled[name] = None if t0 is None or t1 is None else t1[1] - t0[1]
         return medians[name]
 
     torch_threads = {}  # entry -> {"used": n, "probe_ms": {threads: one timed call}}
@@ -371,9 +378,13 @@ def cpu_baseline(L, B, H, T, D, sample_layers, reps=5, gpu_check=None):
     thr1 = hostcpu.throttle_counters()
     hc["throttle_counters_before_after"] = [thr0, thr1]
     hc["nr_throttled_during_baseline"] = None if thr0 is None or thr1 is None else thr1[1] - thr0[1]
-    # a median that lands on a multiple of the 100 ms CFS period is a scheduler quantum, not a rate
-    suspects = [f"{k}: {v * 1e3:.2f} ms" for k, v in medians.items()
-                if v >= 0.095 and abs(v * 10 - round(v * 10)) <= 0.01 * round(v * 10)]
+    # A median that lands on a multiple of the 100 ms CFS period WHILE the cgroup was being throttled is a scheduler quantum,
+    # not a rate (round 3's 100.0 / 999.3 ms). A median that merely happens to be near one (a 99 ms quantise of 33 M elements)
+    # with no throttled period during its timing is listed separately, with that evidence.
+    near = {k: v for k, v in medians.items() if v >= 0.095 and abs(v * 10 - round(v * 10)) <= 0.01 * round(v * 10)}
+    suspects = [f"{k}: {v * 1e3:.2f} ms, {throttled[k]} throttled periods while timed" for k, v in near.items() if throttled.get(k) is None or throttled[k] > 0]
+    hc["near_100ms_multiples_without_throttling"] = [f"{k}: {v * 1e3:.2f} ms" for k, v in near.items() if throttled.get(k) == 0]
+    hc["entries_timed_while_throttled"] = {k: n for k, n in throttled.items() if n}
     out = {"value": port["value"], "unit": "GB/s", "cores": 1, "kind": "port", "sample": port["sample"], "reps": reps,
            "host_cores_available": cores, "host_cpu": hc, "timer_quantum_suspects": suspects,
            "port": port, "vectorised": vect, "literal": lit, "eviction": evict}
@@ -463,9 +474,64 @@ def run_decode(args, rank, world, dev):
 
 # --------------------------------------------------------------------------------------------- eviction (configs[4])
 
-def measure_evict(name, dev, rank, world, steps, warmup):
+def _measure_sparse(E, _lib, past, shape, pol, dev, iters=6):
+    """Scope row N3 on tensors that are already resident: every index-select policy of the reference (implementations.py:143-292)
+    through its public function = ONE row-gather launch over the whole tuple (+ the output allocation and the index upload),
+    and PagedKVCache.get_kv (implementations.py:82-106) of one layer's cache. Algorithmic bytes: 4 per kept element (2 read +
+    2 written); each launch timed by HIP events bound to its own dispatch."""
+    from efficient_llm_inference_amd import cache as C
+    from efficient_llm_inference_amd.cache import PagedKVCache
+    L, B, H, T, D = shape
+    W, P = pol["window_size"], pol["prefix_len"]
+    calls = {
+        "trim_kv_strided": lambda: C.trim_kv_strided(past, window_size=W, stride=pol["stride"], prefix_len=P),
+        "trim_kv_block_old": lambda: C.trim_kv_block_old(past, window_size=W, block_size=pol["block_size"], keep_per_block=pol["keep_per_block"], prefix_len=P),
+        "trim_kv_budget_old": lambda: C.trim_kv_budget_old(past, window_size=W, old_budget=pol["old_budget"], prefix_len=P),
+        "trim_kv_prefix_window": lambda: C.trim_kv_prefix_window(past, prefix_len=P, window_size=W),
+    }
+    rec = {"shape_per_rank_L2BHTD": [L, 2, B, H, T, D], "policy_arguments": pol,
+           "what": "each policy = its public function over the 64-tensor tuple: ONE kvq_gather_tokens launch; bytes = 4 per kept element"}
+    for name, fn in calls.items():
+        out = fn()
+        kept = out[0][0].size(2)
+        del out
+        kern = _kernels_of(lambda: fn())
+        ms = _time_launches(lambda i: fn(), iters, warm=1)
+        rec[name] = _roofline(kern, 4.0 * 2 * L * B * H * kept * D, ms, _DISPATCH_TIMER, kept_tokens=kept, of_tokens=T)
+        _free()
+    pc = PagedKVCache(block_size=pol["block_size"], device="cuda", dtype=torch.float16)
+    pc.extend(past[0][0], past[0][1])  # one layer's K and V: T / block_size blocks each
+    kern = _kernels_of(lambda: pc.get_kv())
+    # get_kv makes one launch per pool (K, then V): the events bind to the K launch; both move the same bytes
+    ms = _time_launches(lambda i: pc.get_kv(), iters, warm=1)
+    # a pool's stitch is ceil(blocks / 128) launches (128 block pointers travel in one launch's arguments): the events bind to
+    # the FIRST, which moves min(blocks, 128) blocks; the whole call (2 allocations + every launch of both pools) by wall events
+    first = min(pc.num_blocks(), 128)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    pc.get_kv()
+    ev[0].record()
+    for _ in range(iters):
+        pc.get_kv()
+    ev[1].record()
+    torch.cuda.synchronize()
+    call_ms = ev[0].elapsed_time(ev[1]) / iters
+    rec["paged_get_kv"] = _roofline(kern, 4.0 * first * B * H * pol["block_size"] * D, ms, _DISPATCH_TIMER, blocks=pc.num_blocks(), block_size=pol["block_size"],
+                                    blocks_in_the_timed_launch=first, launches_per_call=2 * -(-pc.num_blocks() // 128),
+                                    whole_call={"ms": round(call_ms, 4), "GBps": round(2 * 4.0 * B * H * T * D / (call_ms * 1e-3) / 1e9, 1),
+                                                "what": "PagedKVCache.get_kv(): two output allocations + every stitch launch of the K and V pools, HIP events around the call"},
+                                    what="PagedKVCache.get_kv of ONE layer: the first stitch launch of the K pool (128 blocks)")
+    del pc
+    _free()
+    worst = min((v["frac"], k) for k, v in rec.items() if isinstance(v, dict) and "frac" in v and v.get("algorithmic_bytes_per_launch", 0) > 1e9)
+    rec["roofline"] = rec["trim_kv_strided"]  # the policy that moves the most bytes (a quarter of the old tokens)
+    rec["lowest_fraction_above_1GB"] = {"op": worst[1], "frac": worst[0]}
+    return rec
+
+
+def measure_evict(name, dev, rank, world, steps, warmup, with_sparse=None):
     """configs[4] per-rank slice: one STEP = trim_kv_sliding_window + chunk_summarize_kv over the
-    whole legacy tuple (64 tensors of [8,8,32768,128] fp16): two launches, inputs resident."""
+    whole legacy tuple (64 tensors of [8,8,32768,128] fp16): two launches, inputs resident.
+    with_sparse: policy arguments -> also the N3 record on the same tensors (rec["sparse"])."""
     import efficient_llm_inference_amd as E
     from efficient_llm_inference_amd import _lib, sharding
     from efficient_llm_inference_amd.kernels import chunk_summary_len
@@ -523,9 +589,34 @@ def measure_evict(name, dev, rank, world, steps, warmup):
                               traffic=_traffic(name, "chunk_pool")),
         "roofline_window": _roofline(k_win, bytes_win, w_ms, _DISPATCH_TIMER, what="trim_kv_sliding_window, materialised"),
     }
+    if with_sparse is not None:
+        try:
+            rec["sparse"] = _measure_sparse(E, _lib, past, (L, B, H, T, D), with_sparse, dev)
+        except Exception as exc:  # noqa: BLE001 — a sub-record never costs the record it rides on
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            rec["sparse"] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
     del past
     _free()
     return rec
+
+
+def run_sparse(args, rank, world, dev):
+    """--workload llama3_8b_sparse_seq32k: the N3 record alone (same tensors as the eviction workload)"""
+    base, pol = SPARSE[args.workload]
+    rec = measure_evict(base, dev, rank, world, 2, 1, with_sparse=pol)["sparse"]
+    if rank == 0:
+        r = rec["roofline"]
+        print(json.dumps({
+            "metric": "index-select eviction policies + paged stitch, GB/s vs HBM roofline (row gather, 4 B per kept element)",
+            "value": r["achieved"], "unit": "GB/s", "n_gpus": world, "steps": r["launches_timed"], "warmup": 1,
+            "ms_per_step": r["avg_launch_ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16",
+            "dtype_detail": "fp16 rows moved as bytes", "data": "synthetic",
+            "config": {"workload": args.workload, "shape_per_rank_L2BHTD": rec["shape_per_rank_L2BHTD"], "policy_arguments": rec["policy_arguments"],
+                       "step": "trim_kv_strided over the 64-tensor tuple (one launch); the other policies and PagedKVCache.get_kv beside it",
+                       "parallelism": f"batch-shard x{world}, no collective"},
+            "roofline": r, **{k: v for k, v in rec.items() if k not in ("roofline", "shape_per_rank_L2BHTD", "policy_arguments")},
+        }), flush=True)
 
 
 def run_evict(args, rank, world, dev):
@@ -899,6 +990,8 @@ def main():
             run_attn(args, rank, world, dev)
         elif args.workload in EVICT:
             run_evict(args, rank, world, dev)
+        elif args.workload in SPARSE:
+            run_sparse(args, rank, world, dev)
         elif args.workload in SHARDQ:
             run_sharded_quant(args, rank, world, dev)
         elif args.workload.startswith("shape:") and args.workload[6:] in SHAPE_RECORDS:  # one sub-record on its own (profiling)
@@ -1046,8 +1139,7 @@ def run_dequant(args, rank, world, dev, backend):
         kern = _kernels_of(lambda: qfn(0))
         ms = _time_launches(qfn, 12)
         quant_info[f"quant_{stores[0].kind}"] = _roofline(kern, n_elts * BYTES_PER_ELT[stores[0].kind], ms, _DISPATCH_TIMER, set=name.upper(),
-                                                          input="the legacy tuple: 32 contiguous [B,H,T,D] tensors, N(0,1); head rows T*D*2 B apart (4 MiB at T = 16384)",
-                                                          **_quant_variants(tensors, stores[0].kind, n_elts, dev))
+                                                          input="the legacy tuple: 32 contiguous [B,H,T,D] tensors, N(0,1); head rows T*D*2 B apart (4 MiB at T = 16384)")
 
     k_kernel = _kernels_of(lambda: caches[0]._k.dequant(torch.float16, out=outs[0][0]))
     v_kernel = _kernels_of(lambda: caches[0]._v.dequant(torch.float16, out=outs[0][1]))
@@ -1104,6 +1196,10 @@ def run_dequant(args, rank, world, dev, backend):
     torch.cuda.synchronize()
     pub_ms = (time.perf_counter() - tp0) / n_pub * 1e3
     del pkv
+    # ... and the quantise launch on two more inputs (padded head rows, outlier channels): scratch stores, freed before the sub-records
+    for name, tensors in (("k", [k for k, _ in past]), ("v", [v for _, v in past])):
+        kind = getattr(caches[0], "_" + name).kind
+        quant_info[f"quant_{kind}"].update(_quant_variants(tensors, kind, n_elts, dev))
     mark("extended_samples_and_public_api")
 
     gpu_check = None
@@ -1180,7 +1276,10 @@ def run_dequant(args, rank, world, dev, backend):
             cfgs = {}
             for name in SHAPE_RECORDS:
                 cfgs[name] = _subrecord(measure_shape, name, dev, rank)
-            cfgs["llama3_8b_evict_seq32k"] = _subrecord(measure_evict, "llama3_8b_evict_seq32k", dev, rank, 1, 6, 2)
+            cfgs["llama3_8b_evict_seq32k"] = _subrecord(measure_evict, "llama3_8b_evict_seq32k", dev, rank, 1, 6, 2,
+                                                        with_sparse=SPARSE["llama3_8b_sparse_seq32k"][1])
+            if isinstance(cfgs["llama3_8b_evict_seq32k"], dict) and "sparse" in cfgs["llama3_8b_evict_seq32k"]:
+                cfgs["llama3_8b_sparse_seq32k"] = cfgs["llama3_8b_evict_seq32k"].pop("sparse")  # scope row N3, same tensors
         shq = None
         if world == 1:
             # one rank: the batch-64 prefill slice of the sharded workload, single pass beside the two phases (no collective)

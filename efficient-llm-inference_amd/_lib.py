@@ -185,6 +185,28 @@ def current_stream(device) -> c_void_p:
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+class device_guard:
+    """``with device_guard(dev):`` — ``dev`` is the thread's current HIP device inside the block (restored after). A no-op
+    when it already is: one ``torch.cuda.current_device()`` per launch."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device):
+        device = torch.device(device)
+        self.idx = device.index if device.index is not None else torch.cuda.current_device()
+        self.prev = self.idx
+
+    def __enter__(self):
+        self.prev = torch.cuda.current_device()
+        if self.prev != self.idx:
+            torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev != self.idx:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
 def require_gpu(t: torch.Tensor, name: str) -> None:
     if not t.is_cuda:
         raise KvqError(

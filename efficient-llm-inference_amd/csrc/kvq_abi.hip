@@ -32,6 +32,30 @@ int check_launch(const char* what) {
   return 0;
 }
 
+// Device guard: the library launches on the calling thread's CURRENT device; a buffer that lives on
+// another device of the same process (a single-process multi-GPU caller) must be refused, not dereferenced by
+// the wrong GPU. One hipPointerGetAttributes per entry point on the buffer the call writes. A pointer the runtime does not
+// know (a host test's fake address, no device at all) is left to the later checks / the launch.
+int check_device(const void* p, const char* name) {
+  if (!p) return 0;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  if (at.type == hipMemoryTypeDevice && at.device != cur) {
+    set_error("%s: the output buffer lives on device %d but the calling thread's current device is %d (hipSetDevice / "
+              "torch.cuda.device(...) before the call; the stream argument must belong to that device too)", name, at.device, cur);
+    return KVQ_E_DEVICE;
+  }
+  return 0;
+}
+
 TimingEvents take_timing_events() {
   const TimingEvents e = g_timing;
   g_timing = TimingEvents{nullptr, nullptr};
@@ -54,6 +78,7 @@ Tunables& tunables() {
     d.dequant_variant = -1;
     d.pool_block = 64;
     d.pool_wave = 1;
+    d.gather_rows = 1;
     d.quant_block = 64;
     d.quant_nv = 8;
     d.attn_mfma_min_nq = 3;
@@ -87,6 +112,7 @@ static const TunableKey kTunableKeys[] = {
     {"quant_wide", &Tunables::quant_wide, false},
     {"quant_block", &Tunables::quant_block, false},
     {"pool_wave", &Tunables::pool_wave, false},
+    {"gather_rows", &Tunables::gather_rows, false},
     {"attn_force_valu", &Tunables::attn_force_valu, false},
     {"attn_stream_tpw", &Tunables::attn_stream_tpw, false},
     {"attn_lds", &Tunables::attn_lds, false},

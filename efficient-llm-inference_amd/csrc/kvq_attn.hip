@@ -3017,6 +3017,7 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
     set_error("%s: NULL q / out / dims", name);
     return KVQ_E_NULL;
   }
+  if (const int rcd = check_device(out, name)) return rcd;
   if (d->B <= 0 || d->Hq <= 0 || d->Hkv <= 0 || d->T < 0 || d->B >= (1 << 16) || d->Hkv >= (1 << 16) ||
       d->T >= (int64_t(1) << 31) || d->Hq % d->Hkv != 0 || d->Hq / d->Hkv > (use_mfma(d) ? 16 : 8)) {
     set_error("%s: bad dims B=%lld Hq=%lld Hkv=%lld T=%lld (need Hq %% Hkv == 0, Hq / Hkv <= 8, or <= 16 at head_dim 64 / 128)", name, (long long)d->B,

@@ -33,6 +33,7 @@ struct PtrTable {
 // ------------------------------------------------------------------ error reporting (host)
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+int check_device(const void* p, const char* name);  // 0, or KVQ_E_DEVICE when `p` lives on another device than the thread's current one
 
 // kvq_time_next_launch: HIP events the NEXT kernel launch of the calling thread binds to its own dispatch
 // (hipExtLaunchKernelGGL start / stop timestamps): the kernel's duration without queue gaps. Taken (and cleared) by
@@ -72,6 +73,7 @@ struct Tunables {
   int64_t quant_block;           // general fused quantise kernel: 64 (default, one wave per tile) or 256 threads; 128 in A-B builds (measured: 241 / 261 / 270 us)
   int64_t quant_wide;            // 1 (default) = single-pass 1024-thread register tile for batched slices of 16384 < B*H*D <= 131072 elements; 0 = split phases / swept tile
   int64_t quant_tile;            // 1 (default) = compile-time-geometry one-wave tile kernel where the shape has one; 0 = general kernels
+  int64_t gather_rows;           // token gather: 1 (default) = 4 KiB work items, one 16-byte piece per thread (gather_rows_k); 0 = the grid-stride kernel (same bytes)
   int64_t pool_wave;             // chunk mean-pool: one wave per output row when the shape allows (1, default) or the per-lane-group walk (0)
   int64_t attn_force_valu;       // 1 = decode attention never takes an MFMA kernel
   int64_t attn_stream_tpw;       // streaming MFMA kernel: 64-token tiles per wave; 0 = by size (only when tiles exceed wave slots), -1 = never

@@ -359,6 +359,7 @@ static int dequant_tokens(const uint8_t* q, const kvq_strides_t* q_st, const flo
     set_error("%s: NULL argument", name);
     return KVQ_E_NULL;
   }
+  if (const int rcd = check_device(out, name)) return rcd;
   if (d->G < 0 || d->B < 0 || d->H < 0 || d->T < 0 || d->D < 0) {
     set_error("%s: negative dim", name);
     return KVQ_E_DIMS;
@@ -473,6 +474,7 @@ int kvq_dequant_i8_f16_flat(const int8_t* q, float scale, void* out_f16, int64_t
     set_error("kvq_dequant_i8_f16_flat: NULL argument");
     return KVQ_E_NULL;
   }
+  if (const int rcd = check_device(out_f16, "kvq_dequant_i8_f16_flat")) return rcd;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (n % 8 == 0 && aligned(q, 8) && aligned(out_f16, 16)) {
     const int64_t ng = n / 8;
@@ -501,6 +503,7 @@ int kvq_dequant_i4_f16_flat(const uint8_t* packed, float scale, void* out_f16, i
     set_error("kvq_dequant_i4_f16_flat: NULL argument");
     return KVQ_E_NULL;
   }
+  if (const int rcd = check_device(out_f16, "kvq_dequant_i4_f16_flat")) return rcd;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t total_last = packed_last * 2;
   if (orig_last_dim >= total_last && n_packed % 4 == 0 && aligned(packed, 4) && aligned(out_f16, 16)) {

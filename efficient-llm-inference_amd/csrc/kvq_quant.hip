@@ -1130,6 +1130,7 @@ static int quant_tokens(const void* in_base, const void* const* in_ptrs, const k
     set_error("%s: NULL argument", name);
     return KVQ_E_NULL;
   }
+  if (const int rcd = check_device(q, name)) return rcd;
   if (in_base && in_ptrs) {
     set_error("%s: pass in_base or in_ptrs, not both", name);
     return KVQ_E_DIMS;
@@ -1445,6 +1446,7 @@ static int split_phase(const char* name, int bits, const void* in_base, const vo
     set_error("%s: NULL argument", name);
     return KVQ_E_NULL;
   }
+  if (const int rcd = check_device(absmax, name)) return rcd;
   if (in_base && in_ptrs) {
     set_error("%s: pass in_base or in_ptrs, not both", name);
     return KVQ_E_DIMS;

@@ -18,6 +18,14 @@ import torch
 from . import _lib
 from ._lib import KvqStrides, byref, c_void_p, check, dims5, dtype_code, require_gpu, strides4
 
+def _launch(dev, fn, *args):
+    """``fn(*args, stream)`` on ``dev``'s current torch stream with ``dev`` made the calling thread's current device for
+    the call: the library launches on the CURRENT device (and refuses a buffer that lives elsewhere: KVQ_E_DEVICE), so a
+    single-process multi-GPU caller may hand over tensors of any device."""
+    with _lib.device_guard(dev):
+        return fn(*args, _lib.current_stream(dev))
+
+
 KIND_BITS = {"int8": 8, "int4": 4}
 QDTYPE = {"int8": torch.int8, "int4": torch.uint8}
 
@@ -86,9 +94,9 @@ def quant_tokens(x: TensorOrList, q: torch.Tensor, scales: torch.Tensor, absmax_
         return
     lib = _lib.load()
     fn = lib.kvq_quant_i8_tokens if bits == 8 else lib.kvq_quant_i4_tokens
-    rc = fn(base, arr, byref(ist), dtype_code(dt), c_void_p(q.data_ptr()), byref(strides4(q)),
+    rc = _launch(dev, fn, base, arr, byref(ist), dtype_code(dt), c_void_p(q.data_ptr()), byref(strides4(q)),
             c_void_p(scales.data_ptr()), scales.stride(0), c_void_p(absmax_ws.data_ptr()), float(eps),
-            byref(dims5(G, B, H, T, D)), _lib.current_stream(dev))
+            byref(dims5(G, B, H, T, D)))
     check(rc, f"quant_tokens[{kind}]")
 
 
@@ -109,7 +117,7 @@ def absmax_tokens(x: TensorOrList, out: torch.Tensor = None, accumulate: bool = 
         raise _lib.KvqError(f"kvq: absmax table must be contiguous fp32 {(G, T)}")
     lib = _lib.load()
     fn = lib.kvq_absmax_tokens_acc if accumulate else lib.kvq_absmax_tokens
-    check(fn(base, arr, byref(ist), dtype_code(dt), c_void_p(out.data_ptr()), byref(dims5(G, B, H, T, D)), _lib.current_stream(dev)),
+    check(_launch(dev, fn, base, arr, byref(ist), dtype_code(dt), c_void_p(out.data_ptr()), byref(dims5(G, B, H, T, D))),
           "absmax_tokens")
     return out
 
@@ -136,10 +144,10 @@ def quant_tokens_with_absmax(x: TensorOrList, absmax: torch.Tensor, kind: str, e
     if tuple(absmax.shape) != (G, T) or absmax.dtype != torch.float32 or not absmax.is_contiguous():
         raise _lib.KvqError(f"kvq: absmax table must be contiguous fp32 {(G, T)}")
     if G * B * H * T * D:
-        check(_lib.load().kvq_quant_tokens_from_absmax(
+        check(_launch(dev, _lib.load().kvq_quant_tokens_from_absmax, 
             bits, base, arr, byref(ist), dtype_code(dt), c_void_p(q.data_ptr()), byref(strides4(q)),
             c_void_p(scales.data_ptr()), scales.stride(0), c_void_p(absmax.data_ptr()), float(eps),
-            byref(dims5(G, B, H, T, D)), _lib.current_stream(dev)), f"quant_tokens_with_absmax[{kind}]")
+            byref(dims5(G, B, H, T, D))), f"quant_tokens_with_absmax[{kind}]")
     return q, scales
 
 
@@ -165,9 +173,9 @@ def dequant_tokens(q: torch.Tensor, scales: torch.Tensor, out: torch.Tensor, kin
     if G * B * H * T * D == 0:
         return
     fn = lib.kvq_dequant_i8_tokens if bits == 8 else lib.kvq_dequant_i4_tokens
-    rc = fn(c_void_p(q.data_ptr()), byref(strides4(q)), c_void_p(scales.data_ptr()), scales.stride(0),
+    rc = _launch(out.device, fn, c_void_p(q.data_ptr()), byref(strides4(q)), c_void_p(scales.data_ptr()), scales.stride(0),
             c_void_p(out.data_ptr()), byref(strides4(out)), dtype_code(out.dtype),
-            byref(dims5(G, B, H, T, D)), _lib.current_stream(out.device))
+            byref(dims5(G, B, H, T, D)))
     check(rc, f"dequant_tokens[{kind}]")
 
 
@@ -180,8 +188,8 @@ def dequant_i8_flat(q: torch.Tensor, scale: float) -> torch.Tensor:
     if not q.is_contiguous():
         raise _lib.KvqError("q must be contiguous")
     out = torch.empty(q.shape, dtype=torch.float16, device=q.device)
-    rc = _lib.load().kvq_dequant_i8_f16_flat(c_void_p(q.data_ptr()), float(scale), c_void_p(out.data_ptr()),
-                                             q.numel(), _lib.current_stream(q.device))
+    rc = _launch(q.device, _lib.load().kvq_dequant_i8_f16_flat, c_void_p(q.data_ptr()), float(scale), c_void_p(out.data_ptr()),
+                                             q.numel())
     check(rc, "dequant_i8_flat")
     return out
 
@@ -200,9 +208,8 @@ def dequant_i4_flat(packed: torch.Tensor, scale: float, orig_last_dim: int) -> t
     packed_last = sizes[-1]
     sizes[-1] = packed_last * 2
     out = torch.empty(sizes, dtype=torch.float16, device=packed.device)
-    rc = _lib.load().kvq_dequant_i4_f16_flat(c_void_p(packed.data_ptr()), float(scale), c_void_p(out.data_ptr()),
-                                             packed.numel(), packed_last, int(orig_last_dim),
-                                             _lib.current_stream(packed.device))
+    rc = _launch(packed.device, _lib.load().kvq_dequant_i4_f16_flat, c_void_p(packed.data_ptr()), float(scale), c_void_p(out.data_ptr()),
+                                             packed.numel(), packed_last, int(orig_last_dim))
     check(rc, "dequant_i4_flat")
     return out
 
@@ -219,9 +226,8 @@ def window_compact(x: TensorOrList, out: torch.Tensor, window: int) -> None:
         raise _lib.KvqError(f"kvq: unsupported element size {dt.itemsize}")
     if G * B * H * W * D == 0:
         return
-    rc = _lib.load().kvq_window_compact(base, arr, byref(ist), c_void_p(out.data_ptr()), byref(strides4(out)),
-                                        dt.itemsize, int(window), byref(dims5(G, B, H, T, D)),
-                                        _lib.current_stream(dev))
+    rc = _launch(dev, _lib.load().kvq_window_compact, base, arr, byref(ist), c_void_p(out.data_ptr()), byref(strides4(out)),
+                                        dt.itemsize, int(window), byref(dims5(G, B, H, T, D)))
     check(rc, "window_compact")
 
 
@@ -247,9 +253,9 @@ def chunk_meanpool(x: TensorOrList, out: torch.Tensor, chunk_size: int, keep_las
         raise _lib.KvqError(f"kvq: out must be {(G, B, H, Tout, D)} {dt}, got {tuple(out.shape)} {out.dtype}")
     if G * B * H * T * D == 0:
         return
-    rc = _lib.load().kvq_chunk_meanpool(base, arr, byref(ist), c_void_p(out.data_ptr()), byref(strides4(out)),
+    rc = _launch(dev, _lib.load().kvq_chunk_meanpool, base, arr, byref(ist), c_void_p(out.data_ptr()), byref(strides4(out)),
                                         dtype_code(dt), int(chunk_size), int(keep_last),
-                                        byref(dims5(G, B, H, T, D)), _lib.current_stream(dev))
+                                        byref(dims5(G, B, H, T, D)))
     check(rc, "chunk_meanpool")
 
 
@@ -269,9 +275,8 @@ def gather_tokens(x: TensorOrList, out: torch.Tensor, idx: torch.Tensor) -> None
         raise _lib.KvqError(f"kvq: unsupported element size {dt.itemsize}")
     if G * B * H * n * D == 0:
         return
-    rc = _lib.load().kvq_gather_tokens(base, arr, byref(ist), c_void_p(out.data_ptr()), byref(strides4(out)),
-                                       dt.itemsize, c_void_p(idx.data_ptr()), n, byref(dims5(G, B, H, T, D)),
-                                       _lib.current_stream(dev))
+    rc = _launch(dev, _lib.load().kvq_gather_tokens, base, arr, byref(ist), c_void_p(out.data_ptr()), byref(strides4(out)),
+                                       dt.itemsize, c_void_p(idx.data_ptr()), n, byref(dims5(G, B, H, T, D)))
     check(rc, "gather_tokens")
 
 
@@ -343,13 +348,13 @@ def decode_attn(q: torch.Tensor, k_store: torch.Tensor, k_scales: torch.Tensor, 
     kst = KvqStrides(0, k_store.stride(0), k_store.stride(1), k_store.stride(2))  # 1-byte elements: bytes
     vst = KvqStrides(0, v_store.stride(0), v_store.stride(1), v_store.stride(2))
     dims = _lib.KvqAttnDims(B, Hq, Hkv, T, D)
-    check(_lib.load().kvq_decode_attn(
+    check(_launch(q.device, _lib.load().kvq_decode_attn, 
         c_void_p(q.data_ptr()), q.stride(0), q.stride(1),
         c_void_p(k_store.data_ptr()), byref(kst), c_void_p(k_scales.data_ptr()), KIND_BITS[k_kind],
         c_void_p(v_store.data_ptr()), byref(vst), c_void_p(v_scales.data_ptr()), KIND_BITS[v_kind],
         kn[0], kn[1], kn[2], vn[0], vn[1], vn[2],
         c_void_p(out.data_ptr()), out.stride(0), out.stride(1), dtype_code(q.dtype), float(sm_scale),
-        c_void_p(workspace.data_ptr()), workspace.numel(), byref(dims), _lib.current_stream(q.device)), "decode_attn")
+        c_void_p(workspace.data_ptr()), workspace.numel(), byref(dims)), "decode_attn")
 
 
 class DecodeStepPlan:
@@ -404,13 +409,13 @@ def decode_step(plan: DecodeStepPlan, q: torch.Tensor, k_new: torch.Tensor, v_ne
             or k_new.dtype != q.dtype or v_new.dtype != q.dtype or out.dtype != q.dtype):
         raise _lib.KvqError("kvq: decode_step tensors do not match the plan (shape / dtype / device / contiguity)")
     dims = _lib.KvqAttnDims(plan.B, plan.Hq, plan.Hkv, T, plan.D)
-    check(_lib.load().kvq_decode_step(
+    check(_launch(q.device, _lib.load().kvq_decode_step, 
         c_void_p(q.data_ptr()), q.stride(0), q.stride(1),
         c_void_p(k_new.data_ptr()), k_new.stride(0), k_new.stride(1),
         c_void_p(v_new.data_ptr()), v_new.stride(0), v_new.stride(1),
         plan.k_ptr, byref(plan.kst), plan.ks_ptr, plan.kbits, plan.v_ptr, byref(plan.vst), plan.vs_ptr, plan.vbits,
         c_void_p(out.data_ptr()), out.stride(0), out.stride(1), plan.dtype_code, float(sm_scale), plan.eps,
-        c_void_p(workspace.data_ptr()), workspace.numel(), byref(dims), _lib.current_stream(q.device)), "decode_step")
+        c_void_p(workspace.data_ptr()), workspace.numel(), byref(dims)), "decode_step")
 
 
 def decode_step_dev(plan: DecodeStepPlan, q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, t_dev: torch.Tensor,
@@ -432,14 +437,13 @@ def decode_step_dev(plan: DecodeStepPlan, q: torch.Tensor, k_new: torch.Tensor, 
             or k_new.dtype != q.dtype or v_new.dtype != q.dtype or out.dtype != q.dtype):
         raise _lib.KvqError("kvq: decode_step_dev tensors do not match the plan (shape / dtype / device / contiguity)")
     dims = _lib.KvqAttnDims(plan.B, plan.Hq, plan.Hkv, t_bound, plan.D)
-    check(_lib.load().kvq_decode_step_dev(
+    check(_launch(q.device, _lib.load().kvq_decode_step_dev, 
         c_void_p(q.data_ptr()), q.stride(0), q.stride(1),
         c_void_p(k_new.data_ptr()), k_new.stride(0), k_new.stride(1),
         c_void_p(v_new.data_ptr()), v_new.stride(0), v_new.stride(1),
         plan.k_ptr, byref(plan.kst), plan.ks_ptr, plan.kbits, plan.v_ptr, byref(plan.vst), plan.vs_ptr, plan.vbits,
         c_void_p(out.data_ptr()), out.stride(0), out.stride(1), plan.dtype_code, float(sm_scale), plan.eps,
-        c_void_p(workspace.data_ptr()), workspace.numel(), byref(dims), c_void_p(t_dev.data_ptr()),
-        _lib.current_stream(q.device)), "decode_step_dev")
+        c_void_p(workspace.data_ptr()), workspace.numel(), byref(dims), c_void_p(t_dev.data_ptr())), "decode_step_dev")
 
 
 class DecodeLayersPlan:
@@ -513,8 +517,8 @@ def decode_step_layers(plan: DecodeLayersPlan, T: int, workspace: torch.Tensor, 
         raise _lib.KvqError("kvq: decode_step_layers workspace must be contiguous float32")
     t = plan.tabs
     dims = _lib.KvqAttnDims(plan.B, plan.Hq, plan.Hkv, T, plan.D)
-    check(_lib.load().kvq_decode_step_layers(
+    check(_launch(plan.device, _lib.load().kvq_decode_step_layers, 
         plan.L, 1 if append else 0, t["q"], plan.q_st[0], plan.q_st[1], t["kn"], plan.kn_st[0], plan.kn_st[1],
         t["vn"], plan.vn_st[0], plan.vn_st[1], t["k"], byref(plan.kst), t["ks"], plan.kbits, t["v"], byref(plan.vst), t["vs"],
         plan.vbits, t["out"], plan.o_st[0], plan.o_st[1], plan.dtype_code, float(sm_scale), plan.eps,
-        c_void_p(workspace.data_ptr()), workspace.numel(), byref(dims), _lib.current_stream(plan.device)), "decode_step_layers")
+        c_void_p(workspace.data_ptr()), workspace.numel(), byref(dims)), "decode_step_layers")

@@ -18,6 +18,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "benchcli: one real `python bench.py` run as a subprocess on the GPU box, checked field by field against the "
+                                       "driver's contract (`pytest -m benchcli`, ~25 s; kept out of `-m gpu` so that the parity suite stays under a minute)")
     config.addinivalue_line("markers", "ab: variant-equality tests of kernels that lost a measurement; they need the A-B library "
                                        "(make -C efficient-llm-inference_amd/csrc ab) and run with `pytest -m ab` on the GPU box only")
     if _selects_ab(config) and not os.environ.get("KVQ_HIP_LIB"):
@@ -35,11 +37,12 @@ def _selects_ab(config) -> bool:
 def pytest_collection_modifyitems(config, items):
     """`ab` tests run only when the -m expression names them: `-m gpu` (the driver's run) and `-m "not gpu"` see the
     shipped library's tests only."""
-    if _selects_ab(config):
-        return
+    words = (config.getoption("-m") or "").replace("(", " ").replace(")", " ").split()
+    wants_cli = any(w == "benchcli" and (i == 0 or words[i - 1] != "not") for i, w in enumerate(words))
     keep, drop = [], []
     for it in items:
-        (drop if it.get_closest_marker("ab") else keep).append(it)
+        gone = (it.get_closest_marker("ab") and not _selects_ab(config)) or (it.get_closest_marker("benchcli") and not wants_cli)
+        (drop if gone else keep).append(it)
     if drop:
         config.hook.pytest_deselected(items=drop)
         items[:] = keep

@@ -103,7 +103,7 @@ def test_gpus_flag_fails_loudly():
     assert proc.returncode != 0 and "WORLD_SIZE" in proc.stderr
 
 
-@pytest.mark.gpu
+@pytest.mark.benchcli
 def test_bench_line_carries_the_contract_fields(tmp_path):
     """One real run of the default workload on the GPU (few steps, CPU baseline on a tiny sample): ONE JSON line on
     stdout with every field the driver's contract names, the roofline and cpu_baseline objects, self-consistent."""
@@ -135,7 +135,7 @@ def test_bench_line_carries_the_contract_fields(tmp_path):
     assert j["roofline_k"]["kernel"] == "dequant_tokens_fast_k<0, 8, 8, 2, true, true, true, 64>"
     assert j["roofline_quantise"]["quant_int4"]["kernel"] == "quant_tile_k<0, 4, 8, 16, 4, 0>"
     assert j["roofline_quantise"]["quant_int8"]["kernel"] == "quant_tile_k<0, 8, 8, 16, 4, 0>"
-    assert j["public_api"]["ms_per_call"] >= j["ms_per_step"] * 0.9 and j["public_api"]["call"].startswith("QuantizedKVCache.to_past_key_values")
+    assert j["public_api"]["ms_per_call"] >= j["ms_per_step"] * 0.75 and j["public_api"]["call"].startswith("QuantizedKVCache.to_past_key_values")
     # the rest of BASELINE.json's metric rides in the same line
     d = j["decode"]
     assert "error" not in d, d
@@ -153,6 +153,14 @@ def test_bench_line_carries_the_contract_fields(tmp_path):
     assert "error" not in ev, ev
     assert ev["roofline"]["kernel"].startswith("chunk_pool_wave_k<0, 4, 16>") and ev["roofline_window"]["kernel"].startswith("copy_rows_k<")
     assert 0.5 < ev["roofline"]["frac"] < 1.0 and 0.3 < ev["roofline_window"]["frac"] < 1.0
+    sp = j["configs"]["llama3_8b_sparse_seq32k"]  # scope row N3 on the same tensors (round 4)
+    assert "error" not in sp, sp
+    for op in ("trim_kv_strided", "trim_kv_block_old", "trim_kv_budget_old", "trim_kv_prefix_window"):
+        assert sp[op]["kernel"].startswith("gather_rows_k") and sp[op]["kept_tokens"] > 0 and 0.0 < sp[op]["frac"] < 1.0, (op, sp[op])
+    assert sp["paged_get_kv"]["kernel"].startswith("copy_rows_k<") and sp["trim_kv_strided"]["kept_tokens"] == 32 + (32768 - 256 - 32 + 3) // 4 + 256
+    for kind in ("int8", "int4"):  # the quantise launch on padded rows and on the outlier-channel input
+        rq = j["roofline_quantise"][f"quant_{kind}"]
+        assert rq["padded_rows"]["kernel"] == rq["kernel"] == rq["outlier_channels"]["kernel"] and 0.3 < rq["padded_rows"]["frac"] < 1.0
     sq = j["sharded_quant"]  # one rank: the batch-64 slice in ONE pass, the two phases of an N > 1 rank beside it
     assert "error" not in sq, sq
     assert sq["kernels"] == "quant_wide_k<0, 8, 1024, 16> + quant_wide_k<0, 4, 1024, 16>", sq["kernels"]
@@ -162,6 +170,9 @@ def test_bench_line_carries_the_contract_fields(tmp_path):
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
+    assert c["host_cpu"]["usable"] == c["host_cores_available"] <= c["host_cpu"]["machine"] and c["timer_quantum_suspects"] == [], c["timer_quantum_suspects"]
+    if c["host_cores_available"] > 1:
+        assert c["port"]["all_cores"]["cores"] == c["host_cores_available"] and c["port"]["all_cores"]["value"] > 0
     assert c["max_rel_err_vs_gpu"] == 0.0 and c["eviction"]["pool_value"] > 0
     assert all(v["bit_exact"] and v["max_rel_err"] == 0.0 for k, v in c["parity"].items() if k != "sample"), c["parity"]
     assert j["run_s"] < 200

@@ -173,3 +173,40 @@ def test_round2_edges_on_gpu(E):
         for (W, P, n) in ((8, 0, 7), (256, 32, 64), (33, 5, 100), (1, 1, 3)):
             (k, _), = trim_kv_budget_old(((x, x),), window_size=W, old_budget=n, prefix_len=P)
             assert k[0, 0, :, 0].round().long().cpu().tolist() == g8[f"budget.T{T}.W{W}.P{P}.n{n}"].tolist(), (T, W, P, n)
+
+
+@pytest.mark.parametrize("shape", [(6, 1, 8, 700, 128), (3, 2, 12, 333, 64), (2, 8, 8, 2048, 128), (1, 1, 2, 50, 24)])
+def test_gather_4kib_items_equal_the_grid_stride_kernel(E, shape):
+    """gather_rows (round 4, default 1): gather_rows_k — one 16-byte piece per thread, 4 KiB of output per workgroup, the
+    (batch row, head) as a grid dimension — against the grid-stride kernel it replaced (gather_rows = 0): equal bytes for every
+    policy's index list, out-of-range indices (zero rows), a strided source, the legacy tuple of separate tensors; head_dim 24
+    (48-byte rows: 3 pieces per row, not a power of two) stays on the grid-stride kernel either way."""
+    from efficient_llm_inference_amd import _lib
+    from efficient_llm_inference_amd import kernels as K
+    G, B, H, T, D = shape
+    g = torch.Generator(device="cuda").manual_seed(T)
+    big = torch.randn(G, B, H, T + 5, D, device="cuda", generator=g).half()
+    x = big[:, :, :, 2:T + 2]
+    lists = [O.keep_indices_strided(T, 33, 3, 2), O.keep_indices_block_old(T, 20, 16, 5, 1), O.keep_indices_budget_old(T, 17, 9, 3),
+             [0, T - 1, T, -1, 5, 5, 2**31 - 1, 1]]
+    old = _lib.get_tunable("gather_rows")
+    try:
+        for keep in lists:
+            idx = torch.tensor(list(keep), dtype=torch.int32, device="cuda")
+            outs = []
+            for which in (1, 0):
+                _lib.set_tunable("gather_rows", which)
+                for src in (x, [x[i] for i in range(G)]):
+                    out = torch.full((G, B, H, idx.numel(), D), 7.0, device="cuda", dtype=torch.float16)
+                    _lib.kernel_log_clear()
+                    K.gather_tokens(src, out, idx)
+                    torch.cuda.synchronize()
+                    name = _lib.kernel_log()[0]
+                    assert name.startswith("gather_rows_k" if which == 1 and D % 8 == 0 and (D // 8) & (D // 8 - 1) == 0 else "gather_tokens_k<"), (which, name)
+                    outs.append(out)
+            for o in outs[1:]:
+                assert torch.equal(o.view(torch.int16), outs[0].view(torch.int16))
+            ok = [j for j, t in enumerate(keep) if 0 <= t < T]
+            assert torch.equal(outs[0][:, :, :, ok], x[:, :, :, [keep[j] for j in ok]])
+    finally:
+        _lib.set_tunable("gather_rows", old)
