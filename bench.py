@@ -83,6 +83,7 @@ ATTN = {  # name: (L, B, Hq, Hkv, T, D, mode)
     "llama2_7b_decode_attn_seq4k_b8": (32, 8, 32, 32, 4096, 128, "mixed"),  # multi-head (one query head per kv head)
     "llama32_1b_decode_attn_seq16k_b8": (16, 8, 32, 8, 16384, 64, "mixed"),  # grouped-query at head_dim 64
 }
+QUANT_ROW_PAD_TOKENS = 48  # profiles/r04a_quant_stride_table.md: any pad >= 4 tokens moves the input's head rows off a power-of-two stride
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 BYTES_PER_ELT = {"int8": 3.0, "int4": 2.5}  # q read + fp16 write
 MODE_KINDS = {"int8": ("int8", "int8"), "int4": ("int4", "int4"), "mixed": ("int8", "int4")}
@@ -746,6 +747,18 @@ def measure_shape(name, dev, rank, iters=24):
         nbytes = n_elts * BYTES_PER_ELT[kind]
         rec[f"dequant_{kind}"] = _roofline(k_d, nbytes, d_ms, _DISPATCH_TIMER, rotating_stores=n_st)
         rec[f"quant_{kind}"] = _roofline(k_q, nbytes, q_ms, _DISPATCH_TIMER, rotating_stores=n_st)
+        # the same launch with the input's head rows off their stride ([:, :, :, :T] views of T + 48 token rows) — only where the
+        # contiguous stride is a multiple of 1 MiB: 4 MiB rows are the one stride measured to hurt, at 512 KiB a pad of this size
+        # costs 10 % (profiles/r04a_quant_stride_table.md)
+        if (T * D * 2) % (1 << 20) == 0:
+            xps = []
+            for x in xs:
+                full = torch.empty(L, B, H, T + QUANT_ROW_PAD_TOKENS, D, device=dev, dtype=torch.float16)
+                full[:, :, :, :T].copy_(x)
+                xps.append(full[:, :, :, :T])
+            p_ms = _time_launches(lambda i: K.quant_tokens(xps[i % n_rot], stores[i % n_st].q[:, :, :, :T], stores[i % n_st].scales[:, :T], ws, kind), iters)
+            rec[f"quant_{kind}"]["padded_rows"] = _roofline(k_q, nbytes, p_ms, _DISPATCH_TIMER, input=f"[L,B,H,T+{QUANT_ROW_PAD_TOKENS},D][:, :, :, :T] views, same values")
+            del xps
         del stores
     vk = MODE_KINDS[mode][1]
     rec["roofline"] = rec[f"dequant_{vk}"]            # the config's own kind (V set)
@@ -1035,9 +1048,6 @@ def _subrecord(fn, *a, **kw):
         traceback.print_exc(file=sys.stderr)
         _free()
         return {"error": f"{type(exc).__name__}: {exc}"[:400]}
-
-
-QUANT_ROW_PAD_TOKENS = 48  # profiles/r04a_quant_stride_table.md: any pad >= 4 tokens moves the input rows off the 4 MiB stride
 
 
 def _quant_variants(tensors, kind, n_elts, dev):

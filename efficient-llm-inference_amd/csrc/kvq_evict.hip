@@ -221,6 +221,9 @@ __global__ __launch_bounds__(kBlock) void chunk_pool_vec_k(const PoolArgs a, uin
 // chunk's end enter as +0.0, which leaves an fp32 sum that started at +0.0 unchanged (the reference zero-pads too).
 // (A variant without the redundant phases — 64 v_permlane16/32_swap instructions transpose the chunk so that every
 // lane sums ONE dword of all 64 rows — was bit-identical and no faster: 5.76-5.85 vs 5.63-5.69 ms on the same box.)
+#ifndef KVQ_POOL_CALIB
+#define KVQ_POOL_CALIB 0
+#endif
 template <int DT, int G, int RPG>
 __global__ __launch_bounds__(64) void chunk_pool_wave_k(const PoolArgs a) {
   static_assert(DT != KVQ_F32, "16-bit element types");
@@ -264,6 +267,21 @@ __global__ __launch_bounds__(64) void chunk_pool_wave_k(const PoolArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       xf[i][k] = f32x2{Elem<DT>::widen((uint16_t)(raw[i][k] & 0xFFFFu)), Elem<DT>::widen((uint16_t)(raw[i][k] >> 16))};
+#if KVQ_POOL_CALIB == 1  // calibration (`make calib_pool`, NOT the oracle's order): every group sums its own RPG rows once, the G partial
+  // sums are then added group by group — what a blocked summation order would cost instead of the sequential one
+#pragma unroll
+  for (int i = 0; i < RPG; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc2[k] += xf[i][k];
+#pragma unroll
+  for (int ph = 1; ph < G; ++ph) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x2 up = f32x2{__shfl_up(acc2[k][0], DV), __shfl_up(acc2[k][1], DV)};
+      if (lg == (uint32_t)ph) acc2[k] = up + acc2[k];
+    }
+  }
+#else
 #pragma unroll
   for (int ph = 0; ph < G; ++ph) {
     if (ph) {
@@ -275,6 +293,7 @@ __global__ __launch_bounds__(64) void chunk_pool_wave_k(const PoolArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc2[k] += xf[i][k];
   }
+#endif
   float acc[8];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {

@@ -47,16 +47,19 @@ def make_store(kind, pad, dev):
 
 def measure(pad_in, pad_out, dist, iters, dev, check=False):
     from efficient_llm_inference_amd import kernels as K
-    xs = [make_input(pad_in, dist, 42 + i, dev) for i in range(2)]
+    n_in = max(2, -(-(768 << 20) // (L * B * H * T * D * 2)))  # inputs rotate over >= 768 MiB
+    xs = [make_input(pad_in, dist, 42 + i, dev) for i in range(n_in)]
     ws = torch.empty(L * T, device=dev, dtype=torch.float32)
     rec = {"pad_in_tokens": pad_in, "pad_out_tokens": pad_out, "in_row_stride_B": (T + pad_in) * D * 2}
     for kind in ("int8", "int4"):
-        stores = [make_store(kind, pad_out, dev) for _ in range(2)]
-        fn = lambda i: K.quant_tokens(xs[i % 2], stores[i % 2][0], stores[i % 2][1], ws, kind)  # noqa: E731
+        n_st = max(2, -(-(512 << 20) // (L * B * H * T * D // (1 if kind == "int8" else 2))))
+        stores = [make_store(kind, pad_out, dev) for _ in range(n_st)]
+        fn = lambda i: K.quant_tokens(xs[i % n_in], stores[i % n_st][0], stores[i % n_st][1], ws, kind)  # noqa: E731
         kern = _kernels_of(lambda: fn(0))
         ms = _time_launches(fn, iters)
         nbytes = L * B * H * T * D * BPE[kind]
         avg = sum(ms) / len(ms)
+        rec["shape_LBHTD"] = [L, B, H, T, D]
         rec[kind] = {"kernel": kern.split("(")[0][-60:], "avg_us": round(avg * 1e3, 2), "median_us": round(ms[len(ms) // 2] * 1e3, 2),
                      "min_us": round(ms[0] * 1e3, 2), "frac_of_8TBps": round(nbytes / (avg * 1e-3) / 8e12, 4),
                      "out_row_stride_B": (T + pad_out) * (D if kind == "int8" else D // 2)}
@@ -79,7 +82,11 @@ def main():
     ap.add_argument("--iters", type=int, default=24)
     ap.add_argument("--one", default=None, help="pad_in,pad_out: measure only this pair (for the PMC passes)")
     ap.add_argument("--pads", default="0,1,4,16,17,48,80,272,1040")
+    ap.add_argument("--shape", default=None, help="L,B,H,T,D instead of config 4's 32,1,8,16384,128")
     args = ap.parse_args()
+    if args.shape:
+        global L, B, H, T, D
+        L, B, H, T, D = (int(v) for v in args.shape.split(","))
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     if args.one:
