@@ -1719,9 +1719,10 @@ __device__ __forceinline__ void merge_group_one_wave(const AttnArgs& a, const bo
 // LDS that is far from busy). Completion: every request of a tile is an LDS-DMA, so `s_waitcnt vmcnt(OPS x (NB-1))`
 // is "tile k has landed" (loads retire in order); tiles past the wave's last are requested with an empty descriptor
 // (nothing is read) so that the count is the same in every iteration.
-template <int KBITS>
+template <int KCPR>  // 16-byte chunks per stored key row: 8 (128 B: INT8 at head_dim 128) or 4 (64 B: INT4 at 128, INT8 at 64)
 __device__ inline uint32_t k_swizzle(uint32_t row) {
-  if constexpr (KBITS == 8) return (row >> 1) & 7u;
+  static_assert(KCPR == 8 || KCPR == 4, "key rows of 128 or 64 bytes");
+  if constexpr (KCPR == 8) return (row >> 1) & 7u;
   else return (row & 8u) ? 3u : 0u;
 }
 
@@ -1734,18 +1735,18 @@ __device__ __forceinline__ void wait_vmcnt() {  // s_waitcnt vmcnt(N) only (expc
 // MFMA operand fragments of one tile out of its LDS image (K rows swizzled as k_swizzle says, V rows plain), in
 // AttnStream::Raw's register layout: lane (x, g) takes the 16 K bytes of row 16 i + x at chunk 4 c + g, and the V bytes
 // of its eight token rows per 32-token step.
-template <int KBITS, int VBITS, int TC, bool KI8, class RAW>
+template <int KBITS, int VBITS, int TC, bool KI8, class RAW, int HD = 128>
 __device__ __forceinline__ void read_fragments(const uint8_t* img, RAW& r) {  // RAW: AttnStream<...>::Raw of any TG
-  typedef AttnStream<KBITS, VBITS, TC, 128, KI8, false> ST;
+  typedef AttnStream<KBITS, VBITS, TC, HD, KI8, false> ST;
   constexpr int NT = ST::NT, NS = ST::NS, NL = ST::NL, VB = ST::VB;
-  constexpr int KROW = 128 * KBITS / 8, VROW = 128 * VBITS / 8;
+  constexpr int KROW = HD * KBITS / 8, VROW = HD * VBITS / 8;
   const uint32_t lane = threadIdx.x & 63u, x = lane & 15u, g = lane >> 4;
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const uint32_t row = 16u * i + x;
 #pragma unroll
     for (int c = 0; c < NL; ++c) {
-      const u32x4 w = *reinterpret_cast<const u32x4*>(img + row * KROW + (((4u * c + g) ^ k_swizzle<KBITS>(row)) << 4));
+      const u32x4 w = *reinterpret_cast<const u32x4*>(img + row * KROW + (((4u * c + g) ^ k_swizzle<KROW / 16>(row)) << 4));
 #pragma unroll
       for (int j = 0; j < 4; ++j) r.k[i][c][j] = w[j];
     }
@@ -1760,20 +1761,25 @@ __device__ __forceinline__ void read_fragments(const uint8_t* img, RAW& r) {  //
         const u32x2 w = *reinterpret_cast<const u32x2*>(vimg + row * VROW + 8u * x);
         r.v[sidx][j][0] = w[0];
         r.v[sidx][j][VB == 8 ? 1 : 0] = w[1];
-      } else {
+      } else if constexpr (VB == 4) {
         r.v[sidx][j][0] = *reinterpret_cast<const uint32_t*>(vimg + row * VROW + 4u * x);
+      } else {  // head_dim 64, INT4 values: 2 bytes (4 elements) per lane and row
+        static_assert(VB == 2, "V bytes per lane and row");
+        r.v[sidx][j][0] = (uint32_t)*reinterpret_cast<const uint16_t*>(vimg + row * VROW + 2u * x);
       }
     }
   }
 }
 
-template <int KBITS, int VBITS, int TC, bool KI8, int NB, int TG = 1>
+template <int KBITS, int VBITS, int TC, bool KI8, int NB, int TG = 1, int HD = 128>
 __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_lds_mfma_k(const AttnArgs a, const uint32_t tpw) {
-  constexpr int HD = 128;
+  // HD = 64 (round 4; INT8 keys only: 64-byte key rows = the 4-chunk image of INT4 keys at head_dim 128; values of 64 / 32
+  // bytes per row): a 64-token tile is 4 + 2 (INT4 values) or 4 + 4 requests of 1 KiB + the two scale rows, a ring slot 6.5 / 8.5 KiB
+  static_assert(HD == 128 || (HD == 64 && KBITS == 8), "head_dim 128, or 64 with INT8 keys");
   typedef AttnStream<KBITS, VBITS, TC, HD, KI8, false, TG> ST;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   constexpr int DVN = ST::DVN;
-  static_assert(ST::CBK == 16, "head_dim 128 rows: 16-byte K fragments");
+  static_assert(ST::CBK == 16, "16-byte K fragments (head_dim 128, or 64 with INT8 keys)");
   constexpr int KROW = HD * KBITS / 8, VROW = HD * VBITS / 8;   // stored bytes per token row
   constexpr int KCPR = KROW / 16, VCPR = VROW / 16;              // 16-byte chunks per row
   constexpr int KOPS = TC * KROW / 1024, VOPS = TC * VROW / 1024;  // 1 KiB wave requests per tile
@@ -1805,7 +1811,7 @@ __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_lds_mfma_
 #pragma unroll
   for (int par = 0; par < 2; ++par) {
     const uint32_t row = (uint32_t)par * (1024u / KROW) + lane / KCPR;
-    k_off[par] = (lane / KCPR) * (uint32_t)a.k_st + (((lane % KCPR) ^ k_swizzle<KBITS>(row)) << 4);
+    k_off[par] = (lane / KCPR) * (uint32_t)a.k_st + (((lane % KCPR) ^ k_swizzle<KCPR>(row)) << 4);
   }
   const uint32_t v_off = (lane / VCPR) * (uint32_t)a.v_st + ((lane % VCPR) << 4);
 
@@ -1875,7 +1881,7 @@ __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_lds_mfma_
     const uint32_t t0 = (first + k * step) * (uint32_t)TC;
     const uint32_t nt = a.T - t0 < (uint32_t)TC ? a.T - t0 : (uint32_t)TC;
     const uint8_t* slot = ring + (k % NB) * SLOT;
-    read_fragments<KBITS, VBITS, TC, KI8>(slot, r);
+    read_fragments<KBITS, VBITS, TC, KI8, typename ST::Raw, HD>(slot, r);
     static_assert(TC <= kWave, "one scale per lane");
     const float* sc = reinterpret_cast<const float*>(slot + TC * (KROW + VROW));
     if constexpr (TG == 4 && NB > 1) {
@@ -1917,7 +1923,8 @@ __global__ __launch_bounds__(kWave, TC >= 64 ? 2 : 3) void decode_attn_lds_mfma_
 #pragma unroll
       for (int c = 0; c < DVN; ++c) {
         int e = c;
-        if constexpr (VBITS == 4) e = c < 4 ? 2 * c : 2 * (c - 4) + 1;
+        if constexpr (VBITS == 4 && HD == 128) e = c < 4 ? 2 * c : 2 * (c - 4) + 1;
+        if constexpr (VBITS == 4 && HD == 64) e = c == 1 ? 2 : (c == 2 ? 1 : c);
         o8[e] = st.acc[c][q] * st.svref;
       }
       const int64_t di = a.acc_off + (((int64_t)b * a.Hq + hk * a.nq + h) * a.nsplit + split) * a.D + DVN * x;
@@ -1979,7 +1986,7 @@ __global__ __launch_bounds__(kWave, 2) void decode_attn_coal_mfma_k(const AttnAr
 #pragma unroll
   for (int par = 0; par < 2; ++par) {
     const uint32_t row = (uint32_t)par * (1024u / KROW) + lane / KCPR;
-    k_dst[par] = (lane / KCPR) * KROW + (((lane % KCPR) ^ k_swizzle<KBITS>(row)) << 4);
+    k_dst[par] = (lane / KCPR) * KROW + (((lane % KCPR) ^ k_swizzle<KCPR>(row)) << 4);
   }
   struct Flight {  // one tile as requested: whole lines, lane-linear
     u32x4 k[KOPS], v[VOPS];
@@ -2743,23 +2750,25 @@ static int stream_tc() { return KVQ_AB && tunables().attn_stream_tc == 32 ? 32 :
 // attn_lds: -1 (default) / 1 = the LDS-DMA ring kernel serves every streaming plan; 0 = never (A-B builds: the register-
 // staged streaming kernel instead; the default library then has no streaming kernel and takes one-tile splits);
 // 2 (A-B builds) = the coalesced register-staged kernel
-static bool use_lds(const kvq_attn_dims_t* d) {
-  return tunables().attn_lds != 0 && use_mfma(d) && d->D == 128;
+// (head_dim 64, round 4: the ring kernel's HD = 64 instantiation takes INT8 keys only — k_bits; sizing calls pass 8 and cover the
+// one-tile plan beside it)
+static bool use_lds(const kvq_attn_dims_t* d, int k_bits = 8) {
+  return tunables().attn_lds != 0 && use_mfma(d) && (d->D == 128 || (d->D == 64 && k_bits == 8 && !(KVQ_AB && (tunables().attn_lds == 2 || tunables().attn_lds == 3))));
 }
 static int lds_tc() { return KVQ_AB && tunables().attn_lds_tc == 32 ? 32 : 64; }
 // tokens per tile of whichever streaming kernel serves these dims
-static int tile_tc(const kvq_attn_dims_t* d) { return use_lds(d) ? lds_tc() : stream_tc(); }
-static uint32_t stream_tpw(const kvq_attn_dims_t* d) {
-  if (!use_mfma(d) || d->D != 128 || d->T <= 0) return 0;
+static int tile_tc(const kvq_attn_dims_t* d, int k_bits = 8) { return use_lds(d, k_bits) ? (d->D == 64 ? 64 : lds_tc()) : stream_tc(); }
+static uint32_t stream_tpw(const kvq_attn_dims_t* d, int k_bits = 8) {
+  if (!use_mfma(d) || !(d->D == 128 || (d->D == 64 && use_lds(d, k_bits))) || d->T <= 0) return 0;
   const int64_t forced = tunables().attn_stream_tpw;  // -1 = never, 0 = by size, > 0 = that many
   if (forced < 0) return 0;
-  const int kStreamTC = tile_tc(d);
+  const int kStreamTC = tile_tc(d, k_bits);
   const int64_t ntiles = (d->T + kStreamTC - 1) / kStreamTC;
   // wave slots of one round: the LDS-staged kernel holds its tiles in LDS, 4 one-wave workgroups per CU; (A-B) register-
   // staged kernels: 2 waves per SIMD at 64-token tiles, 3 at 32-token tiles
-  const bool ring = use_lds(d) && !(KVQ_AB && tunables().attn_lds == 2);
+  const bool ring = use_lds(d, k_bits) && !(KVQ_AB && tunables().attn_lds == 2);
   if (!ring && !KVQ_AB) return 0;  // the default library's only streaming kernel is the ring kernel
-  int64_t slots = ring ? kLdsSlots : 256 * 4 * (kStreamTC == 64 ? 2 : 3);
+  int64_t slots = ring ? kLdsSlots : 256 * 4 * (kStreamTC == 64 ? 2 : 3);  // (head_dim 64 too: 2048 slots measured 24.9 us per call against 23.7 at 1024, Llama-3.2-1B batch 8)
   if (KVQ_AB && tunables().attn_stream_slots > 0) slots = tunables().attn_stream_slots;
   int64_t tpw = forced > 0 ? forced : (ntiles * d->B * d->Hkv + slots - 1) / slots;
   // by size: the ring pays from three tiles per wave on (batch 1 at 16 K tokens = two tiles per wave: 14.9 us per layer
@@ -2771,10 +2780,10 @@ static uint32_t stream_tpw(const kvq_attn_dims_t* d) {
 static bool plan_onetile(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit);
 // tpw_out (optional): tiles per wave of the streaming layout when THAT is what the plan chose, 0 when it fell back to
 // one-tile splits (the launcher must size its kernel choice from this, never from stream_tpw() on its own)
-static bool plan(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit, uint32_t* tpw_out = nullptr) {
+static bool plan(const kvq_attn_dims_t* d, uint32_t* ts, uint32_t* nsplit, uint32_t* tpw_out = nullptr, int k_bits = 8) {
   if (tpw_out) *tpw_out = 0;
-  if (const uint32_t tpw = stream_tpw(d)) {  // one wave per tpw tiles of 64 (32) tokens
-    const int64_t per = (int64_t)tpw * tile_tc(d);
+  if (const uint32_t tpw = stream_tpw(d, k_bits)) {  // one wave per tpw tiles of 64 (32) tokens
+    const int64_t per = (int64_t)tpw * tile_tc(d, k_bits);
     *ts = (uint32_t)per;
     *nsplit = (uint32_t)((d->T + per - 1) / per);
     if (*nsplit <= (uint32_t)kAttnMaxSplit) {
@@ -2815,7 +2824,7 @@ static int64_t arrive_floats(const kvq_attn_dims_t* d) { return (d->B * d->Hkv +
 // 1 = where the host call covers several layers (kvq_decode_step_layers: ONE memset of the words per call), 2 = in
 // kvq_decode_attn too (a memset per call).
 static bool attn_fold_plan(const kvq_attn_dims_t* d) {
-  if (!KVQ_AB || tunables().attn_fold <= 0 || !use_lds(d) || d->T <= 0 || d->Hq / d->Hkv > 4) return false;
+  if (!KVQ_AB || tunables().attn_fold <= 0 || !use_lds(d) || d->D != 128 || d->T <= 0 || d->Hq / d->Hkv > 4) return false;
   if (KVQ_AB && (tunables().attn_lds == 2 || tunables().attn_lds == 3 || tunables().attn_lds_nb != 0 || lds_tc() != 64 || tunables().attn_fused)) return false;
   uint32_t ts, ns, tpw;
   if (!plan(d, &ts, &ns, &tpw) || tpw == 0u || ns == 0u || ns > 16u) return false;
@@ -2908,7 +2917,19 @@ static void launch_partial(const AttnArgs& a, hipStream_t st) {
     return;
   }
 #endif
-  if (a.mfma && a.stream_tpw && a.lds) {  // (a.lds == 3, A-B: the same kernel with strided tile ownership)
+  if constexpr (kI8) {
+    if (a.mfma && a.stream_tpw && a.lds == 1u && a.D == 64u) {  // head_dim 64 (INT8 keys): ring depth 2, eight one-wave workgroups per CU
+      constexpr int kSlot64 = 64 * (64 * KBITS / 8 + 64 * VBITS / 8) + 512;
+#if KVQ_AB  // ring depth A-B at head_dim 64 (attn_lds_nb = 3 | 4; TG = 4 instantiation)
+      if (a.nq <= 4u && tunables().attn_lds_nb == 3) { KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 64, kI8, 3, 4, 64>), grid, dim3(kWave), (size_t)(3 * kSlot64), st, a, a.stream_tpw); return; }
+      if (a.nq <= 4u && tunables().attn_lds_nb == 4) { KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 64, kI8, 4, 4, 64>), grid, dim3(kWave), (size_t)(4 * kSlot64), st, a, a.stream_tpw); return; }
+#endif
+      if (a.nq <= 4u) KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 64, kI8, 2, 4, 64>), grid, dim3(kWave), (size_t)(2 * kSlot64), st, a, a.stream_tpw);
+      else KVQ_LAUNCH((decode_attn_lds_mfma_k<KBITS, VBITS, 64, kI8, 2, 1, 64>), grid, dim3(kWave), (size_t)(2 * kSlot64), st, a, a.stream_tpw);
+      return;
+    }
+  }
+  if (a.mfma && a.stream_tpw && a.lds && a.D == 128u) {  // (a.lds == 3, A-B: the same kernel with strided tile ownership)
     // ring depth 2: one tile in flight behind the one being reduced, four one-wave workgroups per CU (25.6 KiB each for
     // INT8 keys + INT4 values). Measured at batch 8, 16 K tokens (per layer call incl. merge, profiles/r03d_*): depth 2
     // 40.8 us, depth 3 44.7 us, depth 4 (three workgroups per CU) 86 us; 32-token tiles 42.1-51.6 us.
@@ -3093,9 +3114,9 @@ static int decode_attn_impl(const char* name, const void* q, int64_t q_sb, int64
   a.dtype = dtype;
   a.mfma = use_mfma(d) ? 1 : 0;
   a.stream_tpw = 0u;
-  a.lds = (!t_dev && use_lds(d)) ? (KVQ_AB && tunables().attn_lds == 2 ? 2u : (KVQ_AB && tunables().attn_lds == 3 ? 3u : 1u)) : 0u;
+  a.lds = (!t_dev && use_lds(d, k_bits)) ? (KVQ_AB && tunables().attn_lds == 2 ? 2u : (KVQ_AB && tunables().attn_lds == 3 ? 3u : 1u)) : 0u;
   a.t_dev = t_dev;
-  if (!(t_dev ? plan_onetile(d, &a.TS, &a.nsplit) : plan(d, &a.TS, &a.nsplit, &a.stream_tpw))) {
+  if (!(t_dev ? plan_onetile(d, &a.TS, &a.nsplit) : plan(d, &a.TS, &a.nsplit, &a.stream_tpw, k_bits))) {
     set_error("%s: T=%lld needs more than %d splits of %d tokens", name, (long long)d->T, kAttnMaxSplit, kAttnMaxTS);
     return KVQ_E_DIMS;
   }

@@ -459,11 +459,11 @@ def test_decode_attn_lds_staged_kernel(K, tunable, tpw, which):
         _lib.kernel_log_clear()
         _run_case(K, 2, 32, 8, 1500, 128, "int8", "int4", "f16", True)
         # (4 query heads per kv head: the shipped kernel's one-score-output-per-tile instantiation, TG = 4)
-        assert _lib.kernel_log()[0].startswith(("decode_attn_lds_mfma_k<8, 4, 64, true, 2, 4>", "decode_attn_coal_mfma_k<", "decode_attn_lds_mfma_k<8, 4, 64, true, 2, 4>")[which - 1]), _lib.kernel_log()
+        assert _lib.kernel_log()[0].startswith(("decode_attn_lds_mfma_k<8, 4, 64, true, 2, 4, 128>", "decode_attn_coal_mfma_k<", "decode_attn_lds_mfma_k<8, 4, 64, true, 2, 4, 128>")[which - 1]), _lib.kernel_log()
         _lib.kernel_log_clear()
         _run_case(K, 1, 16, 2, 700, 128, "int8", "int4", "f16", True)  # 8 query heads per kv head: one output per 16-token group
         if which != 2:
-            assert _lib.kernel_log()[0].startswith("decode_attn_lds_mfma_k<8, 4, 64, true, 2, 1>"), _lib.kernel_log()
+            assert _lib.kernel_log()[0].startswith("decode_attn_lds_mfma_k<8, 4, 64, true, 2, 1, 128>"), _lib.kernel_log()
 
 
 @pytest.mark.ab
@@ -480,7 +480,7 @@ def test_decode_attn_lds_kernel_one_output_per_token_group(K, tunable, tpw):
             _run_case(K, *case, "int8", "int8", "bf16", True)
     _lib.kernel_log_clear()
     _run_case(K, 2, 32, 8, 1500, 128, "int8", "int4", "f16", True)
-    assert _lib.kernel_log()[0].startswith("decode_attn_lds_mfma_k<8, 4, 64, true, 2, 1>"), _lib.kernel_log()
+    assert _lib.kernel_log()[0].startswith("decode_attn_lds_mfma_k<8, 4, 64, true, 2, 1, 128>"), _lib.kernel_log()
 
 
 def test_streaming_plan_rejected_falls_back_to_one_tile_splits(K, tunable):
@@ -909,3 +909,34 @@ def test_merge_inside_the_partial_launch_with_eight_query_heads_keeps_two_launch
     _lib.kernel_log_clear()
     _run_case(K, 1, 16, 2, 700, 128, "int8", "int4", "f16", True)
     assert len(_lib.kernel_log()) == 2
+
+
+@pytest.mark.parametrize("tpw", [0, 1, 3, 9])
+def test_decode_attn_lds_staged_kernel_head_dim_64(K, tunable, tpw):
+    """decode_attn_lds_mfma_k<..., HD = 64> (round 4): the ring kernel at head_dim 64 with INT8 keys (64-byte key rows in the
+    4-chunk swizzled image, 32- / 64-byte value rows, 2-byte V fragments for INT4 values) — Llama-3.2-1B / gpt2-family head
+    shapes. Against the oracle: 4 query heads per kv head (the one-score-output instantiation), 8 and 3 per kv head (one per
+    16-token group, padded heads), INT4 and INT8 values, bf16, with and without the new token, ragged tiles, a batch-8 context.
+    INT4 KEYS at head_dim 64 have 32-byte rows (8-byte fragments): they keep the one-tile kernel."""
+    from efficient_llm_inference_amd import _lib
+    tunable("attn_stream_tpw", tpw)
+    cases = [(1, 32, 8, 700, 64), (2, 16, 2, 131, 64), (1, 12, 4, 1000, 64), (3, 8, 2, 1, 64), (1, 8, 2, 64, 64), (1, 8, 2, 129, 64), (8, 32, 8, 4100, 64)]
+    for case in cases:
+        big = case[0] * case[3] > 20000
+        if big and tpw not in (0, 3):
+            continue
+        _run_case(K, *case, "int8", "int4", "f16", True)
+        if not big:
+            _run_case(K, *case, "int8", "int8", "f16", True)
+            _run_case(K, *case, "int8", "int4", "bf16", True)
+            _run_case(K, *case, "int8", "int4", "f16", False)
+    if tpw:
+        _lib.kernel_log_clear()
+        _run_case(K, 2, 32, 8, 1500, 64, "int8", "int4", "f16", True)
+        assert _lib.kernel_log()[0].startswith("decode_attn_lds_mfma_k<8, 4, 64, true, 2, 4, 64>"), _lib.kernel_log()
+        _lib.kernel_log_clear()
+        _run_case(K, 1, 16, 2, 700, 64, "int8", "int8", "f16", True)  # 8 query heads per kv head
+        assert _lib.kernel_log()[0].startswith("decode_attn_lds_mfma_k<8, 8, 64, true, 2, 1, 64>"), _lib.kernel_log()
+        _lib.kernel_log_clear()
+        _run_case(K, 2, 32, 8, 1500, 64, "int4", "int8", "f16", True)  # INT4 keys: not the ring
+        assert _lib.kernel_log()[0].startswith("decode_attn_partial_mfma_k<4, 8, 128, 64"), _lib.kernel_log()
