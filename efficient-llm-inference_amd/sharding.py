@@ -318,9 +318,13 @@ def quantize_tokens_batch_sharded(x_local, kind: str, eps: float = 1e-8, out: "S
     ``[B_local,H,T,D]`` tensors) of a slice whose batch is split over the ranks, with the scale of
     the WHOLE batch (reference ops.py:27,48: one ``abs().max()`` per ``[B,H,1,D]`` slice), layer chunk by layer chunk:
 
-        abs-max of the chunk's local rows (HIP, plain loads: the rows stay in the Infinity Cache)
+        abs-max of the chunk's local rows (HIP)
         -> all_reduce(MAX) of the chunk's [Gc,T] table (RCCL on a side stream, under the NEXT chunk's abs-max pass)
-        -> quantise the chunk with those abs-max values (HIP; the re-read is served from the cache, not from HBM)
+        -> quantise the chunk with those abs-max values (HIP; the rows are read a SECOND time, at HBM speed: measured,
+           chunks sized to the 256 MiB Infinity Cache did not make the re-read cheaper — see CHUNKS_PER_SET above)
+
+    The two passes are the floor of a slice whose scale crosses ranks: 1.67 x (INT8) / 1.80 x (INT4) the single pass's
+    HBM traffic, each pass at 0.76-0.79 of the 8 TB/s peak on its own bytes (profiles/traffic.json).
 
     Returns ``(q, scales)`` as `kernels.quant_tokens` does for the un-sharded batch: ``q`` holds
     this rank's rows, ``scales`` ``[G,T]`` (stored scales widened to fp32) is identical on every
