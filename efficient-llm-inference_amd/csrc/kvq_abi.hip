@@ -81,7 +81,7 @@ Tunables& tunables() {
     d.gather_rows = 1;
     d.quant_block = 64;
     d.quant_nv = 8;
-    d.attn_mfma_min_nq = 3;
+    d.attn_mfma_min_nq = 1;
     d.attn_mfma_tc = 128;
     d.nt_loads = 1;
     d.quant_nt_stores = -1;

@@ -95,7 +95,7 @@ struct Tunables {
   int64_t quant_lds_pad;         // bytes of unused dynamic LDS on the one-wave quantise launch (caps waves per CU)
   int64_t quant_tile_tpw;        // merged-store tile kernel: tiles per wave 2 | 4 (8-row shapes, fp16); 0 = the one-tile kernel
   int64_t quant_tile_tt;         // tile kernel at head_dim 64: tokens per tile 8 (one row per load instruction) or 4 (two rows); 0 = shipped choice
-  int64_t attn_mfma_min_nq;      // fewest query heads per kv head that take the MFMA kernel at head_dim 128 (default 3)
+  int64_t attn_mfma_min_nq;      // fewest query heads per kv head that take the MFMA kernels at head_dim 64 / 128 (default 1 since round 4; 3 before)
   int64_t attn_mfma_tc;          // tokens per one-wave split of the MFMA kernel: 128 (default) or 64
   int64_t attn_stream_tc;        // tokens per tile of the streaming kernel: 64 (default) or 32
   int64_t attn_stream_slots;     // wave slots the streaming plan fills in one round (default 2048 = 2 per SIMD)
