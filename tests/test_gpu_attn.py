@@ -709,14 +709,15 @@ def test_merge_one_round_trip_equals_chained_merge(K, tunable, case):
                 assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("case", [(2, 32, 8, 1500, 3), (1, 8, 2, 1000, 1), (3, 6, 2, 449, 2), (1, 4, 1, 64, 1), (5, 32, 8, 1024, 1)])
+@pytest.mark.parametrize("case", [(2, 32, 8, 1500, 3), (1, 8, 2, 1000, 1), (3, 6, 2, 449, 2), (1, 4, 1, 64, 1), (5, 32, 8, 1024, 1),
+                                  (2, 32, 8, 1500, 3, 64), (1, 12, 12, 1000, 1, 64), (3, 6, 2, 449, 2, 64)])  # (B, Hq, Hkv, T, tiles per wave[, head_dim])
 def test_merge_by_one_wave_equals_the_workgroup_merge(K, tunable, case):
     """attn_merge_wave (default 1): up to 16 split partials per head at head_dim 128 — what the LDS-staged kernel leaves — are
     merged by ONE WAVE per head (weights by v_readlane, no LDS table, no barrier); 0 = the 256-thread workgroup per head.
     Same operands in the same order: equal output BITS — with and without the new token, fp16 and bf16, through
     decode_attn and through decode_step (whose merge launch also quantise-appends the new token: equal stores and scales)."""
-    B, Hq, Hkv, T, tpw = case
-    D = 128
+    B, Hq, Hkv, T, tpw = case[:5]
+    D = case[5] if len(case) > 5 else 128  # 64 (round 4): the head_dim-64 ring kernel's partials, merge_one_wave<64>
     from efficient_llm_inference_amd import _lib
     tunable("attn_stream_tpw", tpw)
     g = torch.Generator(device="cuda").manual_seed(T + tpw)
