@@ -505,9 +505,10 @@ def _measure_sparse(E, _lib, past, shape, pol, dev, iters=6):
     kern = _kernels_of(lambda: pc.get_kv())
     # get_kv makes one launch per pool (K, then V): the events bind to the K launch; both move the same bytes
     ms = _time_launches(lambda i: pc.get_kv(), iters, warm=1)
-    # a pool's stitch is ceil(blocks / 128) launches (128 block pointers travel in one launch's arguments): the events bind to
-    # the FIRST, which moves min(blocks, 128) blocks; the whole call (2 allocations + every launch of both pools) by wall events
-    first = min(pc.num_blocks(), 128)
+    # a pool is ONE allocation: its stitch is one launch for up to 65,535 blocks (kvq_window_compact adds block * stride in the
+    # kernel; before round 4's last change: 128 block pointers per launch, 4 launches per pool here); the events bind to the K
+    # pool's launch; the whole call (2 allocations + both pools' launches) by wall events
+    first = min(pc.num_blocks(), 65535)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     pc.get_kv()
     ev[0].record()
@@ -517,10 +518,10 @@ def _measure_sparse(E, _lib, past, shape, pol, dev, iters=6):
     torch.cuda.synchronize()
     call_ms = ev[0].elapsed_time(ev[1]) / iters
     rec["paged_get_kv"] = _roofline(kern, 4.0 * first * B * H * pol["block_size"] * D, ms, _DISPATCH_TIMER, blocks=pc.num_blocks(), block_size=pol["block_size"],
-                                    blocks_in_the_timed_launch=first, launches_per_call=2 * -(-pc.num_blocks() // 128),
+                                    blocks_in_the_timed_launch=first, launches_per_call=2 * -(-pc.num_blocks() // 65535),
                                     whole_call={"ms": round(call_ms, 4), "GBps": round(2 * 4.0 * B * H * T * D / (call_ms * 1e-3) / 1e9, 1),
                                                 "what": "PagedKVCache.get_kv(): two output allocations + every stitch launch of the K and V pools, HIP events around the call"},
-                                    what="PagedKVCache.get_kv of ONE layer: the first stitch launch of the K pool (128 blocks)")
+                                    what="PagedKVCache.get_kv of ONE layer: the K pool's stitch launch (every block)")
     del pc
     _free()
     worst = min((v["frac"], k) for k, v in rec.items() if isinstance(v, dict) and "frac" in v and v.get("algorithmic_bytes_per_launch", 0) > 1e9)

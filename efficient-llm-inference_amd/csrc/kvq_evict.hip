@@ -22,6 +22,7 @@ struct CopyArgs {
   uint32_t segs_per_bh;  // 1 when (t,d) is contiguous on both sides, else W (one segment per token)
   int64_t seg_bytes;     // bytes per segment
   uint32_t cps;          // chunks per segment
+  uint32_t one_base;     // 1: ONE allocation, group g starts at in.p[0] + g * isb.g (no 128-pointer limit per launch: a paged pool of thousands of blocks is one launch)
 };
 
 constexpr int kCopyUnroll = 1;  // one 16-byte vector per thread + non-temporal load/store: the fastest copy recipe
@@ -37,8 +38,8 @@ __global__ __launch_bounds__(kBlock) void copy_rows_k(const CopyArgs a) {
   const uint32_t seg = item % a.segs_per_bh;
   const uint32_t bh = item / a.segs_per_bh;
   const uint32_t b = bh / a.H, h = bh - b * a.H;
-  const char* src = reinterpret_cast<const char*>(a.in.p[g]) + (int64_t)b * a.isb.b + (int64_t)h * a.isb.h +
-                    (int64_t)seg * a.isb.t;
+  const char* gsrc = a.one_base ? reinterpret_cast<const char*>(a.in.p[0]) + (int64_t)g * a.isb.g : reinterpret_cast<const char*>(a.in.p[g]);
+  const char* src = gsrc + (int64_t)b * a.isb.b + (int64_t)h * a.isb.h + (int64_t)seg * a.isb.t;
   char* dst = a.out + (int64_t)g * a.osb.g + (int64_t)b * a.osb.b + (int64_t)h * a.osb.h + (int64_t)seg * a.osb.t;
   const int64_t c0 = (int64_t)chunk * kCopyChunk;
   if constexpr (VEC) {
@@ -407,15 +408,20 @@ int kvq_window_compact(const void* in_base, const void* const* in_ptrs, const kv
     return KVQ_E_DIMS;
   }
   const int64_t first_kept_bytes = (d->T - W) * a.isb.t;
+  // more groups than one launch's pointer table holds, all in ONE allocation (a paged pool's blocks): the kernel adds
+  // g * stride itself, up to 65,535 groups per launch (PagedKVCache.get_kv at 32 K tokens: 1 launch per pool instead of 4)
+  a.one_base = (in_base && d->G > kPtrsPerLaunch) ? 1u : 0u;
+  const int64_t per_launch = a.one_base ? 65535 : kPtrsPerLaunch;
 
-  for (int64_t g0 = 0; g0 < d->G; g0 += kPtrsPerLaunch) {
-    const int64_t gn = d->G - g0 < kPtrsPerLaunch ? d->G - g0 : kPtrsPerLaunch;
-    rc = fill_ptrs(a.in, in_base, in_ptrs, g0, gn, a.isb.g, first_kept_bytes, name);
+  for (int64_t g0 = 0; g0 < d->G; g0 += per_launch) {
+    const int64_t gn = d->G - g0 < per_launch ? d->G - g0 : per_launch;
+    rc = fill_ptrs(a.in, in_base, in_ptrs, g0, a.one_base ? 1 : gn, a.isb.g, first_kept_bytes, name);
     if (rc) return rc;
     a.out = static_cast<char*>(out) + g0 * a.osb.g;
     bool vec = a.seg_bytes % 16 == 0 && aligned(a.out, 16) && a.isb.b % 16 == 0 && a.isb.h % 16 == 0 &&
-               a.isb.t % 16 == 0 && a.osb.g % 16 == 0 && a.osb.b % 16 == 0 && a.osb.h % 16 == 0 && a.osb.t % 16 == 0;
-    for (int64_t i = 0; i < gn && vec; ++i) vec = aligned(a.in.p[i], 16);
+               a.isb.t % 16 == 0 && a.osb.g % 16 == 0 && a.osb.b % 16 == 0 && a.osb.h % 16 == 0 && a.osb.t % 16 == 0 &&
+               (!a.one_base || a.isb.g % 16 == 0);
+    for (int64_t i = 0; i < (a.one_base ? 1 : gn) && vec; ++i) vec = aligned(a.in.p[i], 16);
     if (vec)
       KVQ_LAUNCH((copy_rows_k<true>), dim3((unsigned)blocks, (unsigned)gn), dim3(kBlock), 0, st, a);
     else

@@ -210,3 +210,26 @@ def test_gather_4kib_items_equal_the_grid_stride_kernel(E, shape):
             assert torch.equal(outs[0][:, :, :, ok], x[:, :, :, [keep[j] for j in ok]])
     finally:
         _lib.set_tunable("gather_rows", old)
+
+
+def test_paged_cache_with_more_blocks_than_one_pointer_table(E):
+    """A pool of more than 128 blocks (the pointer table one launch carries) is ONE allocation: kvq_window_compact stitches it in
+    one launch, the kernel adding block * stride itself (round 4). 250 full blocks + a ragged one, K and V, against the input."""
+    from efficient_llm_inference_amd import _lib
+    from efficient_llm_inference_amd.cache import PagedKVCache
+    x = torch.randn(2, 3, 1003, 64, device="cuda").half()
+    pc = PagedKVCache(block_size=4, device="cuda", dtype=torch.float16)
+    pc.extend(x, x * 2)
+    assert pc.num_blocks() == 251
+    _lib.kernel_log_clear()
+    k, v = pc.get_kv()
+    torch.cuda.synchronize()
+    assert _lib.kernel_log() == ["copy_rows_k<true>"]
+    assert torch.equal(k, x) and torch.equal(v, x * 2)
+    # the pointer-list form (separately allocated tensors) still goes 128 per launch: 130 tensors, window of 5 tokens
+    from efficient_llm_inference_amd import kernels as K
+    xs = [torch.randn(1, 2, 9, 8, device="cuda").half() for _ in range(130)]
+    out = torch.empty(130, 1, 2, 5, 8, device="cuda", dtype=torch.float16)
+    K.window_compact(xs, out, 5)
+    torch.cuda.synchronize()
+    assert all(torch.equal(out[i], xs[i][:, :, -5:]) for i in range(130))
