@@ -176,3 +176,29 @@ def test_bench_line_carries_the_contract_fields(tmp_path):
     assert c["max_rel_err_vs_gpu"] == 0.0 and c["eviction"]["pool_value"] > 0
     assert all(v["bit_exact"] and v["max_rel_err"] == 0.0 for k, v in c["parity"].items() if k != "sample"), c["parity"]
     assert j["run_s"] < 200
+
+
+def test_usable_cores_reads_the_cgroup_quota(monkeypatch):
+    """oracle/hostcpu.py (the cpu_baseline leg's pool size): a CFS quota of 16 cores on a 256-core machine — cgroup v2's
+    `cpu.max` = "1600000 100000", what the GPU box reports — caps the usable cores at 16; "max" and v1's -1 mean no quota; the
+    throttle counters come from cpu.stat. Files are faked: the container this suite runs in has no quota."""
+    from oracle import hostcpu
+    files = {"/proc/self/cgroup": "0::/process_api/abc\n", "/sys/fs/cgroup/cpu.max": "1600000 100000",
+             "/sys/fs/cgroup/cpu.stat": "usage_usec 5\nnr_periods 100\nnr_throttled 7\nthrottled_usec 1234\n"}
+    monkeypatch.setattr(hostcpu, "_read", lambda p: files.get(p))
+    monkeypatch.setattr(hostcpu.os, "cpu_count", lambda: 256)
+    monkeypatch.setattr(hostcpu.os, "sched_getaffinity", lambda pid: set(range(256)), raising=False)
+    monkeypatch.delenv("KVQ_CPU_BASELINE_THREADS", raising=False)
+    u = hostcpu.usable_cores()
+    assert u == {"machine": 256, "affinity": 256, "quota": 16.0, "usable": 16, "override": None}
+    assert hostcpu.throttle_counters() == (100, 7, 1234)
+    files["/sys/fs/cgroup/cpu.max"] = "max 100000"
+    assert hostcpu.usable_cores()["usable"] == 256 and hostcpu.quota_cores() is None
+    # cgroup v1: quota / period files of the cpu controller; -1 = unlimited; a nested, tighter group wins
+    files.clear()
+    files.update({"/proc/self/cgroup": "4:cpu,cpuacct:/docker/xyz\n", "/sys/fs/cgroup/cpu/docker/xyz/cpu.cfs_quota_us": "250000",
+                  "/sys/fs/cgroup/cpu/docker/xyz/cpu.cfs_period_us": "100000", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us": "-1",
+                  "/sys/fs/cgroup/cpu/cpu.cfs_period_us": "100000"})
+    assert hostcpu.quota_cores() == 2.5 and hostcpu.usable_cores()["usable"] == 2
+    monkeypatch.setenv("KVQ_CPU_BASELINE_THREADS", "5")
+    assert hostcpu.usable_cores()["usable"] == 5
