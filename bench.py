@@ -782,7 +782,7 @@ def run_attn(args, rank, world, dev):
     kk, vk = MODE_KINDS[mode]
     torch.manual_seed(42 + rank)
     qc = E.QuantizedKVCache(n_layers=L, mode=mode, device="cuda", compute_dtype=torch.float16)
-    qc.reserve(T)
+    qc.reserve(T + int(os.environ.get("KVQ_BENCH_TCAP_PAD", "0")))  # (experiment knob: store rows off their power-of-two stride)
     for g0 in range(0, L, 4):  # quantise 4 layers at a time: bounded fp16 scratch
         n = min(4, L - g0)
         qc._k.append([torch.randn(B, Hkv, T, D, device=dev, dtype=torch.float16) for _ in range(n)], g0=g0)

@@ -17,6 +17,8 @@ What changed underneath (MI355X-first, results identical):
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -120,6 +122,19 @@ def dequantize_int4_per_tensor_packed(packed: torch.Tensor, scale: torch.Tensor,
 # ----------------------------------------------------------------------------- persistent store
 
 
+def _skewed_capacity(n: int) -> int:
+    """The smallest capacity >= n that is 8 more than a multiple of 16 tokens. A store's (batch row, kv head) rows are
+    ``Tcap * Dq`` bytes apart; the attention kernels' waves walk 64 of those rows in lockstep at the same relative offset, and the
+    memory controller's channel choice repeats with the row stride: measured on decode attention over a Llama-3-8B batch-8
+    store of 16,384 tokens (profiles/r04h_attn_store_capacity_skew.txt), a power-of-two Tcap (2 MiB INT8 rows) takes 39.5 us per
+    layer call, Tcap = 16384 + 8 (rows 1 KiB further apart) 38.5, + 64 43.4, + 128 41.4 — every capacity that is 8 mod 16 tokens
+    measured 38.5-38.7, every multiple of 64 beyond the power of two 39.6-43.4. Quantise and dequantise do not care
+    (profiles/r04a_quant_stride_table.md)."""
+    if os.environ.get("KVQ_STORE_CAP_EXACT"):  # measurement knob: the capacity as asked for (the sweep behind the numbers above)
+        return n
+    return (n + 7) // 16 * 16 + 8
+
+
 class _KVStore:
     """One quantised KV set in HBM: ``q [G,B,H,Tcap,Dq]`` + stored scales ``[G,Tcap]`` (fp32 view
     of the input-dtype value). G groups never share scales (layer x K|V); all groups hold the
@@ -150,7 +165,7 @@ class _KVStore:
         if self.B is None or T <= self.cap:
             self._want = max(self._want, T)
             return
-        new_cap = max(T, 2 * self.cap, 16)
+        new_cap = _skewed_capacity(max(T, 2 * self.cap, 16))
         Dq = packed_dim(self.kind, self.D)
         q = torch.empty(self.G, self.B, self.H, new_cap, Dq, dtype=QDTYPE[self.kind], device=self.device)
         sc = torch.zeros(self.G, new_cap, dtype=torch.float32, device=self.device)
