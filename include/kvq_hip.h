@@ -153,7 +153,8 @@ int kvq_quant_tokens_from_absmax(int bits, const void* in_base, const void* cons
 /* Replaces trim_kv_sliding_window (src/cache/implementations.py:124-140), materialised:
  * out[g,b,h,0:W,:] = in[g,b,h,T-W:T,:] with W = min(window, T). The reference returns views
  * and leaves the byte movement to the next torch.cat; a persistent buffer must compact.
- * in and out must not overlap. elem_size is 2 or 4 bytes. */
+ * in and out must not overlap. elem_size is 2 or 4 bytes. A pointer list goes 128 groups per launch; a single base with
+ * in_st->g (one allocation: e.g. a paged pool's blocks) is ONE launch for up to 65,535 groups. */
 int kvq_window_compact(const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st,
                        void* out, const kvq_strides_t* out_st, int elem_size, int64_t window,
                        const kvq_dims_t* dims, void* stream);
