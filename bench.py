@@ -475,7 +475,7 @@ def run_decode(args, rank, world, dev):
 
 # --------------------------------------------------------------------------------------------- eviction (configs[4])
 
-def _measure_sparse(E, _lib, past, shape, pol, dev, iters=6):
+def _measure_sparse(past, shape, pol, iters=6):
     """Scope row N3 on tensors that are already resident: every index-select policy of the reference (implementations.py:143-292)
     through its public function = ONE row-gather launch over the whole tuple (+ the output allocation and the index upload),
     and PagedKVCache.get_kv (implementations.py:82-106) of one layer's cache. Algorithmic bytes: 4 per kept element (2 read +
@@ -593,7 +593,7 @@ def measure_evict(name, dev, rank, world, steps, warmup, with_sparse=None):
     }
     if with_sparse is not None:
         try:
-            rec["sparse"] = _measure_sparse(E, _lib, past, (L, B, H, T, D), with_sparse, dev)
+            rec["sparse"] = _measure_sparse(past, (L, B, H, T, D), with_sparse)
         except Exception as exc:  # noqa: BLE001 — a sub-record never costs the record it rides on
             import traceback
             traceback.print_exc(file=sys.stderr)
