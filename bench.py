@@ -653,9 +653,8 @@ def measure_sharded_quant(name, dev, rank, world, steps, warmup):
     outs = [sharding.ShardedQuantBuffers(k, "int8"), sharding.ShardedQuantBuffers(v, "int4")]
 
     def run(two_phase):
-        def step():
-            sharding.quantize_tokens_batch_sharded(k, "int8", out=outs[0], two_phase=two_phase)
-            sharding.quantize_tokens_batch_sharded(v, "int4", out=outs[1], two_phase=two_phase)
+        def step():  # K and V together: ONE abs-max launch and ONE collective when the [2L,T] table is small (a decode append)
+            sharding.quantize_kv_batch_sharded(k, v, ("int8", "int4"), outs=outs, two_phase=two_phase)
 
         kernels = _kernels_of(step)
         for _ in range(warmup):
@@ -687,12 +686,17 @@ def measure_sharded_quant(name, dev, rank, world, steps, warmup):
         "frac_of_hbm_peak_per_gpu": round(step_bytes / world / (elapsed / steps) / 1e9 / HBM_PEAK_GBPS, 4),
         "kernels": kernels,
         "config": {"workload": name, "shape_L_Bglobal_H_T_D": [L, Bg, H, T, D], "batch_rows_per_rank": Bl,
-                   "step": ("per layer chunk: kvq_absmax_tokens -> all_reduce(MAX) [Lc,T] fp32 (side stream) -> "
-                            "kvq_quant_tokens_from_absmax; K (INT8) then V (INT4)") if world > 1 else
+                   "step": (("K + V together: ONE kvq_absmax_tokens over the 2L tensors -> ONE all_reduce(MAX) [2L,T] fp32 -> "
+                             "kvq_quant_tokens_from_absmax of K (INT8) and of V (INT4)") if sharding.kv_joint_table_ok(L, T) else
+                            ("per layer chunk: kvq_absmax_tokens -> all_reduce(MAX) [Lc,T] fp32 (side stream) -> "
+                             "kvq_quant_tokens_from_absmax; K (INT8) then V (INT4)")) if world > 1 else
                            "one rank, nothing to exchange: kvq_quant_i8_tokens / kvq_quant_i4_tokens, ONE pass (see two_phase)",
-                   "layer_chunks": outs[0].n_chunks, "collective": "all_reduce(MAX)", "collective_backend": sharding.backend() or "none (1 rank)",
+                   "layer_chunks": outs[0].n_chunks, "kv_joint_table": sharding.kv_joint_table_ok(L, T),
+                   "collectives_per_step": 1 if sharding.kv_joint_table_ok(L, T) else 2 * outs[0].n_chunks,
+                   "collective": "all_reduce(MAX)", "collective_backend": sharding.backend() or "none (1 rank)",
                    "collective_bytes_per_step": 2 * L * T * 4, "bytes_per_step_single_pass": int(step_bytes),
-                   "parallelism": f"batch rows sharded x{world}; one all_reduce(MAX) per layer chunk, set and step",
+                   "parallelism": f"batch rows sharded x{world}; " + ("one all_reduce(MAX) per step (K + V tables joined)" if sharding.kv_joint_table_ok(L, T)
+                                                                    else "one all_reduce(MAX) per layer chunk, set and step"),
                    "timing_reduction_backend": sharding.backend()},
     }
     if phases is not None:

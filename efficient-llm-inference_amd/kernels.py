@@ -37,8 +37,41 @@ def packed_dim(kind: str, D: int) -> int:
     return D if kind == "int8" else (D + 1) // 2
 
 
+class TensorGroups:
+    """The G separately addressed ``[B,H,T,D]`` tensors of one launch with the pointer table already built: the
+    concatenation of stacked ``[Gi,B,H,T,D]`` tensors that share shape, dtype and strides (e.g. a decode step's K and V
+    sets, `sharding.quantize_kv_batch_sharded`) without 2G Python views and ``data_ptr()`` calls per step. Accepted
+    wherever a tensor list is; holds the tensors alive."""
+
+    def __init__(self, stacked: Sequence[torch.Tensor]):
+        first = stacked[0]
+        for t in stacked:
+            if t.dim() != 5:
+                raise _lib.KvqError(f"kvq: expected [G,B,H,T,D] tensors, got shape {tuple(t.shape)}")
+            require_gpu(t, "input")
+            if t.shape[1:] != first.shape[1:] or t.dtype != first.dtype or t.stride() != first.stride() or t.device != first.device:
+                raise _lib.KvqError("kvq: all tensors of one launch must share shape, dtype, strides and device")
+        if first.size(4) > 1 and first.stride(4) != 1:
+            raise _lib.KvqError("kvq: last dim must be contiguous")
+        step = first.stride(0) * first.element_size()
+        ptrs = [t.data_ptr() + g * step for t in stacked for g in range(t.size(0))]
+        if len(ptrs) > 256:
+            raise _lib.KvqError("kvq: more than 256 tensors in one call")
+        _, sb, sh, st, _ = first.stride()
+        self.arr, self.strides = _lib.ptr_array(ptrs), KvqStrides(0, sb, sh, st)
+        self.dims, self.dtype, self.device, self.keep = (len(ptrs),) + tuple(first.shape[1:]), first.dtype, first.device, list(stacked)
+        self.key = tuple((t.data_ptr(), t.size(0)) for t in stacked) + (first.stride(), first.shape[1:], first.dtype)
+
+    @staticmethod
+    def key_of(stacked):
+        first = stacked[0]
+        return tuple((t.data_ptr(), t.size(0)) for t in stacked) + (first.stride(), first.shape[1:], first.dtype)
+
+
 def _in_views(x: TensorOrList):
     """-> (base_ptr|None, ptr_array|None, strides, (G,B,H,T,D), dtype, device, keepalive)"""
+    if isinstance(x, TensorGroups):
+        return None, x.arr, x.strides, x.dims, x.dtype, x.device, x
     if isinstance(x, torch.Tensor):
         if x.dim() != 5:
             raise _lib.KvqError(f"kvq: expected [G,B,H,T,D], got shape {tuple(x.shape)}")

@@ -276,6 +276,7 @@ def all_reduce_absmax(table: torch.Tensor, force: bool = False) -> torch.Tensor:
 # short launches per set cost more than they save — so: ONE chunk on a single rank (nothing to overlap), CHUNKS_PER_SET
 # chunks when a collective has to hide. KVQ_SHARD_CHUNK_BYTES overrides (A-B runs).
 CHUNKS_PER_SET = 4
+SMALL_TABLE_BYTES = int(os.environ.get("KVQ_SHARD_SMALL_TABLE_BYTES", str(16 << 10)))  # (0: per set and per layer chunk, as round 3 — A-B runs); [G,T] fp32 tables up to this size are exchanged whole (and K + V together: quantize_kv_batch_sharded)
 CHUNK_BYTES = int(os.environ.get("KVQ_SHARD_CHUNK_BYTES", "0"))  # 0 = by rank count (above)
 
 
@@ -301,6 +302,10 @@ class ShardedQuantBuffers:
             chunk_bytes = CHUNK_BYTES
         if chunk_bytes > 0:
             self.groups_per_chunk = max(1, min(G, chunk_bytes // per_group))
+        elif G * T * 4 <= SMALL_TABLE_BYTES and not force_overlap:
+            # a decode append (T = 1) or a few tokens: the [G,T] table is a few hundred bytes, its all_reduce is pure latency
+            # and there is no abs-max pass long enough to hide it under — ONE chunk, ONE collective
+            self.groups_per_chunk = G
         else:
             self.groups_per_chunk = G if (ws == 1 and not force_overlap) else max(1, -(-G // CHUNKS_PER_SET))
         self.chunks = [(g0, min(G, g0 + self.groups_per_chunk)) for g0 in range(0, G, self.groups_per_chunk)]
@@ -378,3 +383,52 @@ def quantize_tokens_batch_sharded(x_local, kind: str, eps: float = 1e-8, out: "S
         torch.cuda.current_stream(out.q.device).wait_event(out.ev_reduced[pending])
         quant(pending)
     return out.q, out.scales
+
+
+def kv_joint_table_ok(G: int, T: int) -> bool:
+    """Does a K + V pair of G-tensor sets with T tokens take the joint path of :func:`quantize_kv_batch_sharded`?
+    (2G tensors fit the 128-entry pointer table of ONE launch; the [2G,T] fp32 table is small enough that its exchange is latency.)"""
+    return 2 * G <= 128 and 2 * G * T * 4 <= SMALL_TABLE_BYTES
+
+
+def quantize_kv_batch_sharded(k_local, v_local, kinds, eps: float = 1e-8, outs=None, two_phase: bool = None):
+    """One decode step's (or a short chunk's) K AND V slices of a batch that is split over the ranks, together:
+
+        ONE abs-max launch over the 2G tensors of both sets -> ONE all_reduce(MAX) of the [2G,T] table -> two quantise launches
+
+    instead of two abs-max launches and two collectives (`quantize_tokens_batch_sharded` per set, which on several ranks also
+    cuts each set into layer chunks to hide the collective under the next chunk's abs-max pass — right for a prefill chunk,
+    wrong for a decode append: its table is `2 * L * 4` bytes, its collectives are pure latency, and fewer of them is the
+    only lever: xGMI all_reduce latency, not bandwidth). Taken when the joint table is at most SMALL_TABLE_BYTES; larger
+    slices fall back to the per-set pipeline. Returns ``((qk, k_scales), (qv, v_scales))``, bit-identical to the per-set calls
+    and to the un-sharded quantise (reference ops.py:27,48: one scale per [B,H,1,D] slice of the WHOLE batch).
+    ``outs``: a pair of ShardedQuantBuffers to reuse."""
+    from . import kernels as K
+    if outs is None:
+        outs = (ShardedQuantBuffers(k_local, kinds[0]), ShardedQuantBuffers(v_local, kinds[1]))
+    ok, ov = outs
+    G, B, H, T, D = ok.shape
+    _, ws = world()
+    if two_phase is None:
+        two_phase = ws > 1
+    k0, v0 = k_local[0], v_local[0]
+    joint = (two_phase and kv_joint_table_ok(G, T) and ov.shape == ok.shape and len(k_local) == G and len(v_local) == G
+             and k0.dtype == v0.dtype and k0.stride() == v0.stride())  # one launch = one dtype and one stride triple
+    if not joint:
+        return (quantize_tokens_batch_sharded(k_local, kinds[0], eps, ok, two_phase),
+                quantize_tokens_batch_sharded(v_local, kinds[1], eps, ov, two_phase))
+    if getattr(ok, "joint", None) is None or ok.joint.shape != (2 * G, T):
+        ok.joint = torch.empty(2 * G, T, dtype=torch.float32, device=ok.q.device)
+    if isinstance(k_local, torch.Tensor) and isinstance(v_local, torch.Tensor):
+        # 2G separately addressed [B,H,T,D] tensors, one launch; the pointer table is arithmetic on the two bases and is
+        # kept while the caller hands in the same two buffers (a serving loop's staging tensors)
+        both = getattr(ok, "joint_in", None)
+        if both is None or both.key != K.TensorGroups.key_of((k_local, v_local)):
+            both = ok.joint_in = K.TensorGroups((k_local, v_local))
+    else:
+        both = list(k_local) + list(v_local)  # the legacy-tuple form (per-layer tensors)
+    K.absmax_tokens(both, ok.joint)
+    all_reduce_absmax(ok.joint)
+    K.quant_tokens_with_absmax(k_local, ok.joint[:G], kinds[0], eps, q=ok.q, scales=ok.scales)
+    K.quant_tokens_with_absmax(v_local, ok.joint[G:], kinds[1], eps, q=ov.q, scales=ov.scales)
+    return (ok.q, ok.scales), (ov.q, ov.scales)

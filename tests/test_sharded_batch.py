@@ -23,6 +23,7 @@ from tests.conftest import ROOT
 from tests.util import bits, odt, seeded_kv, to_numpy, to_torch
 
 SHAPE = (3, 5, 4, 9, 64)  # G, B, H, T, D: 5 batch rows over 2 ranks = 3 + 2
+APPEND = (6, 5, 8, 1, 128)  # a decode step's K (or V) slices of 6 layers, batch 5
 
 
 def _free_port():
@@ -119,10 +120,28 @@ def test_split_phases_equal_fused_kernels(shape, dtype):
         assert torch.equal(store, q) and torch.equal(scales, sc)
 
 
+def _count_calls(sharding, monkeypatch=None):
+    """Count the abs-max launches, table exchanges and quantise launches `sharding` makes from here on."""
+    from efficient_llm_inference_amd import kernels as K
+    calls = {"absmax": 0, "all_reduce": 0, "quant": 0}
+
+    def counted(fn, key):
+        def wrapper(*a, **kw):
+            calls[key] += 1
+            return fn(*a, **kw)
+        return wrapper
+
+    setter = monkeypatch.setattr if monkeypatch is not None else setattr
+    setter(K, "absmax_tokens", counted(K.absmax_tokens, "absmax"))
+    setter(K, "quant_tokens_with_absmax", counted(K.quant_tokens_with_absmax, "quant"))
+    setter(sharding, "all_reduce_absmax", counted(sharding.all_reduce_absmax, "all_reduce"))
+    return calls
+
+
 def _gpu_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    from efficient_llm_inference_amd import sharding
+    from efficient_llm_inference_amd import _lib, sharding
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     # both ranks share the one GPU of the box: RCCL refuses duplicate devices, gloo carries the table
@@ -136,6 +155,14 @@ def _gpu_worker(rank, world, port, q):
             for kind in ("int8", "int4"):
                 qq, sc = sharding.quantize_tokens_batch_sharded(mine, kind)
                 res[(dtype, kind)] = (to_numpy(qq), to_numpy(sc))
+        # a decode append: K and V of one token, ONE abs-max launch over both sets and ONE exchange of the joint table
+        xk, xv = _batch("f16", APPEND), _batch("f16", APPEND)[::-1].copy()
+        rows = sharding.shard_batch_rows(APPEND[1])
+        mk, mv = (to_torch(np.ascontiguousarray(a[:, rows.start:rows.stop]), "f16") for a in (xk, xv))
+        calls = _count_calls(sharding)
+        (qk, sk), (qv, sv) = sharding.quantize_kv_batch_sharded(mk, mv, ("int8", "int4"))
+        torch.cuda.synchronize()
+        res["append"] = (to_numpy(qk), to_numpy(sk), to_numpy(qv), to_numpy(sv), dict(calls))
         q.put((rank, backend, res))
     finally:
         sharding.shutdown()
@@ -162,6 +189,14 @@ def test_sharded_batch_two_processes_share_gpu():
             assert np.array_equal(got, q_ref), (dtype, kind)
             for r in range(2):
                 assert np.array_equal(out[r][2][(dtype, kind)][1].view(np.uint32), s32_ref.view(np.uint32)), (dtype, kind, r)
+    xk, xv = _batch("f16", APPEND), _batch("f16", APPEND)[::-1].copy()
+    for i, (x, kind) in enumerate(((xk, "int8"), (xv, "int4"))):
+        q_ref, _, s32_ref = O.quantize_tokens(x, kind, dtype=odt("f16"))
+        assert np.array_equal(np.concatenate([out[0][2]["append"][2 * i], out[1][2]["append"][2 * i]], axis=1), q_ref), kind
+        for r in range(2):
+            assert np.array_equal(out[r][2]["append"][2 * i + 1].view(np.uint32), s32_ref.view(np.uint32)), (kind, r)
+    for r in range(2):  # per rank, for the two sets: ONE abs-max launch, ONE exchange, two quantise launches
+        assert out[r][2]["append"][4] == {"absmax": 1, "all_reduce": 1, "quant": 2}, out[r][2]["append"][4]
 
 
 def _rccl_worker(port, q):
@@ -238,3 +273,50 @@ def test_single_rank_takes_one_pass_and_equals_the_two_phases(kind):
         assert np.array_equal(to_numpy(qq), q_ref) and np.array_equal(to_numpy(sc).view(np.uint32), s32_ref.view(np.uint32)), (two_phase, logs)
     assert len(logs[None]) == 1 and logs[None][0].startswith("quant_wide_k<"), logs
     assert [k.rsplit(", ", 1)[-1] for k in logs[True]] == ["1>", "2>"] and all(k.startswith("quant_tile_k<") for k in logs[True]), logs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [APPEND, (32, 5, 8, 1, 128), (4, 5, 3, 5, 24), (64, 6, 2, 2, 64)])
+@pytest.mark.parametrize("as_list", [False, True])
+def test_joint_kv_append_equals_the_per_set_calls(shape, as_list, monkeypatch):
+    """`quantize_kv_batch_sharded`: K and V of a decode step (or a few tokens) share ONE abs-max launch and ONE exchange.
+    Same bytes and stored scales as the per-set two-phase calls and as the oracle on the un-sharded slice; reused buffers;
+    a pair whose strides differ, or whose table is large, falls back to the per-set pipeline."""
+    from efficient_llm_inference_amd import _lib, sharding
+    G = shape[0]
+    xk, xv = _batch("f16", shape), (_batch("f16", shape)[::-1] * np.float16(0.5)).copy()
+    tk, tv = to_torch(xk, "f16"), to_torch(xv, "f16")
+    if as_list:  # the legacy-tuple form: separately allocated per-layer tensors
+        tk, tv = [t.clone() for t in tk], [t.clone() for t in tv]
+    outs = (sharding.ShardedQuantBuffers(tk, "int8"), sharding.ShardedQuantBuffers(tv, "int4"))
+    assert outs[0].n_chunks == 1 and sharding.kv_joint_table_ok(G, shape[3])
+    calls = _count_calls(sharding, monkeypatch)
+    for _ in range(2):
+        (qk, sk), (qv, sv) = sharding.quantize_kv_batch_sharded(tk, tv, ("int8", "int4"), outs=outs, two_phase=True)
+        torch.cuda.synchronize()
+    assert calls == {"absmax": 2, "all_reduce": 2, "quant": 4}, calls  # per call: ONE abs-max launch, ONE exchange
+    for x, kind, qq, sc in ((xk, "int8", qk, sk), (xv, "int4", qv, sv)):
+        q_ref, _, s32_ref = O.quantize_tokens(x, kind, dtype=odt("f16"))
+        assert np.array_equal(to_numpy(qq), q_ref), kind
+        assert np.array_equal(to_numpy(sc).view(np.uint32), s32_ref.view(np.uint32)), kind
+    # fallbacks: one rank with nothing to exchange (two_phase None -> the single-pass kernels), and a strided V
+    _lib.kernel_log_clear()
+    (qk2, sk2), (qv2, sv2) = sharding.quantize_kv_batch_sharded(tk, tv, ("int8", "int4"), two_phase=None)
+    torch.cuda.synchronize()
+    assert len(_lib.kernel_log()) == 2 and torch.equal(qk2, qk) and torch.equal(qv2, qv) and torch.equal(sv2, sv) and torch.equal(sk2, sk)
+    if not as_list:
+        wide = torch.zeros(shape[:3] + (shape[3] + 3, shape[4]), dtype=torch.float16, device="cuda")
+        wide[:, :, :, :shape[3]] = tv
+        calls.update(absmax=0, all_reduce=0, quant=0)
+        (qk3, sk3), (qv3, sv3) = sharding.quantize_kv_batch_sharded(tk, wide[:, :, :, :shape[3]], ("int8", "int4"), two_phase=True)
+        torch.cuda.synchronize()
+        assert calls["absmax"] == 2 and torch.equal(qv3, qv) and torch.equal(sv3, sv) and torch.equal(qk3, qk), calls
+
+
+def test_small_tables_are_exchanged_whole():
+    """The chunk plan: a table of at most SMALL_TABLE_BYTES is one chunk (one collective) whatever the rank count;
+    the joint K + V path needs the pair's table under the same bound and 2G tensors within one launch's pointer table."""
+    from efficient_llm_inference_amd import sharding
+    assert sharding.kv_joint_table_ok(32, 1) and sharding.kv_joint_table_ok(64, 32)
+    assert not sharding.kv_joint_table_ok(65, 1) and not sharding.kv_joint_table_ok(32, 16384)
+    assert 2 * 32 * 64 * 4 <= sharding.SMALL_TABLE_BYTES < 32 * 512 * 4  # a 512-token prefill chunk keeps its layer-chunk pipeline
