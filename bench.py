@@ -196,6 +196,42 @@ def _traffic(workload, key):
         return None
 
 
+def _device_state(step, n_steps=600):
+    """Clocks / power / temperatures of the card WHILE it runs `n_steps` of the headline step (enqueued first, read while the
+    queue drains): the numbers that differ between two boxes of the pool when the same stream kernel lands 7 % apart
+    (pool 0.74 on one box, 0.78 on another). `rocm-smi --json` in a child process (sysfs reads, no compute
+    context) + torch's amdsmi-backed readers; every failure is reported, none is fatal."""
+    import subprocess
+    rec = {"what": f"read while {n_steps} headline steps were queued on the GPU (outside the timed region)"}
+    t0 = time.perf_counter()
+    for i in range(n_steps):
+        step(i)
+    rec["enqueue_s"] = round(time.perf_counter() - t0, 3)
+    try:
+        idx = torch.cuda.current_device()
+        out = subprocess.run(["rocm-smi", "-d", str(idx), "--showclocks", "--showpower", "--showtemp", "--showperflevel", "--json"],
+                             capture_output=True, text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+        for key, val in card.items():
+            k = key.lower()
+            if "clock speed" in k:
+                rec[key.split()[0] + "_mhz"] = int("".join(ch for ch in val if ch.isdigit()) or 0)
+            elif "temperature" in k or "power (w)" in k or "performance level" in k:
+                rec[key] = val
+    except Exception as exc:  # noqa: BLE001 - a missing tool must not cost the bench line
+        rec["rocm_smi_error"] = repr(exc)[:160]
+    for name in ("clock_rate", "power_draw", "temperature", "utilization"):
+        try:
+            rec["torch_" + name] = getattr(torch.cuda, name)()
+        except Exception as exc:  # noqa: BLE001
+            rec["torch_" + name] = repr(exc)[:80]
+    still_busy = not torch.cuda.current_stream().query()
+    torch.cuda.synchronize()
+    rec["gpu_still_busy_when_read"] = bool(still_busy)
+    rec["read_s"] = round(time.perf_counter() - t0, 3)
+    return rec
+
+
 def _free():
     import gc
     gc.collect()
@@ -1217,6 +1253,7 @@ def run_dequant(args, rank, world, dev, backend):
     for name, tensors in (("k", [k for k, _ in past]), ("v", [v for _, v in past])):
         kind = getattr(caches[0], "_" + name).kind
         quant_info[f"quant_{kind}"].update(_quant_variants(tensors, kind, n_elts, dev))
+    device_state = _device_state(step) if rank == 0 else None
     mark("extended_samples_and_public_api")
 
     gpu_check = None
@@ -1331,6 +1368,7 @@ def run_dequant(args, rank, world, dev, backend):
             if Tc < T:
                 line["cpu_baseline"]["tokens_sampled"] = f"first {Tc} of {T} tokens (per-token work: the rates do not depend on T)"
             mark("cpu_baseline")
+        line["device_state"] = device_state
         line["run_s"] = round(time.perf_counter() - t_run0, 2)
         phases["startup_before_workload"] = round(t_run0 - _T_PROCESS0, 2)
         line["phases_s"] = phases

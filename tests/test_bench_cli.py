@@ -176,6 +176,8 @@ def test_bench_line_carries_the_contract_fields(tmp_path):
     assert c["max_rel_err_vs_gpu"] == 0.0 and c["eviction"]["pool_value"] > 0
     assert all(v["bit_exact"] and v["max_rel_err"] == 0.0 for k, v in c["parity"].items() if k != "sample"), c["parity"]
     assert j["run_s"] < 200
+    ds = j["device_state"]  # clocks / power / temperature read while the headline step was queued: never fatal, always present
+    assert isinstance(ds["gpu_still_busy_when_read"], bool) and ("mclk_mhz" in ds or "rocm_smi_error" in ds), ds
 
 
 def test_usable_cores_reads_the_cgroup_quota(monkeypatch):
