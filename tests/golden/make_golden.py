@@ -25,7 +25,10 @@ Groups:
          DynamicCache.from_legacy_cache / to_legacy_cache, which transformers >= 5 removed): the same reference code
          run with a GENERATOR-SIDE adapter that gives DynamicCache those two methods back; only float-independent
          observables are kept (n_new, est_mb, paged alloc / used MB and block counts, the cache length the model saw
-         at every forward, dict key order / value kinds).
+         at every forward, dict key order / value kinds). Part C (round 4): from the same part-B runs, the token fed
+         and the fp32 next-token logits of EVERY forward of every method — the reference's quantised / evicting decode
+         loops as numbers, for a tolerance-level comparison with this package's loops on the GPU (fp32 model; GEMM
+         summation order differs between the CPU run and the card, so not bit-level).
   G8     round-2 additions: window_size == 0 edge of the trims (the reference's ``-0:`` slice keeps
          everything), budget-policy index lists at more lengths, and known-answer tests of the
          quality helpers text_similarity / token_agreement_rate (src/evaluation/quality.py:124-150)
@@ -323,14 +326,22 @@ def gen_benchmarker():
     class Recorder:
         """the model as the reference calls it, noting (new tokens fed, cache length seen) per forward"""
         def __init__(self, m):
-            self.m, self.config, self.calls = m, m.config, []
+            self.m, self.config, self.calls, self.fed, self.logits = m, m.config, [], [], []
         def __call__(self, **kw):
             past = kw.get("past_key_values")
             plen = 0
             if past is not None:
                 plen = int(past.get_seq_length()) if hasattr(past, "get_seq_length") else int(past[0][0].size(2))
             self.calls.append((int(kw["input_ids"].shape[-1]), plen))
-            return self.m(**kw)
+            res = self.m(**kw)
+            # part C: the last token fed and the next-token logits of every forward (one prompt at a time: batch 1)
+            self.fed.append(int(kw["input_ids"][0, -1]))
+            self.logits.append(res.logits[0, -1, :].detach().to(torch.float32).numpy().copy())
+            return res
+        def clear(self):
+            self.calls.clear()
+            self.fed.clear()
+            self.logits.clear()
 
     def kinds(d):  # value kind per key: n None, a NaN, f float, i int, s str
         out = []
@@ -377,8 +388,10 @@ def gen_benchmarker():
     try:
         for method in ("sliding_window", "quant_int8", "quant_int4", "quant_mixed", "paged_attention", "chunked_cache",
                        "prefix_window", "strided_cache", "block_cache", "budget_cache"):
-            rec.calls.clear()
+            rec.clear()
             res = ref.benchmark_method(prompts, method=method, **kw)
+            out[f"C.{method}.fed"] = np.array(rec.fed, dtype=np.int64)
+            out[f"C.{method}.logits"] = np.stack(rec.logits).astype(np.float32)
             out[f"B.{method}.keys"] = np.array(list(res.keys()))
             out[f"B.{method}.kinds"] = np.array([kinds(res)])
             out[f"B.{method}.total_new_tokens"] = np.array([res["total_new_tokens"]], dtype=np.int64)

@@ -5,6 +5,7 @@ import os
 import socket
 import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -235,3 +236,19 @@ def test_fused_attention_rejects_unsupported_variants():
                 FA._fused_attention_forward(plain, None, None, None, sliding_window=128)
         finally:
             FA._ACTIVE = prev
+
+
+def test_g9_part_c_tells_the_methods_apart():
+    """Part C of the fixture (the reference's per-forward logits, tests/golden/make_golden.py::gen_benchmarker) is only a pin
+    if different loops give different numbers: every pair of methods is at least 5 x the GPU test's tolerance apart
+    (tests/test_gpu_benchmarker.py::G9_LOGIT_TOL), and each method's logits are finite with the shape of its call list."""
+    methods = [k.split(".")[1] for k in G9.files if k.startswith("C.") and k.endswith(".logits")]
+    assert len(methods) == 10
+    for m in methods:
+        lg = G9[f"C.{m}.logits"]
+        assert lg.dtype == np.float32 and np.isfinite(lg).all() and lg.shape == (len(G9[f"B.{m}.calls"]), 260)
+        assert len(G9[f"C.{m}.fed"]) == lg.shape[0]
+    for i, a in enumerate(methods):
+        for b in methods[i + 1:]:
+            d = float(np.abs(G9[f"C.{a}.logits"] - G9[f"C.{b}.logits"]).max())
+            assert d > 1e-4, (a, b, d)  # closest pair: quant_int4 / quant_mixed, 3.4e-4

@@ -84,6 +84,8 @@ class CallRecorder:
     def __init__(self, model):
         self.__dict__["m"] = model
         self.__dict__["calls"] = []
+        self.__dict__["fed"] = []  # part C of the fixture: last token fed and fp32 next-token logits of every forward
+        self.__dict__["logits"] = []
 
     def __getattr__(self, name):
         return getattr(self.__dict__["m"], name)
@@ -94,7 +96,15 @@ class CallRecorder:
         if past is not None:
             plen = int(past.get_seq_length()) if hasattr(past, "get_seq_length") else int(past[0][0].size(2))
         self.calls.append((int(kw["input_ids"].shape[-1]), plen))
-        return self.__dict__["m"](*a, **kw)
+        res = self.__dict__["m"](*a, **kw)
+        self.fed.append(int(kw["input_ids"][0, -1]))
+        self.logits.append(res.logits[0, -1, :].detach().to(torch.float32).cpu().numpy().copy())
+        return res
+
+    def clear(self):
+        self.calls.clear()
+        self.fed.clear()
+        self.logits.clear()
 
 
 def value_kinds(d) -> str:
