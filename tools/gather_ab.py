@@ -13,7 +13,46 @@ import torch  # noqa: E402
 from bench import _time_launches  # noqa: E402
 
 
+def patterns():
+    """`--patterns`: WHY is block_old (8 of every 64 tokens) slower than stride 4? The same number of 2 KiB runs (8 consecutive
+    token rows), the same output, only WHERE in its 16 KiB block each run sits:
+      last8      block_old's own list: every run at offset 14 KiB of its block (address bits 11-13 always 111)
+      first8     every run at offset 0
+      rotate     run k at offset (k mod 8) * 2 KiB: the runs cover every residue below 16 KiB equally
+      rows_4     32-token blocks, 4 kept (1 KiB runs, 8 KiB spacing), last-4 and rotated
+    If the policy's fixed offset is what costs, `rotate` runs at the stride-4 rate and first8 = last8."""
+    from efficient_llm_inference_amd import kernels as K
+    dev = torch.device("cuda:0")
+    L, B, H, T, D = 32, 8, 8, 32768, 128
+    torch.manual_seed(42)
+    xs = [torch.randn(B, H, T, D, device=dev, dtype=torch.float16) for _ in range(2 * L)]
+
+    def runs(block, keep, where):
+        idx = []
+        for k, start in enumerate(range(0, T, block)):
+            off = {"last": block - keep, "first": 0, "rotate": (k * keep) % block}[where]
+            idx.extend(range(start + off, start + off + keep))
+        return idx
+
+    cases = {"last8_of_64": runs(64, 8, "last"), "first8_of_64": runs(64, 8, "first"), "rotate8_of_64": runs(64, 8, "rotate"),
+             "last4_of_32": runs(32, 4, "last"), "rotate4_of_32": runs(32, 4, "rotate"),
+             "last16_of_128": runs(128, 16, "last"), "rotate16_of_128": runs(128, 16, "rotate"),
+             "stride_8": list(range(0, T, 8)), "stride_4": list(range(0, T, 4))}
+    for rnd in range(3):
+        for name, keep in cases.items():
+            idx = torch.tensor(keep, dtype=torch.int32, device=dev)
+            out = torch.empty(2 * L, B, H, len(keep), D, dtype=torch.float16, device=dev)
+            ms = _time_launches(lambda i: K.gather_tokens(xs, out, idx), 5, warm=1)
+            avg = sum(ms) / len(ms)
+            print(json.dumps({"round": rnd, "pattern": name, "kept": len(keep), "us": round(avg * 1e3, 1),
+                              "frac": round(4.0 * 2 * L * B * H * len(keep) * D / (avg * 1e-3) / 8e12, 4)}), flush=True)
+            del out
+            torch.cuda.empty_cache()
+
+
 def main():
+    if "--patterns" in sys.argv:
+        return patterns()
     from efficient_llm_inference_amd import _lib
     from efficient_llm_inference_amd import cache as C
     dev = torch.device("cuda:0")
