@@ -1,10 +1,13 @@
 """Pins the C oracle (oracle/kvq_oracle.c — checker + cpu_baseline leg) to the numpy oracle and,
 through the goldens, to the reference. CPU only."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import c_oracle as C
 from oracle import kvq_oracle as O
+from tests.conftest import ROOT
 from tests.util import seeded_kv
 
 
@@ -104,3 +107,19 @@ def test_c_oracle_threaded_entry_points_equal_the_scalar_ones(threads):
             assert np.array_equal(d1.view(np.uint16), dn.view(np.uint16))
         for chunk, keep in ((4, 3), (64, 256), (5, 0)):
             assert np.array_equal(C.chunk_summarize(x[0], chunk, keep).view(np.uint16), C.chunk_summarize(x[0], chunk, keep, threads=threads).view(np.uint16))
+
+
+def test_c_oracle_is_clean_under_sanitizers():
+    """`make -C oracle san`: kvq_oracle.c under AddressSanitizer + UBSan and under ThreadSanitizer, around
+    oracle/san_driver.c — every entry point, 1 thread against 2 / 3 / 8 / 37, ragged and empty shapes, exact-size heap
+    buffers. A report aborts the driver (non-zero exit); threaded results must equal the single-threaded bytes.
+    (GPU sanitizers are not available on the pool: the CPU build is where they run.)"""
+    import subprocess
+    odir = os.path.join(ROOT, "oracle")
+    build = subprocess.run(["make", "-C", odir, "san"], capture_output=True, text=True, timeout=300)
+    assert build.returncode == 0, build.stdout[-1500:] + build.stderr[-1500:]
+    for exe, env in (("san_asan", {"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "halt_on_error=1"}),
+                     ("san_tsan", {"TSAN_OPTIONS": "halt_on_error=1"})):
+        run = subprocess.run([os.path.join(odir, exe)], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
+        assert run.returncode == 0 and "0 mismatches" in run.stdout, (exe, run.stdout[-800:], run.stderr[-3000:])
+        assert "Sanitizer" not in run.stderr, (exe, run.stderr[-3000:])
