@@ -419,7 +419,7 @@ def quantize_kv_batch_sharded(k_local, v_local, kinds, eps: float = 1e-8, outs=N
                 quantize_tokens_batch_sharded(v_local, kinds[1], eps, ov, two_phase))
     if getattr(ok, "joint", None) is None or ok.joint.shape != (2 * G, T):
         ok.joint = torch.empty(2 * G, T, dtype=torch.float32, device=ok.q.device)
-    if isinstance(k_local, torch.Tensor) and isinstance(v_local, torch.Tensor):
+    if isinstance(k_local, torch.Tensor) and isinstance(v_local, torch.Tensor) and k_local.stride() == v_local.stride():
         # 2G separately addressed [B,H,T,D] tensors, one launch; the pointer table is arithmetic on the two bases and is
         # kept while the caller hands in the same two buffers (a serving loop's staging tensors)
         both = getattr(ok, "joint_in", None)
