@@ -311,6 +311,13 @@ def test_joint_kv_append_equals_the_per_set_calls(shape, as_list, monkeypatch):
         (qk3, sk3), (qv3, sv3) = sharding.quantize_kv_batch_sharded(tk, wide[:, :, :, :shape[3]], ("int8", "int4"), two_phase=True)
         torch.cuda.synchronize()
         assert calls["absmax"] == 2 and torch.equal(qv3, qv) and torch.equal(sv3, sv) and torch.equal(qk3, qk), calls
+        # V with the same inner strides but every second layer of a larger stack: still ONE abs-max launch (pointer-list form)
+        twice = torch.zeros((2 * G,) + tuple(shape[1:]), dtype=torch.float16, device="cuda")
+        twice[::2] = tv
+        calls.update(absmax=0, all_reduce=0, quant=0)
+        (qk4, sk4), (qv4, sv4) = sharding.quantize_kv_batch_sharded(tk, twice[::2], ("int8", "int4"), two_phase=True)
+        torch.cuda.synchronize()
+        assert calls == {"absmax": 1, "all_reduce": 1, "quant": 2} and torch.equal(qv4, qv) and torch.equal(sv4, sv) and torch.equal(qk4, qk), calls
 
 
 def test_small_tables_are_exchanged_whole():
