@@ -196,13 +196,13 @@ def _traffic(workload, key):
         return None
 
 
-def _device_state(step, n_steps=600):
+def _device_state(step, n_steps=600, what="headline steps"):
     """Clocks / power / temperatures of the card WHILE it runs `n_steps` of the headline step (enqueued first, read while the
     queue drains): the numbers that differ between two boxes of the pool when the same stream kernel lands 7 % apart
     (pool 0.74 on one box, 0.78 on another). `rocm-smi --json` in a child process (sysfs reads, no compute
     context) + torch's amdsmi-backed readers; every failure is reported, none is fatal."""
     import subprocess
-    rec = {"what": f"read while {n_steps} headline steps were queued on the GPU (outside the timed region)"}
+    rec = {"what": f"read while {n_steps} {what} were queued on the GPU (outside the timed region)"}
     t0 = time.perf_counter()
     for i in range(n_steps):
         step(i)
@@ -629,6 +629,9 @@ def measure_evict(name, dev, rank, world, steps, warmup, with_sparse=None):
                               traffic=_traffic(name, "chunk_pool")),
         "roofline_window": _roofline(k_win, bytes_win, w_ms, _DISPATCH_TIMER, what="trim_kv_sliding_window, materialised"),
     }
+    if rank == 0:  # the card's clocks / power / temperatures under THIS stream kernel (the one that differs most between boxes)
+        rec["device_state"] = _device_state(lambda i: E.chunk_summarize_kv(past, chunk_size=chunk, keep_last=keep), n_steps=40,
+                                            what="chunk_summarize_kv launches (5-6 ms each)")
     if with_sparse is not None:
         try:
             rec["sparse"] = _measure_sparse(past, (L, B, H, T, D), with_sparse)
@@ -667,7 +670,7 @@ def run_evict(args, rank, world, dev):
             "value": rec["value"], "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "dtype_detail": "fp16 in/out, fp32 accumulate", "data": "synthetic", "config": rec["config"],
-            "roofline": rec["roofline"], "roofline_window": rec["roofline_window"],
+            "roofline": rec["roofline"], "roofline_window": rec["roofline_window"], "device_state": rec.get("device_state"),
         }), flush=True)
 
 
