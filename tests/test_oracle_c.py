@@ -121,5 +121,7 @@ def test_c_oracle_is_clean_under_sanitizers():
     for exe, env in (("san_asan", {"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "halt_on_error=1"}),
                      ("san_tsan", {"TSAN_OPTIONS": "halt_on_error=1"})):
         run = subprocess.run([os.path.join(odir, exe)], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
+        if "unexpected memory mapping" in run.stderr:  # the sanitizer runtime against this kernel's address-space randomisation, not a finding
+            run = subprocess.run(["setarch", "-R", os.path.join(odir, exe)], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
         assert run.returncode == 0 and "0 mismatches" in run.stdout, (exe, run.stdout[-800:], run.stderr[-3000:])
         assert "Sanitizer" not in run.stderr, (exe, run.stderr[-3000:])
