@@ -80,6 +80,8 @@ ATTN = {  # name: (L, B, Hq, Hkv, T, D, mode)
     "llama3_8b_decode_attn_seq16k": (32, 1, 32, 8, 16384, 128, "mixed"),
     "llama3_8b_decode_attn_seq16k_b8": (32, 8, 32, 8, 16384, 128, "mixed"),
     "gpt2_decode_attn_seq1k": (12, 1, 12, 12, 1024, 64, "int8"),
+    "llama3_8b_decode_attn_seq1k": (32, 1, 32, 8, 1024, 128, "mixed"),      # short contexts: launch-bound (two kernels per layer call)
+    "llama3_8b_decode_attn_seq2k_b8": (32, 8, 32, 8, 2048, 128, "mixed"),
     "llama2_7b_decode_attn_seq4k_b8": (32, 8, 32, 32, 4096, 128, "mixed"),  # multi-head (one query head per kv head)
     "llama32_1b_decode_attn_seq16k_b8": (16, 8, 32, 8, 16384, 64, "mixed"),  # grouped-query at head_dim 64
 }

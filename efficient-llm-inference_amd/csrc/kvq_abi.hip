@@ -138,6 +138,7 @@ static const TunableKey kTunableKeys[] = {
     {"attn_mfma_tc", &Tunables::attn_mfma_tc, true},
     {"attn_fused", &Tunables::attn_fused, true},
     {"attn_fold", &Tunables::attn_fold, true},
+    {"attn_onepass", &Tunables::attn_onepass, true},
     {"attn_k_i8", &Tunables::attn_k_i8, true},
     {"attn_merge_fast", &Tunables::attn_merge_fast, true},
     {"attn_stream_roll", &Tunables::attn_stream_roll, true},

@@ -51,5 +51,6 @@ namespace kvq {
 #include "attn/ring.inc"
 #include "attn/coal_ab.inc"
 #include "attn/fused_ab.inc"
+#include "attn/onepass_ab.inc"
 #include "attn/merge.inc"
 #include "attn/host.inc"

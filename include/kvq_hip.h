@@ -305,7 +305,8 @@ int64_t kvq_kernel_log(char* buf, int64_t n);
  *               16-token group in the LDS-staged kernel at <= 4 query heads per kv head too), "attn_k_i8" (-1|0|1; tolerance-level
  *               difference), "attn_fused" (one launch per call; refused while the stream is being captured into a
  *               HIP graph: its arrival epoch is a launch argument), "attn_fused_tc" / "attn_fused_nw", "attn_fold" (the merge
- *               INSIDE the LDS-staged kernel's launch, by arrival ticket: 1 = in kvq_decode_step_layers, 2 = kvq_decode_attn too).
+ *               INSIDE the LDS-staged kernel's launch, by arrival ticket: 1 = in kvq_decode_step_layers, 2 = kvq_decode_attn too),
+ *               "attn_onepass" (<= 2,048 stored tokens in ONE launch, one 8-wave workgroup per (batch row, kv head), merge from LDS).
  * Returns 0, or KVQ_E_DIMS for an unknown key / an A-B key in the default library. Process-global. */
 int kvq_set_tunable(const char* key, int64_t value);
 int64_t kvq_get_tunable(const char* key);

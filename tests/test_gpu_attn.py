@@ -943,3 +943,72 @@ def test_decode_attn_lds_staged_kernel_head_dim_64(K, tunable, tpw):
         _lib.kernel_log_clear()
         _run_case(K, 2, 32, 8, 1500, 64, "int4", "int8", "f16", True)  # INT4 keys: not the ring
         assert _lib.kernel_log()[0].startswith("decode_attn_partial_mfma_k<4, 8, 128, 64"), _lib.kernel_log()
+
+
+# ---------------------------------------------------------------------------- one pass (A-B key attn_onepass)
+
+ONEPASS_CASES = [c for c in CASES if c[3] <= 2048 and c[4] in (64, 128) and c[1] // c[2] * c[4] <= 512] + [
+    (1, 12, 12, 1024, 64), (1, 12, 12, 1025, 64), (2, 32, 8, 2048, 128), (1, 8, 8, 1500, 128), (8, 32, 8, 129, 128)]
+
+
+@pytest.mark.ab
+@pytest.mark.parametrize("case", ONEPASS_CASES)
+@pytest.mark.parametrize("kinds", [("int8", "int8"), ("int8", "int4"), ("int4", "int4"), ("int4", "int8")])
+def test_decode_attn_one_pass_matches_oracle(K, tunable, case, kinds):
+    """A-B key attn_onepass: up to 2,048 stored tokens in ONE launch — one 8-wave workgroup per (batch row, kv head), one or
+    two 128-token tiles per wave, merge of the <= 16 slots and of the exact new token from LDS. Same oracle, same tolerance as
+    the two-launch path; the kernel log shows the single kernel."""
+    from efficient_llm_inference_amd import _lib
+    tunable("attn_onepass", 1)
+    for dtype, with_new in (("f16", True), ("f16", False), ("bf16", True)):
+        _lib.kernel_log_clear()
+        _run_case(K, *case, kinds[0], kinds[1], dtype, with_new)
+        log = _lib.kernel_log()
+        assert len(log) == 1 and log[0].startswith("decode_attn_onepass_k<"), log
+
+
+@pytest.mark.ab
+@pytest.mark.parametrize("shape", [(1, 12, 12, 64), (2, 32, 8, 128)])
+@pytest.mark.parametrize("kinds", [("int8", "int8"), ("int8", "int4")])
+def test_one_pass_decode_step_with_a_device_side_token_count(K, tunable, shape, kinds):
+    """The one-pass kernel behind kvq_decode_step_dev (what a captured decode graph replays): one set of launch arguments
+    for every context length up to the bound — here a bound past 1,024 tokens, so two tiles per wave — attention within
+    tolerance, slot T quantised bit-exactly by the launch's two extra workgroups, nothing else touched."""
+    from efficient_llm_inference_amd import _lib
+    tunable("attn_onepass", 1)
+    B, Hq, Hkv, D = shape
+    cap, bound = 1310, 1300
+    rng = np.random.default_rng(Hq * 11 + D)
+    k = rng.standard_normal((1, B, Hkv, cap, D)).astype(np.float16)
+    v = rng.standard_normal((1, B, Hkv, cap, D)).astype(np.float16)
+    kq, _, ks = O.quantize_tokens(k, kinds[0])
+    vq, _, vs = O.quantize_tokens(v, kinds[1])
+    q = rng.standard_normal((B, Hq, D)).astype(np.float16)
+    sm = D ** -0.5
+    qt = to_torch(q)
+    ws = torch.empty(K.decode_attn_workspace_cap(B, Hq, Hkv, cap, D), dtype=torch.float32, device="cuda")
+    t_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for T in (1, 127, 128, 129, 1023, 1024, 1025, 1299):
+        k_store = torch.full((B, Hkv, cap, kq.shape[-1]), 9, dtype=K.QDTYPE[kinds[0]], device="cuda")
+        v_store = torch.full((B, Hkv, cap, vq.shape[-1]), 9, dtype=K.QDTYPE[kinds[1]], device="cuda")
+        k_sc = torch.full((cap,), -1.0, device="cuda")
+        v_sc = torch.full((cap,), -1.0, device="cuda")
+        k_store[:, :, :T] = to_torch(kq[0][:, :, :T])
+        v_store[:, :, :T] = to_torch(vq[0][:, :, :T])
+        k_sc[:T] = to_torch(ks[0][:T])
+        v_sc[:T] = to_torch(vs[0][:T])
+        kn, vn = to_torch(k[0][:, :, T].copy()), to_torch(v[0][:, :, T].copy())
+        out = torch.full_like(qt, float("nan"))
+        plan = K.DecodeStepPlan(qt, k_store, k_sc, kinds[0], v_store, v_sc, kinds[1], 1e-8)
+        t_dev.fill_(T)
+        _lib.kernel_log_clear()
+        K.decode_step_dev(plan, qt, kn, vn, t_dev, bound, out, ws, sm)
+        torch.cuda.synchronize()
+        assert [n.split("<")[0] for n in _lib.kernel_log()] == ["decode_attn_onepass_k"], _lib.kernel_log()
+        ref = O.decode_attention(q, kq[0][:, :, :T], ks[0][:T], kinds[0], vq[0][:, :, :T], vs[0][:T], kinds[1], D, sm,
+                                 k[0][:, :, T].astype(np.float32), v[0][:, :, T].astype(np.float32))
+        got = to_numpy(out).astype(np.float64)
+        assert np.isfinite(got).all() and (np.abs(got - ref) <= TOL["f16"] * (np.abs(ref) + np.abs(ref).max())).all(), T
+        assert np.array_equal(to_numpy(k_store[:, :, :T + 1]), kq[0][:, :, :T + 1]) and np.array_equal(to_numpy(v_store[:, :, :T + 1]), vq[0][:, :, :T + 1]), T
+        assert np.array_equal(to_numpy(k_sc[:T + 1]), ks[0][:T + 1]) and np.array_equal(to_numpy(v_sc[:T + 1]), vs[0][:T + 1])
+        assert int((k_store[:, :, T + 1:] != 9).sum()) == 0 and float((k_sc[T + 1:] + 1.0).abs().sum()) == 0.0
