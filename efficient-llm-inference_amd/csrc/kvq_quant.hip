@@ -1099,6 +1099,48 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
   }
 }
 
+// PHASE 1 for a slice of very few tokens (a batch-sharded DECODE APPEND: T = 1). The tile walk gives every 8-row group its own
+// one-wave workgroup, and all rows / 8 of them end in an atomicMax on the SAME word of the table: device-scope atomics from
+// eight XCDs on one address are served one after the other — 21.5 us for the 8.4 MB of a batch-64 K + V append of 64 tensors
+// (rocprofv3: profiles/r04z_rocprofv3_kernel_stats_shardq_append.csv, quant_tile_k<..., 1>). Here ONE 256-thread workgroup
+// owns a (group, token): 256 / DV rows per pass, 8 independent 16-byte loads per thread in flight, LDS across its 4 waves,
+// then ONE plain store — or a plain max with the word when the caller accumulates (no other workgroup of the launch touches
+// it) — no atomics, and no memset launch in front. The maximum does not depend on the order: same table, bit for bit.
+template <int IDT, int DV>
+__global__ __launch_bounds__(kBlock) void absmax_fewtokens_k(const QuantTileArgs a, const int accumulate) {
+  static_assert(IDT != KVQ_F32, "two-byte inputs");
+  constexpr int D = DV * 8;
+  constexpr int RPP = kBlock / DV;  // rows per pass
+  constexpr int UN = 8;
+  __shared__ uint32_t s_m[kBlock / kWave];
+  const uint32_t tid = threadIdx.x, t = blockIdx.x, g = blockIdx.y;
+  const uint32_t piece = tid % DV, slot = tid / DV;
+  const char* base = reinterpret_cast<const char*>(a.in.p[g]) + (int64_t)t * (D * 2) + piece * 16u;
+  uint32_t m = 0u;
+  for (uint32_t r0 = slot; r0 < a.rows; r0 += (uint32_t)(RPP * UN)) {
+    Vec8<IDT> x[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const uint32_t r = r0 + (uint32_t)(u * RPP);
+      x[u].w = u32x4{0u, 0u, 0u, 0u};
+      if (r < a.rows) x[u].w = *reinterpret_cast<const u32x4*>(base + (int64_t)r * a.is_h);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) m = max(m, x[u].absmax_bits());
+  }
+  m = group_umax(m, 6);  // the whole wave
+  if ((tid & 63u) == 0u) s_m[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0u) {
+    m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+    float* dst = a.absmax + (int64_t)g * a.T + t;
+    float v = Vec8<IDT>::bits_to_f32(m);
+    if (accumulate) v = fmaxf(v, *dst);
+    *dst = v;
+  }
+}
+constexpr int64_t kFewTokens = 2;  // T <= this: absmax_fewtokens_k instead of the tile walk's atomics (phase 1 only)
+
 // Can the one-wave tile kernels over 8-row groups (quant_tile_k PHASE 1 / 2) serve this call? bits = 0: the abs-max phase
 // alone (no store side to check).
 static bool split_tile_ok(int bits, const void* in_base, const void* const* in_ptrs, const kvq_strides_t* in_st, int in_dtype,
@@ -1494,7 +1536,8 @@ static int split_phase(const char* name, int bits, const void* in_base, const vo
     ta.T = (uint32_t)d->T;
     ta.rows = (uint32_t)Rt;
     ta.eps = eps;
-    if (PHASE == 1 && !accumulate && hipMemsetAsync(absmax, 0, sizeof(float) * (size_t)(d->G * d->T), st) != hipSuccess) return check_launch(name);
+    const bool few = PHASE == 1 && d->T <= kFewTokens && Rt > 8 && tunables().quant_few_tokens != 0;  // one workgroup per (group, token), no atomics
+    if (PHASE == 1 && !few && !accumulate && hipMemsetAsync(absmax, 0, sizeof(float) * (size_t)(d->G * d->T), st) != hipSuccess) return check_launch(name);
     for (int64_t g0 = 0; g0 < d->G; g0 += kPtrsPerLaunch) {
       const int64_t gn = d->G - g0 < kPtrsPerLaunch ? d->G - g0 : kPtrsPerLaunch;
       for (int64_t i = 0; i < gn; ++i)
@@ -1502,6 +1545,21 @@ static int split_phase(const char* name, int bits, const void* in_base, const vo
       ta.absmax = absmax + g0 * d->T;
       ta.q = PHASE == 2 ? q + g0 * a.qs.g : nullptr;
       ta.scales = PHASE == 2 ? scales + g0 * ssg : nullptr;
+      if constexpr (PHASE == 1) {
+        if (few) {
+          const dim3 fgrid((unsigned)d->T, (unsigned)gn);
+          if (d->D == 128) {
+            if (in_dtype == KVQ_F16) KVQ_LAUNCH((absmax_fewtokens_k<KVQ_F16, 16>), fgrid, dim3(kBlock), 0, st, ta, accumulate ? 1 : 0);
+            else KVQ_LAUNCH((absmax_fewtokens_k<KVQ_BF16, 16>), fgrid, dim3(kBlock), 0, st, ta, accumulate ? 1 : 0);
+          } else {
+            if (in_dtype == KVQ_F16) KVQ_LAUNCH((absmax_fewtokens_k<KVQ_F16, 8>), fgrid, dim3(kBlock), 0, st, ta, accumulate ? 1 : 0);
+            else KVQ_LAUNCH((absmax_fewtokens_k<KVQ_BF16, 8>), fgrid, dim3(kBlock), 0, st, ta, accumulate ? 1 : 0);
+          }
+          const int rcf = check_launch(name);
+          if (rcf) return rcf;
+          continue;
+        }
+      }
       const dim3 grid((unsigned)((d->T + tt - 1) / tt), (unsigned)gn, (unsigned)((Rt + 7) / 8));
 #define KVQ_PH(IDT_, BITS_, DV_, TT_) KVQ_LAUNCH((quant_tile_k<IDT_, BITS_, 8, DV_, TT_, PHASE>), grid, dim3(kWave), 0, st, ta)
 #if KVQ_AB

@@ -327,3 +327,45 @@ def test_small_tables_are_exchanged_whole():
     assert sharding.kv_joint_table_ok(32, 1) and sharding.kv_joint_table_ok(64, 32)
     assert not sharding.kv_joint_table_ok(65, 1) and not sharding.kv_joint_table_ok(32, 16384)
     assert 2 * 32 * 64 * 4 <= sharding.SMALL_TABLE_BYTES < 32 * 512 * 4  # a 512-token prefill chunk keeps its layer-chunk pipeline
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(6, 5, 8, 1, 128), (64, 8, 8, 1, 128), (3, 64, 8, 2, 128), (130, 3, 8, 1, 128), (2, 1, 16, 1, 128)])
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_absmax_of_a_decode_append_takes_one_workgroup_per_group_and_token(shape, dtype):
+    """kvq_absmax_tokens on a slice of one or two tokens (a batch-sharded decode append): `absmax_fewtokens_k` — one 256-thread
+    workgroup per (group, token), a plain store — instead of rows / 8 one-wave workgroups that all atomicMax into the same
+    word. Same table bit for bit as the tile walk (knob quant_few_tokens = 0) and as the oracle; `accumulate` keeps what the
+    table holds; three tokens and up, or at most 8 rows, stay on the tile walk."""
+    from efficient_llm_inference_amd import _lib
+    from efficient_llm_inference_amd import kernels as K
+    G, B, H, T, D = shape
+    x = seeded_kv(shape, dtype, seed=5, dist="heavy")
+    xt = to_torch(x, dtype)
+    ref = O.absmax_tokens(x, odt(dtype))
+    tables = {}
+    for knob in (1, 0):
+        _lib.set_tunable("quant_few_tokens", knob)
+        try:
+            _lib.kernel_log_clear()
+            got = K.absmax_tokens(xt)
+            torch.cuda.synchronize()
+            log = _lib.kernel_log()
+            tables[knob] = got
+            assert np.array_equal(to_numpy(got).view(np.uint32), np.asarray(ref, dtype=np.float32).view(np.uint32)), (knob, log)
+            assert log[0].startswith("absmax_fewtokens_k<" if knob == 1 and B * H > 8 else "quant_tile_k<"), (knob, log)
+            # accumulate: the table already holds values (another chunk's / a larger one): the result is the max with them
+            seeded = torch.full_like(got, 0.125)
+            seeded[::2] = 1e9
+            K.absmax_tokens(xt, seeded, accumulate=True)
+            want = torch.maximum(got, torch.full_like(got, 0.125))
+            want[::2] = 1e9
+            assert torch.equal(seeded, want), knob
+        finally:
+            _lib.set_tunable("quant_few_tokens", 1)
+    assert torch.equal(tables[0], tables[1])
+    # three tokens: the tile walk
+    x3 = to_torch(seeded_kv((2, 4, 8, 3, 128), dtype, seed=6), dtype)
+    _lib.kernel_log_clear()
+    K.absmax_tokens(x3)
+    assert _lib.kernel_log()[0].startswith("quant_tile_k<"), _lib.kernel_log()

@@ -37,6 +37,8 @@ if [ "${PART:-all}" = "all" ] || [ "$PART" = "stats" ]; then
   stats attn_llama2_7b_b8 --steps 30 --warmup 5 --workload llama2_7b_decode_attn_seq4k_b8
   stats shape_gpt2m --steps 24 --warmup 2 --workload shape:gpt2m_int4_seq4k
   stats shape_gpt2 --steps 24 --warmup 2 --workload shape:gpt2_shape_seq32k
+  stats shardq_prefill512 --steps 20 --warmup 5 --workload llama3_8b_batch64_sharded_prefill512
+  stats shardq_append --steps 200 --warmup 20 --workload llama3_8b_batch64_sharded_append
 fi
 if [ "${PART:-all}" = "all" ] || [ "$PART" = "pmc" ]; then
   echo "== pmc traffic" | tee -a $O/progress.txt
