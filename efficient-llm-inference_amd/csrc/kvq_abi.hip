@@ -79,7 +79,7 @@ Tunables& tunables() {
     d.pool_block = 64;
     d.pool_wave = 1;
     d.gather_rows = 1;
-    d.quant_few_tokens = 1;
+    d.quant_few_tokens = 16;  // measured crossover against the tile walk: profiles/r04aa_absmax_few_tokens_sweep.jsonl
     d.quant_block = 64;
     d.quant_nv = 8;
     d.attn_mfma_min_nq = 1;

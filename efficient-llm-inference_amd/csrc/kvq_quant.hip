@@ -1099,13 +1099,15 @@ static void launch_quant(const QuantArgs& a, bool fused, hipStream_t st) {
   }
 }
 
-// PHASE 1 for a slice of very few tokens (a batch-sharded DECODE APPEND: T = 1). The tile walk gives every 8-row group its own
+// PHASE 1 for a slice of few tokens (a batch-sharded DECODE APPEND: T = 1; up to tunables().quant_few_tokens = 16). The tile walk gives every 8-row group its own
 // one-wave workgroup, and all rows / 8 of them end in an atomicMax on the SAME word of the table: device-scope atomics from
 // eight XCDs on one address are served one after the other — 21.5 us for the 8.4 MB of a batch-64 K + V append of 64 tensors
 // (rocprofv3: profiles/r04z_rocprofv3_kernel_stats_shardq_append.csv, quant_tile_k<..., 1>). Here ONE 256-thread workgroup
 // owns a (group, token): 256 / DV rows per pass, 8 independent 16-byte loads per thread in flight, LDS across its 4 waves,
 // then ONE plain store — or a plain max with the word when the caller accumulates (no other workgroup of the launch touches
 // it) — no atomics, and no memset launch in front. The maximum does not depend on the order: same table, bit for bit.
+// Against the tile walk on [64, 64, 8, T, 128] fp16 (profiles/r04aa_absmax_few_tokens_sweep.jsonl): T = 1 4.3 vs 21.2 us, 2: 4.3 vs
+// 11.6, 4: 7.9 vs 10.3, 8: 10.7 vs 13.0, 16: 20.9 vs 21.1, 32: 47.2 vs 48.9, 64: 94.4 vs 90.1 — the default threshold is 16.
 template <int IDT, int DV>
 __global__ __launch_bounds__(kBlock) void absmax_fewtokens_k(const QuantTileArgs a, const int accumulate) {
   static_assert(IDT != KVQ_F32, "two-byte inputs");
@@ -1139,7 +1141,6 @@ __global__ __launch_bounds__(kBlock) void absmax_fewtokens_k(const QuantTileArgs
     *dst = v;
   }
 }
-constexpr int64_t kFewTokens = 2;  // T <= this: absmax_fewtokens_k instead of the tile walk's atomics (phase 1 only)
 
 // Can the one-wave tile kernels over 8-row groups (quant_tile_k PHASE 1 / 2) serve this call? bits = 0: the abs-max phase
 // alone (no store side to check).
@@ -1536,7 +1537,7 @@ static int split_phase(const char* name, int bits, const void* in_base, const vo
     ta.T = (uint32_t)d->T;
     ta.rows = (uint32_t)Rt;
     ta.eps = eps;
-    const bool few = PHASE == 1 && d->T <= kFewTokens && Rt > 8 && tunables().quant_few_tokens != 0;  // one workgroup per (group, token), no atomics
+    const bool few = PHASE == 1 && d->T <= tunables().quant_few_tokens && Rt > 8;  // one workgroup per (group, token), no atomics
     if (PHASE == 1 && !few && !accumulate && hipMemsetAsync(absmax, 0, sizeof(float) * (size_t)(d->G * d->T), st) != hipSuccess) return check_launch(name);
     for (int64_t g0 = 0; g0 < d->G; g0 += kPtrsPerLaunch) {
       const int64_t gn = d->G - g0 < kPtrsPerLaunch ? d->G - g0 : kPtrsPerLaunch;

@@ -330,13 +330,13 @@ def test_small_tables_are_exchanged_whole():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(6, 5, 8, 1, 128), (64, 8, 8, 1, 128), (3, 64, 8, 2, 128), (130, 3, 8, 1, 128), (2, 1, 16, 1, 128)])
+@pytest.mark.parametrize("shape", [(6, 5, 8, 1, 128), (64, 8, 8, 1, 128), (3, 64, 8, 2, 128), (130, 3, 8, 1, 128), (2, 1, 16, 1, 128), (3, 5, 8, 16, 128), (2, 9, 3, 7, 128)])
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 def test_absmax_of_a_decode_append_takes_one_workgroup_per_group_and_token(shape, dtype):
-    """kvq_absmax_tokens on a slice of one or two tokens (a batch-sharded decode append): `absmax_fewtokens_k` — one 256-thread
+    """kvq_absmax_tokens on a slice of few tokens (a batch-sharded decode append: one; the default threshold is 16): `absmax_fewtokens_k` — one 256-thread
     workgroup per (group, token), a plain store — instead of rows / 8 one-wave workgroups that all atomicMax into the same
     word. Same table bit for bit as the tile walk (knob quant_few_tokens = 0) and as the oracle; `accumulate` keeps what the
-    table holds; three tokens and up, or at most 8 rows, stay on the tile walk."""
+    table holds; more than 16 tokens, or at most 8 rows, stay on the tile walk."""
     from efficient_llm_inference_amd import _lib
     from efficient_llm_inference_amd import kernels as K
     G, B, H, T, D = shape
@@ -344,7 +344,7 @@ def test_absmax_of_a_decode_append_takes_one_workgroup_per_group_and_token(shape
     xt = to_torch(x, dtype)
     ref = O.absmax_tokens(x, odt(dtype))
     tables = {}
-    for knob in (1, 0):
+    for knob in (16, 0):
         _lib.set_tunable("quant_few_tokens", knob)
         try:
             _lib.kernel_log_clear()
@@ -353,7 +353,7 @@ def test_absmax_of_a_decode_append_takes_one_workgroup_per_group_and_token(shape
             log = _lib.kernel_log()
             tables[knob] = got
             assert np.array_equal(to_numpy(got).view(np.uint32), np.asarray(ref, dtype=np.float32).view(np.uint32)), (knob, log)
-            assert log[0].startswith("absmax_fewtokens_k<" if knob == 1 and B * H > 8 else "quant_tile_k<"), (knob, log)
+            assert log[0].startswith("absmax_fewtokens_k<" if knob and B * H > 8 else "quant_tile_k<"), (knob, log)
             # accumulate: the table already holds values (another chunk's / a larger one): the result is the max with them
             seeded = torch.full_like(got, 0.125)
             seeded[::2] = 1e9
@@ -362,10 +362,10 @@ def test_absmax_of_a_decode_append_takes_one_workgroup_per_group_and_token(shape
             want[::2] = 1e9
             assert torch.equal(seeded, want), knob
         finally:
-            _lib.set_tunable("quant_few_tokens", 1)
-    assert torch.equal(tables[0], tables[1])
-    # three tokens: the tile walk
-    x3 = to_torch(seeded_kv((2, 4, 8, 3, 128), dtype, seed=6), dtype)
+            _lib.set_tunable("quant_few_tokens", 16)
+    assert torch.equal(tables[0], tables[16])
+    # past the threshold: the tile walk
+    x3 = to_torch(seeded_kv((2, 4, 8, 17, 128), dtype, seed=6), dtype)
     _lib.kernel_log_clear()
     K.absmax_tokens(x3)
     assert _lib.kernel_log()[0].startswith("quant_tile_k<"), _lib.kernel_log()
