@@ -1012,3 +1012,58 @@ def test_one_pass_decode_step_with_a_device_side_token_count(K, tunable, shape, 
         assert np.array_equal(to_numpy(k_store[:, :, :T + 1]), kq[0][:, :, :T + 1]) and np.array_equal(to_numpy(v_store[:, :, :T + 1]), vq[0][:, :, :T + 1]), T
         assert np.array_equal(to_numpy(k_sc[:T + 1]), ks[0][:T + 1]) and np.array_equal(to_numpy(v_sc[:T + 1]), vs[0][:T + 1])
         assert int((k_store[:, :, T + 1:] != 9).sum()) == 0 and float((k_sc[T + 1:] + 1.0).abs().sum()) == 0.0
+
+
+# ---------------------------------------------------------------------------- new-token slices past the register path
+
+@pytest.mark.parametrize("shape", [(16, 32, 8, 300, 128), (64, 8, 8, 130, 128), (33, 12, 12, 77, 64), (9, 16, 8, 200, 128)])
+@pytest.mark.parametrize("kinds", [("int8", "int4"), ("int4", "int8")])
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_decode_step_appends_a_large_batch_with_several_workgroups(K, tunable, shape, kinds, dtype):
+    """kvq_decode_step / kvq_decode_step_dev with a new-token slice of more than 8,192 elements (batch > 8 at 8 kv heads x 128):
+    `quant_new_token_parts` — one workgroup per 8,192 elements, each taking the abs-max of the WHOLE slice and quantising its own
+    piece — instead of ONE workgroup walking the slice element by element (158 us per layer at batch 64). Slot T and its scale
+    bit-exact with the oracle's quantiser and with the one-workgroup routine (knob attn_new_token_parts = 0), nothing else
+    touched, attention within tolerance; host-side and device-side token count."""
+    B, Hq, Hkv, T, D = shape
+    rng = np.random.default_rng(B * 131 + T)
+    mk = (lambda s: O.f32_to_bf16_bits(rng.standard_normal(s).astype(np.float32))) if dtype == "bf16" else (lambda s: rng.standard_normal(s).astype(np.float16))
+    k, v = mk((1, B, Hkv, T + 1, D)), mk((1, B, Hkv, T + 1, D))
+    odt_ = "bf16" if dtype == "bf16" else None
+    kq, _, ks = O.quantize_tokens(k, kinds[0], dtype=odt_)
+    vq, _, vs = O.quantize_tokens(v, kinds[1], dtype=odt_)
+    q = mk((B, Hq, D))
+    sm = D ** -0.5
+    ref = O.decode_attention(_as_f32(q, dtype), kq[0][:, :, :T], ks[0][:T], kinds[0], vq[0][:, :, :T], vs[0][:T], kinds[1], D, sm,
+                             _as_f32(k[0][:, :, T], dtype), _as_f32(v[0][:, :, T], dtype), kv_dtype=dtype)
+    cap = T + 5
+    qt = to_torch(q, dtype)
+    kn, vn = to_torch(np.ascontiguousarray(k[0][:, :, T]), dtype), to_torch(np.ascontiguousarray(v[0][:, :, T]), dtype)
+    ws = torch.empty(K.decode_attn_workspace_cap(B, Hq, Hkv, cap, D), dtype=torch.float32, device="cuda")
+    t_dev = torch.full((1,), T, dtype=torch.int32, device="cuda")
+    stores = {}
+    for knob, dev_side in ((1, False), (1, True), (0, False)):
+        tunable("attn_new_token_parts", knob)
+        k_store = torch.full((B, Hkv, cap, kq.shape[-1]), 9, dtype=K.QDTYPE[kinds[0]], device="cuda")
+        v_store = torch.full((B, Hkv, cap, vq.shape[-1]), 9, dtype=K.QDTYPE[kinds[1]], device="cuda")
+        k_sc = torch.full((cap,), -1.0, device="cuda")
+        v_sc = torch.full((cap,), -1.0, device="cuda")
+        k_store[:, :, :T] = to_torch(kq[0][:, :, :T])
+        v_store[:, :, :T] = to_torch(vq[0][:, :, :T])
+        k_sc[:T] = to_torch(ks[0][:T])
+        v_sc[:T] = to_torch(vs[0][:T])
+        out = torch.full_like(qt, float("nan"))
+        plan = K.DecodeStepPlan(qt, k_store, k_sc, kinds[0], v_store, v_sc, kinds[1], 1e-8)
+        if dev_side:
+            K.decode_step_dev(plan, qt, kn, vn, t_dev, T + 2, out, ws, sm)
+        else:
+            K.decode_step(plan, qt, kn, vn, T, out, ws, sm)
+        torch.cuda.synchronize()
+        got = _as_f32(to_numpy(out), dtype).astype(np.float64)
+        assert np.isfinite(got).all() and (np.abs(got - ref) <= TOL[dtype] * (np.abs(ref) + np.abs(ref).max())).all(), (knob, dev_side)
+        assert np.array_equal(to_numpy(k_store[:, :, :T + 1]), kq[0]) and np.array_equal(to_numpy(v_store[:, :, :T + 1]), vq[0]), (knob, dev_side)
+        assert np.array_equal(to_numpy(k_sc[:T + 1]), ks[0]) and np.array_equal(to_numpy(v_sc[:T + 1]), vs[0]), (knob, dev_side)
+        assert int((k_store[:, :, T + 1:] != 9).sum()) == 0 and int((v_store[:, :, T + 1:] != 9).sum()) == 0
+        assert float((k_sc[T + 1:] + 1.0).abs().sum()) == 0.0 and float((v_sc[T + 1:] + 1.0).abs().sum()) == 0.0
+        stores[(knob, dev_side)] = (k_store, v_store)
+    assert torch.equal(stores[(1, False)][0], stores[(0, False)][0]) and torch.equal(stores[(1, False)][1], stores[(0, False)][1])
