@@ -391,7 +391,7 @@ def test_decode_attn_fused_workspace_reuse(K, tunable, shape):
 
 @pytest.mark.parametrize("lds", [-1, pytest.param(0, marks=pytest.mark.ab)])  # 0 (A-B library): the register-staged kernel
 @pytest.mark.parametrize("tc", [64, pytest.param(32, marks=pytest.mark.ab)])
-@pytest.mark.parametrize("tpw", [pytest.param(1, marks=pytest.mark.ab), 2, pytest.param(3, marks=pytest.mark.ab), 5])  # shipped library: 1 / 3 tiles per wave are test_decode_attn_lds_staged_kernel's
+@pytest.mark.parametrize("tpw", [pytest.param(1, marks=pytest.mark.ab), pytest.param(2, marks=pytest.mark.ab), pytest.param(3, marks=pytest.mark.ab), 5])  # shipped library: 1 / 3 / 9 tiles per wave are test_decode_attn_lds_staged_kernel's, 5 runs here (2 with the A-B suite)
 def test_decode_attn_streaming_kernel_matches_oracle(K, tunable, tc, tpw, lds):
     """decode_attn_stream_mfma_k (one wave walks `tpw` tiles with the next tile's rows in flight, online
     softmax across tiles): forced on small shapes through the tunables — odd / even tile counts per wave, a
@@ -1016,9 +1016,13 @@ def test_one_pass_decode_step_with_a_device_side_token_count(K, tunable, shape, 
 
 # ---------------------------------------------------------------------------- new-token slices past the register path
 
-@pytest.mark.parametrize("shape", [(16, 32, 8, 300, 128), (64, 8, 8, 130, 128), (33, 12, 12, 77, 64), (9, 16, 8, 200, 128)])
-@pytest.mark.parametrize("kinds", [("int8", "int4"), ("int4", "int8")])
-@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("shape,kinds,dtype", [
+    ((16, 32, 8, 300, 128), ("int8", "int4"), "f16"),   # 2 pieces per slice
+    ((64, 8, 8, 130, 128), ("int8", "int4"), "f16"),    # 8 pieces: the 65,536-element bound of the fused append
+    ((64, 8, 8, 130, 128), ("int4", "int8"), "bf16"),
+    ((33, 12, 12, 77, 64), ("int4", "int8"), "f16"),    # head_dim 64, 12 heads: pieces that end inside a row walk step
+    ((9, 16, 8, 200, 128), ("int8", "int8"), "bf16"),   # 9,216 elements: just past the register path
+])
 def test_decode_step_appends_a_large_batch_with_several_workgroups(K, tunable, shape, kinds, dtype):
     """kvq_decode_step / kvq_decode_step_dev with a new-token slice of more than 8,192 elements (batch > 8 at 8 kv heads x 128):
     `quant_new_token_parts` — one workgroup per 8,192 elements, each taking the abs-max of the WHOLE slice and quantising its own

@@ -330,8 +330,8 @@ def test_small_tables_are_exchanged_whole():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(6, 5, 8, 1, 128), (64, 8, 8, 1, 128), (3, 64, 8, 2, 128), (130, 3, 8, 1, 128), (2, 1, 16, 1, 128), (3, 5, 8, 16, 128), (2, 9, 3, 7, 128)])
-@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("shape,dtype", [((6, 5, 8, 1, 128), "f16"), ((64, 8, 8, 1, 128), "bf16"), ((3, 64, 8, 2, 128), "f16"), ((130, 3, 8, 1, 128), "f16"),
+                                         ((2, 1, 16, 1, 128), "bf16"), ((3, 5, 8, 16, 128), "f16"), ((2, 9, 3, 7, 128), "bf16")])
 def test_absmax_of_a_decode_append_takes_one_workgroup_per_group_and_token(shape, dtype):
     """kvq_absmax_tokens on a slice of few tokens (a batch-sharded decode append: one; the default threshold is 16): `absmax_fewtokens_k` — one 256-thread
     workgroup per (group, token), a plain store — instead of rows / 8 one-wave workgroups that all atomicMax into the same
