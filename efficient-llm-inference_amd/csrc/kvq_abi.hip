@@ -79,6 +79,7 @@ Tunables& tunables() {
     d.pool_block = 64;
     d.pool_wave = 1;
     d.gather_rows = 1;
+    d.attn_ring_dev = 1;
     d.attn_new_token_parts = 1;
     d.quant_few_tokens = 16;  // measured crossover against the tile walk: profiles/r04aa_absmax_few_tokens_sweep.jsonl
     d.quant_block = 64;
@@ -115,6 +116,7 @@ static const TunableKey kTunableKeys[] = {
     {"quant_block", &Tunables::quant_block, false},
     {"pool_wave", &Tunables::pool_wave, false},
     {"gather_rows", &Tunables::gather_rows, false},
+    {"attn_ring_dev", &Tunables::attn_ring_dev, false},
     {"attn_new_token_parts", &Tunables::attn_new_token_parts, false},
     {"quant_few_tokens", &Tunables::quant_few_tokens, false},
     {"attn_force_valu", &Tunables::attn_force_valu, false},

@@ -106,6 +106,7 @@ struct Tunables {
   int64_t attn_merge_fast;       // 1 (default) = merge kernel that requests everything up front (<= 256 splits); 0 = the chained one
   int64_t attn_k_i8;             // INT8 keys at head_dim 128: stored bytes straight into v_mfma_i32_16x16x64_i8 (query as two int8 planes): -1 = streaming kernel only (default), 0 = never, 1 = always
   int64_t quant_few_tokens;      // abs-max phase of a slice of at most this many tokens (a sharded decode append: 1): one workgroup per (group, token) and a plain store instead of the tile walk's atomics on one word; 0 = never (tests / A-B)
+  int64_t attn_ring_dev;         // kvq_decode_step_dev (device-side token count) on the LDS-staged ring kernel where the host-side call takes it (1, default); 0 = always one-tile splits, as before round 4
   int64_t attn_new_token_parts;  // decode step, new-token slices past 8,192 elements: one workgroup per 8,192 elements, each taking the whole slice's abs-max (1, default); 0 = the generic one-workgroup routine (tests)
   int64_t attn_onepass;          // A-B: up to 2,048 stored tokens in ONE launch, one 8-wave workgroup per (batch row, kv head), merge from LDS (decode_attn_onepass_k): 0 (default) = never; measured slower (r04x)
   int64_t attn_fold;             // merge inside the LDS-staged kernel's launch (arrival ticket, last wave merges; same bits): 0 (default) = never, 1 = in kvq_decode_step_layers (one memset per host call), 2 = kvq_decode_attn too; measured slower (r04b)

@@ -290,7 +290,7 @@ int64_t kvq_kernel_log(char* buf, int64_t n);
  *   256-thread quantise kernel), "quant_tile" (1 = compile-time one-wave tile kernel where the shape has one, default;
  *   0 = general kernels), "quant_wide" (1 = single-pass 1024-thread register tile for batched slices of 16384 < B*H*D <=
  *   131072 two-byte elements, default; 0 = split phases / swept tile), "quant_block" (general quantise kernel: 64-thread one-wave tiles, default, or 256; 128 in A-B builds), "pool_wave" (1 = one wave per output row where the shape allows, default; 0 = per-lane-group
- *   walk), "gather_rows" (token gather: 1 = 4 KiB work items, one 16-byte piece per thread, default; 0 = the grid-stride kernel), "attn_new_token_parts" (kvq_decode_step with a new-token slice past 8,192 elements: 1 = one workgroup per 8,192 elements, default; 0 = the generic one-workgroup routine), "quant_few_tokens" (kvq_absmax_tokens on slices of at most this many tokens: one workgroup per (group, token) and a plain store; 0 = always the tile walk's atomics), "attn_force_valu" (0/1), "attn_stream_tpw" (tiles per wave of the streaming attention kernel: -1 never,
+ *   walk), "gather_rows" (token gather: 1 = 4 KiB work items, one 16-byte piece per thread, default; 0 = the grid-stride kernel), "attn_ring_dev" (kvq_decode_step_dev on the LDS-staged ring kernel where the host-side call takes it: 1, default; 0 = always one-tile splits), "attn_new_token_parts" (kvq_decode_step with a new-token slice past 8,192 elements: 1 = one workgroup per 8,192 elements, default; 0 = the generic one-workgroup routine), "quant_few_tokens" (kvq_absmax_tokens on slices of at most this many tokens: one workgroup per (group, token) and a plain store; 0 = always the tile walk's atomics), "attn_force_valu" (0/1), "attn_stream_tpw" (tiles per wave of the streaming attention kernel: -1 never,
  *   0 by size, > 0 that many), "attn_lds" (LDS-staged MFMA attention: -1 by shape, 0 never, 1 wherever it applies),
  *   "attn_merge_wave" (merge of <= 16 splits at head_dim 128: 1 = one wave per head, default; 0 = one workgroup per head).
  * A-B keys select variants that lost a measurement and exist only in the A-B library (`make -C csrc ab` ->

@@ -1071,3 +1071,56 @@ def test_decode_step_appends_a_large_batch_with_several_workgroups(K, tunable, s
         assert float((k_sc[T + 1:] + 1.0).abs().sum()) == 0.0 and float((v_sc[T + 1:] + 1.0).abs().sum()) == 0.0
         stores[(knob, dev_side)] = (k_store, v_store)
     assert torch.equal(stores[(1, False)][0], stores[(0, False)][0]) and torch.equal(stores[(1, False)][1], stores[(0, False)][1])
+
+
+# ---------------------------------------------------------------------------- device-side token count on the ring kernel
+
+@pytest.mark.parametrize("shape,kinds", [((8, 32, 8, 128), ("int8", "int4")), ((8, 32, 8, 64), ("int8", "int4")), ((16, 16, 16, 128), ("int8", "int8"))])
+def test_decode_step_dev_on_the_ring_kernel(K, tunable, shape, kinds):
+    """kvq_decode_step_dev at a batch and bound where the host-side call takes the LDS-staged ring kernel: since round 4 the
+    device-side-count call takes it too — every wave derives its tile range from the count (ceil(tiles / nsplit) tiles per wave,
+    waves past the count exit), the merge derives the live splits the same way. For a sweep of counts under ONE bound: the ring
+    kernel is what runs, attention within tolerance of the oracle, slot T quantised bit-exactly, nothing else touched; the
+    knob attn_ring_dev = 0 gives the one-tile splits of before, same tolerance."""
+    from efficient_llm_inference_amd import _lib
+    B, Hq, Hkv, D = shape
+    cap, bound = 3110, 3100
+    rng = np.random.default_rng(Hq * 13 + D)
+    k = rng.standard_normal((1, B, Hkv, cap, D)).astype(np.float16)
+    v = rng.standard_normal((1, B, Hkv, cap, D)).astype(np.float16)
+    kq, _, ks = O.quantize_tokens(k, kinds[0])
+    vq, _, vs = O.quantize_tokens(v, kinds[1])
+    q = rng.standard_normal((B, Hq, D)).astype(np.float16)
+    sm = D ** -0.5
+    qt = to_torch(q)
+    ws = torch.empty(K.decode_attn_workspace_cap(B, Hq, Hkv, cap, D), dtype=torch.float32, device="cuda")
+    ws.fill_(float("nan"))  # stale partials of dead splits must never reach the output
+    t_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+    kq_t, vq_t, ks_t, vs_t = to_torch(kq[0]), to_torch(vq[0]), to_torch(ks[0]), to_torch(vs[0])
+    for knob, counts in ((1, (1, 63, 64, 65, 700, 2049, 3071, 3099)), (0, (65, 3099))):
+        tunable("attn_ring_dev", knob)
+        for T in counts:
+            k_store = torch.full((B, Hkv, cap, kq.shape[-1]), 9, dtype=K.QDTYPE[kinds[0]], device="cuda")
+            v_store = torch.full((B, Hkv, cap, vq.shape[-1]), 9, dtype=K.QDTYPE[kinds[1]], device="cuda")
+            k_sc = torch.full((cap,), -1.0, device="cuda")
+            v_sc = torch.full((cap,), -1.0, device="cuda")
+            k_store[:, :, :T] = kq_t[:, :, :T]
+            v_store[:, :, :T] = vq_t[:, :, :T]
+            k_sc[:T] = ks_t[:T]
+            v_sc[:T] = vs_t[:T]
+            kn, vn = to_torch(k[0][:, :, T].copy()), to_torch(v[0][:, :, T].copy())
+            out = torch.full_like(qt, float("nan"))
+            plan = K.DecodeStepPlan(qt, k_store, k_sc, kinds[0], v_store, v_sc, kinds[1], 1e-8)
+            t_dev.fill_(T)
+            _lib.kernel_log_clear()
+            K.decode_step_dev(plan, qt, kn, vn, t_dev, bound, out, ws, sm)
+            torch.cuda.synchronize()
+            log = _lib.kernel_log()
+            assert log[0].startswith("decode_attn_lds_mfma_k<" if knob else "decode_attn_partial_mfma_k<"), (knob, T, log)
+            ref = O.decode_attention(q, kq[0][:, :, :T], ks[0][:T], kinds[0], vq[0][:, :, :T], vs[0][:T], kinds[1], D, sm,
+                                     k[0][:, :, T].astype(np.float32), v[0][:, :, T].astype(np.float32))
+            got = to_numpy(out).astype(np.float64)
+            assert np.isfinite(got).all() and (np.abs(got - ref) <= TOL["f16"] * (np.abs(ref) + np.abs(ref).max())).all(), (knob, T)
+            assert torch.equal(k_store[:, :, T], kq_t[:, :, T]) and torch.equal(v_store[:, :, T], vq_t[:, :, T]), (knob, T)
+            assert float(k_sc[T]) == float(ks_t[T]) and float(v_sc[T]) == float(vs_t[T])
+            assert int((k_store[:, :, T + 1:] != 9).sum()) == 0 and float((k_sc[T + 1:] + 1.0).abs().sum()) == 0.0
