@@ -31,7 +31,11 @@ SHAPES = [  # name, (L, B, H, T, D), dtype
 
 
 def main():
+    from efficient_llm_inference_amd import _lib
     from efficient_llm_inference_amd import kernels as K
+    for kv in sys.argv[1:]:  # KEY=VALUE tunables (e.g. quant_wide_min=8192)
+        k, v = kv.split("=")
+        _lib.set_tunable(k, int(v))
     dev = torch.device("cuda:0")
     for name, (L, B, H, T, D), dt in SHAPES:
         n = L * B * H * T * D
